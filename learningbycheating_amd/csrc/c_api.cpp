@@ -1,0 +1,125 @@
+// C-ABI entry points (include/lbc_hip.h) over the internal launchers.
+#include "lbc_common.hpp"
+#include "lbc_hip.h"
+
+extern "C" {
+
+const char* lbc_backend(void)
+{
+#ifdef LBC_HIP_EMULATED_FOR_TESTS
+    return "emu-cpu";
+#else
+    return "hip-gfx950";
+#endif
+}
+int lbc_version(void) { return 100; }
+
+static IgemmArgs conv_args(const lbc_conv_desc* d)
+{
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K;
+    a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
+    a.relu = d->relu;
+    return a;
+}
+
+int lbc_conv2d_fwd(const lbc_conv_desc* d, const float* x, const float* w, const float* bias,
+                   const float* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
+                   float* y, float* stats, int* stats_rows, lbc_stream_t stream)
+{
+    LBC_REQUIRE(d, "conv2d_fwd: null desc");
+    IgemmArgs a = conv_args(d);
+    a.OH = (d->H + 2 * d->P - d->KH) / d->S + 1;
+    a.OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
+    a.LH = a.OH; a.LW = a.OW; a.ostep = 1;
+    a.M = d->N * a.OH * a.OW;
+    const int cfg = lbc_igemm_pick(a.M, a.K);
+    if (stats_rows) *stats_rows = lbc_igemm_rows(a, cfg);
+    if (!y) return LBC_OK;   // query only
+    a.x = x; a.w = w; a.y = y; a.bias = bias; a.resid = resid; a.stats = stats;
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
+    return lbc_igemm_launch(a, /*wmajor=*/1, /*mode=*/0, cfg, (hipStream_t)stream);
+}
+
+// dgrad of a Conv2d with geometry d: gathered tensor = dy [N,OH,OW,K], output = dx [N,H,W,C]
+static int conv_dgrad_impl(const lbc_conv_desc* d, const float* dy, const float* w, int wmajor, const float* resid,
+                           const float* bias, const float* pre_scale, const float* pre_shift, int pre_relu,
+                           int relu, float* dx, float* stats, int* stats_rows, hipStream_t s)
+{
+    const int OH = (d->H + 2 * d->P - d->KH) / d->S + 1;
+    const int OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu;
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
+    a.N = d->N; a.H = OH; a.W = OW; a.C = d->K;
+    a.OH = d->H; a.OW = d->W; a.K = d->C;
+    a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
+    a.stats = stats;
+    int rows = 0;
+    if (d->S == 1) {
+        a.LH = a.OH; a.LW = a.OW; a.ostep = 1; a.oy0 = 0; a.ox0 = 0;
+        a.M = d->N * a.LH * a.LW;
+        const int cfg = lbc_igemm_pick(a.M, a.K);
+        rows = lbc_igemm_rows(a, cfg);
+        if (stats_rows) *stats_rows = rows;
+        if (!dx) return LBC_OK;
+        return lbc_igemm_launch(a, wmajor, 1, cfg, s);
+    }
+    // stride 2: one launch per output parity phase
+    LBC_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "dgrad s2: odd spatial size %dx%d", d->H, d->W);
+    a.LH = d->H / 2; a.LW = d->W / 2; a.ostep = 2;
+    a.M = d->N * a.LH * a.LW;
+    const int cfg = lbc_igemm_pick(a.M, a.K);
+    const int per = lbc_igemm_rows(a, cfg);
+    if (stats_rows) *stats_rows = 4 * per;
+    if (!dx) return LBC_OK;
+    for (int ph = 0; ph < 4; ++ph) {
+        a.oy0 = ph >> 1; a.ox0 = ph & 1;
+        a.stat_row0 = ph * per;
+        int rc = lbc_igemm_launch(a, wmajor, 1, cfg, s);
+        if (rc) return rc;
+    }
+    return LBC_OK;
+}
+
+int lbc_conv2d_dgrad(const lbc_conv_desc* d, const float* dy, const float* w, const float* resid,
+                     float* dx, lbc_stream_t stream)
+{
+    LBC_REQUIRE(d, "conv2d_dgrad: null desc");
+    // weights [K][T][C]: depth index (gathered channel) = k is the slow axis -> wmajor 0 with row length C
+    return conv_dgrad_impl(d, dy, w, /*wmajor=*/0, resid, nullptr, nullptr, nullptr, 0, 0, dx, nullptr, nullptr,
+                           (hipStream_t)stream);
+}
+
+// ConvTranspose2d(C->K, 3, 2, 1, 1) forward == dgrad of a Conv2d(K->C, 3, 2, 1) whose weight tensor
+// [C_T][kh][kw][K_T] is exactly the transposed conv's channels_last weight.
+static lbc_conv_desc deconv_as_conv(const lbc_conv_desc* d)
+{
+    lbc_conv_desc c = *d;
+    c.N = d->N; c.H = 2 * d->H; c.W = 2 * d->W; c.C = d->K;   // the conv's input is the deconv's output
+    c.K = d->C;
+    return c;
+}
+
+int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const float* x, const float* w, const float* bias,
+                        const float* pre_scale, const float* pre_shift, int pre_relu,
+                        float* y, float* stats, int* stats_rows, lbc_stream_t stream)
+{
+    LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_fwd: geometry must be k3 s2 p1 op1");
+    lbc_conv_desc c = deconv_as_conv(d);
+    return conv_dgrad_impl(&c, x, w, /*wmajor=*/0, nullptr, bias, pre_scale, pre_shift, pre_relu, d->relu, y, stats,
+                           stats_rows, (hipStream_t)stream);
+}
+
+int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const float* dy, const float* w, float* dx, lbc_stream_t stream)
+{
+    LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_dgrad: geometry must be k3 s2 p1 op1");
+    lbc_conv_desc c = deconv_as_conv(d);
+    c.relu = 0;
+    // forward gather conv over dy with the deconv weight read as [O=C_T][kh][kw][I=K_T]
+    return lbc_conv2d_fwd(&c, dy, w, nullptr, nullptr, nullptr, nullptr, 0, dx, nullptr, nullptr, stream);
+}
+
+}  // extern "C"

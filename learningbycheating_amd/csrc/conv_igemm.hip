@@ -1,0 +1,325 @@
+// Implicit-GEMM convolution for gfx950 (MI355X), fp32 on the exact-f32 MFMA
+// (v_mfma_f32_32x32x2_f32).  One kernel template serves
+//   * nn.Conv2d forward                (reference bird_view/models/resnet.py:15-22,102)
+//   * nn.Conv2d input gradient         (autograd of the same call sites)
+//   * nn.ConvTranspose2d forward       (reference bird_view/models/image.py:39,42,45)
+//   * nn.ConvTranspose2d input gradient
+// No im2col buffer exists anywhere: the A operand (pixels x channels of one
+// filter tap) is gathered straight from the NHWC activation into LDS with
+// 16-byte loads, zero-filled outside the image, optionally with the producing
+// BatchNorm(+ReLU) applied on the fly (pre_scale/pre_shift).
+//
+// Tiling: a 256-thread workgroup (4 waves, 2x2) owns a BM x BN output tile and
+// walks depth in (tap, 32-channel) chunks, double-buffered through LDS with the
+// next chunk's global loads in flight under the current chunk's MFMAs.  LDS rows
+// are padded to 36 floats so ds_read_b128 fragment reads are conflict free.
+// A lane's f32x4 fragment holds channels {4*(l>>5)+i}; MFMA step i therefore
+// contracts the channel pair {i, 4+i} of each 8-channel group -- A and B use the
+// same pairing, so the sum over depth is complete.
+#include "lbc_common.hpp"
+
+namespace {
+
+constexpr int BK = 32;          // channels per depth chunk
+constexpr int LDK = BK + 4;     // padded LDS row (floats) for [row][k] tiles
+
+template <int BM, int BN, bool WMAJOR, int MODE>
+__global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
+{
+    constexpr int WM = 2, WN = 2;
+    constexpr int MT = BM / WM / 32;
+    constexpr int NT = BN / WN / 32;
+    constexpr int RA = BM / 32;            // A rows (float4 loads) per thread per chunk
+    constexpr int RB = BN / 32;            // B float4 loads per thread per chunk
+    constexpr int LDN = BN + 4;            // padded LDS row for [k][n] tiles
+    constexpr int SB = WMAJOR ? BN * LDK : BK * LDN;
+
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) float sB[2][SB];
+    __shared__ int sTap[16];
+    __shared__ int sNTap;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.x * BM;
+    const int n0 = blockIdx.y * BN;
+    const int T = a.KH * a.KW;
+
+    if (tid == 0) {
+        int nt = 0;
+        for (int t = 0; t < T; ++t) {
+            bool ok = true;
+            if (MODE == 1 && a.S == 2) {
+                const int r = t / a.KW, s = t - r * a.KW;
+                ok = (((a.oy0 + a.P - r) & 1) == 0) && (((a.ox0 + a.P - s) & 1) == 0);
+            }
+            if (ok) sTap[nt++] = t;
+        }
+        sNTap = nt;
+    }
+
+    // ---- per-thread A row descriptors -------------------------------------
+    const int seg = tid & 7;
+    const int arow = tid >> 3;
+    int pixbase[RA];
+    int ay[RA], ax[RA];
+#pragma unroll
+    for (int j = 0; j < RA; ++j) {
+        const int m = m0 + arow + 32 * j;
+        if (m < a.M) {
+            const int lhw = a.LH * a.LW;
+            const int n = m / lhw;
+            const int rem = m - n * lhw;
+            const int ly = rem / a.LW;
+            const int lx = rem - ly * a.LW;
+            const int oy = ly * a.ostep + a.oy0;
+            const int ox = lx * a.ostep + a.ox0;
+            pixbase[j] = n * a.H * a.W;
+            if (MODE == 0) { ay[j] = oy * a.S - a.P; ax[j] = ox * a.S - a.P; }
+            else           { ay[j] = oy + a.P;       ax[j] = ox + a.P; }
+        } else {
+            pixbase[j] = 0; ay[j] = -(1 << 20); ax[j] = -(1 << 20);
+        }
+    }
+    __syncthreads();
+    const int ntap = sNTap;
+    const int cpt = a.C / BK;
+    const int nit = ntap * cpt;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[RA], rb[RB];
+
+    auto load_chunk = [&](int it) {
+        const int ti = it / cpt;
+        const int c0 = (it - ti * cpt) * BK;
+        const int tap = sTap[ti];
+        const int r = tap / a.KW, s = tap - r * a.KW;
+        float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (a.pre_scale) {
+            ps = *reinterpret_cast<const float4*>(a.pre_scale + c0 + seg * 4);
+            pt = *reinterpret_cast<const float4*>(a.pre_shift + c0 + seg * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < RA; ++j) {
+            int iy, ix;
+            if (MODE == 0) { iy = ay[j] + r; ix = ax[j] + s; }
+            else if (a.S == 2) { iy = (ay[j] - r) >> 1; ix = (ax[j] - s) >> 1; }
+            else { iy = ay[j] - r; ix = ax[j] - s; }
+            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ok) {
+                const size_t off = (size_t)(pixbase[j] + iy * a.W + ix) * (size_t)a.C + (size_t)(c0 + seg * 4);
+                v = *reinterpret_cast<const float4*>(a.x + off);
+                if (a.pre_scale) {
+                    v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y;
+                    v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w;
+                    if (a.pre_relu) {
+                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                    }
+                }
+            }
+            ra[j] = v;
+        }
+        if (WMAJOR) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int row = arow + 32 * j;
+                const size_t off = (size_t)(n0 + row) * (size_t)(T * a.C) + (size_t)(tap * a.C + c0 + seg * 4);
+                rb[j] = *reinterpret_cast<const float4*>(a.w + off);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int idx = tid + 256 * j;
+                const int krow = idx / (BN / 4);
+                const int s4 = idx - krow * (BN / 4);
+                const size_t off = (size_t)(c0 + krow) * (size_t)(T * a.K) + (size_t)(tap * a.K + n0 + s4 * 4);
+                rb[j] = *reinterpret_cast<const float4*>(a.w + off);
+            }
+        }
+    };
+
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < RA; ++j)
+            *reinterpret_cast<float4*>(&sA[buf][(arow + 32 * j) * LDK + seg * 4]) = ra[j];
+        if (WMAJOR) {
+#pragma unroll
+            for (int j = 0; j < RB; ++j)
+                *reinterpret_cast<float4*>(&sB[buf][(arow + 32 * j) * LDK + seg * 4]) = rb[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                const int idx = tid + 256 * j;
+                const int krow = idx / (BN / 4);
+                const int s4 = idx - krow * (BN / 4);
+                *reinterpret_cast<float4*>(&sB[buf][krow * LDN + s4 * 4]) = rb[j];
+            }
+        }
+    };
+
+    const int l31 = lane & 31;
+    const int kh = lane >> 5;
+
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            f32x4 af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&sA[buf][((wm * MT + i) * 32 + l31) * LDK + g * 8 + kh * 4]);
+            if (WMAJOR) {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bf[j] = *reinterpret_cast<const f32x4*>(&sB[buf][((wn * NT + j) * 32 + l31) * LDK + g * 8 + kh * 4]);
+            } else {
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        bf[j][i] = sB[buf][(g * 8 + kh * 4 + i) * LDN + (wn * NT + j) * 32 + l31];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int nj = 0; nj < NT; ++nj)
+                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][i], bf[nj][i], acc[mi][nj], 0, 0, 0);
+        }
+    };
+
+    if (nit > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int it = 0; it < nit; ++it) {
+        const bool more = (it + 1 < nit);
+        if (more) load_chunk(it + 1);
+        compute(it & 1);
+        if (more) store_chunk((it + 1) & 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ------------------------------------------------------------
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int m = m0 + row;
+            if (m < a.M) {
+                size_t obase;
+                if (MODE == 0 && a.ostep == 1) {
+                    obase = (size_t)m * (size_t)a.K;
+                } else {
+                    const int lhw = a.LH * a.LW;
+                    const int n = m / lhw;
+                    const int rem = m - n * lhw;
+                    const int ly = rem / a.LW;
+                    const int lx = rem - ly * a.LW;
+                    const int oy = ly * a.ostep + a.oy0;
+                    const int ox = lx * a.ostep + a.ox0;
+                    obase = ((size_t)(n * a.OH + oy) * (size_t)a.OW + (size_t)ox) * (size_t)a.K;
+                }
+#pragma unroll
+                for (int nj = 0; nj < NT; ++nj) {
+                    const int col = n0 + (wn * NT + nj) * 32 + l31;
+                    float v = acc[mi][nj][r];
+                    if (a.bias) v += a.bias[col];
+                    if (a.resid) v += a.resid[obase + col];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    a.y[obase + col] = v;
+                    s1[nj] += v;
+                    s2[nj] += v * v;
+                }
+            }
+        }
+    }
+
+    if (a.stats) {
+        // combine the two half-waves (rows 4*kh+...), then the two M-waves through LDS
+        float* red = &sA[0][0];   // [WM][2][BN]; the main loop's last barrier has passed
+#pragma unroll
+        for (int nj = 0; nj < NT; ++nj) {
+            s1[nj] += __shfl_xor(s1[nj], 32);
+            s2[nj] += __shfl_xor(s2[nj], 32);
+        }
+        if (kh == 0) {
+#pragma unroll
+            for (int nj = 0; nj < NT; ++nj) {
+                const int c = (wn * NT + nj) * 32 + l31;
+                red[(wm * 2 + 0) * BN + c] = s1[nj];
+                red[(wm * 2 + 1) * BN + c] = s2[nj];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+            float* dst = a.stats + (size_t)(a.stat_row0 + blockIdx.x) * 2 * (size_t)a.K;
+            dst[n0 + tid] = t1;
+            dst[a.K + n0 + tid] = t2;
+        }
+    }
+}
+
+template <int BM, int BN>
+int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
+{
+    dim3 grid((unsigned)lbc_cdiv(a.M, BM), (unsigned)(a.K / BN));
+    if (wmajor && mode == 0)      hipLaunchKernelGGL((conv_igemm_f32<BM, BN, true, 0>), grid, dim3(256), 0, s, a);
+    else if (wmajor && mode == 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, true, 1>), grid, dim3(256), 0, s, a);
+    else if (!wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, false, 0>), grid, dim3(256), 0, s, a);
+    else                          hipLaunchKernelGGL((conv_igemm_f32<BM, BN, false, 1>), grid, dim3(256), 0, s, a);
+    return lbc_check_launch("conv_igemm_f32");
+}
+
+const int kCfgBM[3] = {128, 128, 64};
+const int kCfgBN[3] = {64, 128, 64};
+
+}  // namespace
+
+int lbc_igemm_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kCfgBM[cfg]); }
+
+int lbc_igemm_pick(long long M, int K)
+{
+    // Prefer the largest tile that still gives the 256 CUs >= 1.5 waves of workgroups.
+    const long long want = 384;
+    if (K % 128 == 0 && ((M + 127) / 128) * (K / 128) >= want) return 1;
+    if (((M + 127) / 128) * (K / 64) >= want) return 0;
+    return 2;
+}
+
+int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s)
+{
+    LBC_REQUIRE(cfg >= 0 && cfg < 3, "igemm: bad cfg %d", cfg);
+    LBC_REQUIRE(a.C % BK == 0, "igemm: gathered channels %d not a multiple of %d", a.C, BK);
+    LBC_REQUIRE(a.K % kCfgBN[cfg] == 0, "igemm: output channels %d not a multiple of tile %d", a.K, kCfgBN[cfg]);
+    LBC_REQUIRE(a.KH * a.KW <= 16, "igemm: too many taps");
+    LBC_REQUIRE(a.S == 1 || a.S == 2, "igemm: stride %d unsupported", a.S);
+    LBC_REQUIRE(a.M > 0, "igemm: empty launch");
+    LBC_REQUIRE((long long)a.N * a.H * a.W * a.C < (1ll << 31) && (long long)a.N * a.OH * a.OW * a.K < (1ll << 31),
+                "igemm: tensor exceeds 2^31 elements");
+    switch (cfg) {
+        case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);
+        case 1: return launch_cfg<128, 128>(a, wmajor, mode, s);
+        default: return launch_cfg<64, 64>(a, wmajor, mode, s);
+    }
+}

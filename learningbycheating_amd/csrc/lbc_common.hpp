@@ -1,0 +1,88 @@
+// Shared declarations for the gfx950 kernels of the LbC sensorimotor hot path.
+// All activations are NHWC fp32 in HBM; conv weights are read in the memory
+// order of a channels_last torch tensor: Conv2d (O,I,kh,kw) -> [O][kh][kw][I],
+// ConvTranspose2d (I,O,kh,kw) -> [I][kh][kw][O].
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+#define LBC_OK 0
+#define LBC_EINVAL (-1)
+#define LBC_ELAUNCH (-2)
+#define LBC_ESTATE (-3)
+
+void lbc_set_error(const char* fmt, ...);
+int lbc_check_launch(const char* what);
+
+#define LBC_REQUIRE(cond, ...)                 \
+    do {                                       \
+        if (!(cond)) {                         \
+            lbc_set_error(__VA_ARGS__);        \
+            return LBC_EINVAL;                 \
+        }                                      \
+    } while (0)
+
+static inline int lbc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------
+// Implicit-GEMM convolution (conv_igemm.hip).
+//   rows    m = (n, ly, lx) over a lattice of output pixels
+//   columns k = output channel
+//   depth     = (tap, c) over the gathered tensor's channels
+// mode 0 (gather):      iy = oy*S + r - P                 (Conv2d forward,
+//                                                          ConvTranspose2d dgrad)
+// mode 1 (transposed):  iy = (oy + P - r)/S when divisible (Conv2d dgrad,
+//                                                          ConvTranspose2d forward);
+//                       for S==2 one launch per output parity phase.
+// wmajor 1: w[k][tap][c] (depth-contiguous), wmajor 0: w[c][tap][k].
+// ---------------------------------------------------------------------------
+struct IgemmArgs {
+    const float* x;       // gathered tensor, NHWC [N][H][W][C]
+    const float* w;
+    float* y;             // NHWC [N][OH][OW][K]
+    const float* bias;    // [K] or nullptr
+    const float* resid;   // like y (may alias y) or nullptr; added before relu
+    float* stats;         // [rows][2][K] per-block (sum, sum of squares) of the stored value, or nullptr
+    // fused BatchNorm-on-load of x (per gathered channel): x' = relu?(x*ps[c] + pt[c]); nullptr = identity
+    const float* pre_scale;
+    const float* pre_shift;
+    int pre_relu;
+    int N, H, W, C;
+    int OH, OW, K;
+    int KH, KW, S, P;
+    int M;                // rows handled by this launch
+    int LH, LW;           // lattice extents; pixel = (ly*ostep + oy0, lx*ostep + ox0)
+    int oy0, ox0, ostep;
+    int relu;
+    int stat_row0;
+};
+
+int lbc_igemm_rows(const IgemmArgs& a, int cfg);   // number of M tiles (= stats rows) of a launch
+int lbc_igemm_pick(long long M, int K);
+int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s);
+
+// Weight-gradient GEMM (conv_wgrad.hip):
+//   out[p][tap][q] = sum_m  P[m][p] * Q[gather(m, tap)][q]
+// P rows m = (n, oy, ox) dense NHWC [N][OH][OW][CP]; Q NHWC [N][H][W][CQ] gathered at
+// (oy*S + r - P, ox*S + s - P).  Split over m into `nsplit` partial slabs which
+// lbc_splitk_reduce sums in a fixed order (deterministic).
+struct WgradArgs {
+    const float* p;
+    const float* q;
+    float* partial;       // [nsplit][CP][T][CQ]
+    // optional fused transform of q on load (BatchNorm apply [+relu]) per q channel
+    const float* q_scale;
+    const float* q_shift;
+    int q_relu;
+    int N, OH, OW, CP;
+    int H, W, CQ;
+    int KH, KW, S, P;
+    int nsplit;
+};
+int lbc_wgrad_pick_split(const WgradArgs& a);
+int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s);
+int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* out, float beta, hipStream_t s);

@@ -1,0 +1,225 @@
+// TEST INFRASTRUCTURE ONLY -- never part of the product path.
+//
+// A CPU emulation of the handful of HIP device-side constructs that
+// learningbycheating_amd/csrc/*.hip uses, so that the *unmodified* kernel
+// sources can be compiled with the host clang++ (this directory shadows
+// <hip/hip_runtime.h>) and their indexing / masking / MFMA-fragment logic can
+// be exercised on a machine with no GPU.  Every workgroup is run as a set of
+// cooperatively scheduled fibers (one per HIP thread); __syncthreads(), wave
+// shuffles and MFMA are rendezvous points.  The MFMA emulation implements the
+// gfx950 lane<->element maps documented in the CDNA4 guide (A[i=l&31][k=l>>5],
+// B[k=l>>5][j=l&31], D row=(r&3)+8*(r>>2)+4*(l>>5), col=l&31 for 32x32x2f32)
+// with the exact k-ordered fmaf chain of the hardware.
+//
+// The product loader (learningbycheating_amd/_lib.py) only ever loads the real
+// gfx950 library; the emulated library is built and loaded by tests/emu only.
+#pragma once
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+
+#define LBC_HIP_EMULATED_FOR_TESTS 1
+
+// ---- qualifiers -----------------------------------------------------------
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __shared__ static
+#define __launch_bounds__(...)
+#ifndef __restrict__
+#define __restrict__ __restrict
+#endif
+
+// ---- basic types ----------------------------------------------------------
+struct dim3 {
+    unsigned x, y, z;
+    constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct emu_uint3 { unsigned x, y, z; };
+extern emu_uint3 threadIdx, blockIdx;
+extern dim3 blockDim, gridDim;
+
+struct alignas(8) float2 { float x, y; };
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) int2 { int x, y; };
+struct alignas(16) int4 { int x, y, z, w; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+struct alignas(4) uchar4 { unsigned char x, y, z, w; };
+struct alignas(8) ushort4 { unsigned short x, y, z, w; };
+static inline float2 make_float2(float x, float y) { return {x, y}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return {x, y, z, w}; }
+static inline int2 make_int2(int x, int y) { return {x, y}; }
+static inline int4 make_int4(int x, int y, int z, int w) { return {x, y, z, w}; }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return {x, y}; }
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return {x, y, z, w}; }
+static inline ushort4 make_ushort4(unsigned short x, unsigned short y, unsigned short z, unsigned short w) { return {x, y, z, w}; }
+
+typedef int hipError_t;
+typedef struct emu_stream_t* hipStream_t;
+typedef struct emu_event_t* hipEvent_t;
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorUnknown = 999 };
+enum hipMemcpyKind { hipMemcpyHostToHost, hipMemcpyHostToDevice, hipMemcpyDeviceToHost, hipMemcpyDeviceToDevice, hipMemcpyDefault };
+static inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "hipSuccess" : "hipError(emu)"; }
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
+static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
+static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
+static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+
+// ---- fiber runtime (emu_runtime.cpp) ---------------------------------------
+namespace emu {
+void launch(dim3 grid, dim3 block, const std::function<void()>& body);
+void sync_block();
+// Wave rendezvous: returns pointer to the 64-slot exchange area valid until the
+// lane's next rendezvous.  Each lane first writes its own slot of `mine`.
+struct alignas(16) Slot { unsigned char b[64]; };
+Slot* wave_slots_begin();   // slot array (64) this lane must write its slot into
+void wave_rendezvous();     // blocks until all 64 lanes of the wave arrived
+int lane_id();
+}  // namespace emu
+
+template <typename K, typename... Args>
+static inline void emu_launch_kernel(K kernel, dim3 grid, dim3 block, Args... args) {
+    ::emu::launch(grid, block, [&]() { kernel(args...); });
+}
+#define hipLaunchKernelGGL(kernel, grid, block, shmem, stream, ...) \
+    emu_launch_kernel(kernel, dim3(grid), dim3(block), __VA_ARGS__)
+
+static inline void __syncthreads() { emu::sync_block(); }
+
+// ---- wave collectives -------------------------------------------------------
+template <typename T>
+static inline T emu_wave_read(T v, int src_lane) {
+    static_assert(sizeof(T) <= 64, "slot too small");
+    emu::Slot* s = emu::wave_slots_begin();
+    memcpy(s[emu::lane_id()].b, &v, sizeof(T));
+    emu::wave_rendezvous();
+    T r;
+    memcpy(&r, s[src_lane & 63].b, sizeof(T));
+    return r;
+}
+template <typename T> static inline T __shfl_xor(T v, int mask, int width = 64) {
+    int l = emu::lane_id();
+    int src = l ^ mask;
+    if ((src / width) != (l / width)) src = l;
+    return emu_wave_read(v, src);
+}
+template <typename T> static inline T __shfl_down(T v, unsigned d, int width = 64) {
+    int l = emu::lane_id();
+    int src = l + (int)d;
+    if ((src / width) != (l / width)) src = l;
+    return emu_wave_read(v, src);
+}
+template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64) {
+    int l = emu::lane_id();
+    int src = l - (int)d;
+    if (src < 0 || (src / width) != (l / width)) src = l;
+    return emu_wave_read(v, src);
+}
+template <typename T> static inline T __shfl(T v, int src, int width = 64) {
+    int l = emu::lane_id();
+    return emu_wave_read(v, (l / width) * width + (src % width));
+}
+
+// ---- MFMA -------------------------------------------------------------------
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
+typedef short emu_s16x8 __attribute__((ext_vector_type(8)));
+
+static inline emu_f32x16 emu_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
+    struct AB { float a, b; };
+    emu::Slot* s = emu::wave_slots_begin();
+    int l = emu::lane_id();
+    AB me{a, b};
+    memcpy(s[l].b, &me, sizeof(me));
+    emu::wave_rendezvous();
+    emu_f32x16 d = c;
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int k = 0; k < 2; ++k) {
+            AB A, B;
+            memcpy(&A, s[row + 32 * k].b, sizeof(A));   // A[i=row][k] lives in lane row+32k (.a)
+            memcpy(&B, s[col + 32 * k].b, sizeof(B));   // B[k][j=col] lives in lane col+32k (.b)
+            acc = fmaf(A.a, B.b, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x2f32 emu_mfma_f32_32x32x2f32
+
+static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, int, int, int) {
+    struct AB { float a, b; };
+    emu::Slot* s = emu::wave_slots_begin();
+    int l = emu::lane_id();
+    AB me{a, b};
+    memcpy(s[l].b, &me, sizeof(me));
+    emu::wave_rendezvous();
+    emu_f32x4 d = c;
+    int col = l & 15;
+    for (int r = 0; r < 4; ++r) {
+        int row = (l >> 4) * 4 + r;
+        float acc = c[r];
+        for (int k = 0; k < 4; ++k) {
+            AB A, B;
+            memcpy(&A, s[row + 16 * k].b, sizeof(A));
+            memcpy(&B, s[col + 16 * k].b, sizeof(B));
+            acc = fmaf(A.a, B.b, acc);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
+
+static inline float emu_bf16_to_f32(short h) {
+    unsigned u = ((unsigned)(unsigned short)h) << 16;
+    float f;
+    memcpy(&f, &u, 4);
+    return f;
+}
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31], j=0..7.
+static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c, int, int, int) {
+    struct AB { short a[8], b[8]; };
+    emu::Slot* s = emu::wave_slots_begin();
+    int l = emu::lane_id();
+    AB me;
+    for (int j = 0; j < 8; ++j) { me.a[j] = a[j]; me.b[j] = b[j]; }
+    memcpy(s[l].b, &me, sizeof(me));
+    emu::wave_rendezvous();
+    emu_f32x16 d = c;
+    int col = l & 31;
+    for (int r = 0; r < 16; ++r) {
+        int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+        float acc = c[r];
+        for (int kh = 0; kh < 2; ++kh) {
+            AB A, B;
+            memcpy(&A, s[row + 32 * kh].b, sizeof(A));
+            memcpy(&B, s[col + 32 * kh].b, sizeof(B));
+            for (int j = 0; j < 8; ++j) acc += emu_bf16_to_f32(A.a[j]) * emu_bf16_to_f32(B.b[j]);
+        }
+        d[r] = acc;
+    }
+    return d;
+}
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_f32_32x32x16_bf16
+
+// ---- misc device builtins ----------------------------------------------------
+template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+#define __expf(x) expf(x)
+static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
+static inline double rsqrt(double x) { return 1.0 / sqrt(x); }
+static inline float __fdividef(float a, float b) { return a / b; }
+#define __builtin_amdgcn_s_setprio(x) ((void)0)
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_readfirstlane(v) emu_wave_read((v), 0)
