@@ -122,4 +122,73 @@ int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const float* dy, const float* 
     return lbc_conv2d_fwd(&c, dy, w, nullptr, nullptr, nullptr, nullptr, 0, dx, nullptr, nullptr, stream);
 }
 
+
+static WgradArgs conv_wgrad_args(const lbc_conv_desc* d)
+{
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = d->N;
+    a.OH = (d->H + 2 * d->P - d->KH) / d->S + 1;
+    a.OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
+    a.CP = d->K;
+    a.H = d->H; a.W = d->W; a.CQ = d->C;
+    a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
+    a.nsplit = lbc_wgrad_pick_split(a);
+    return a;
+}
+
+size_t lbc_conv2d_wgrad_workspace(const lbc_conv_desc* d)
+{
+    if (!d) return 0;
+    WgradArgs a = conv_wgrad_args(d);
+    return (size_t)a.nsplit * (size_t)a.CP * (size_t)(a.KH * a.KW) * (size_t)a.CQ * sizeof(float);
+}
+
+int lbc_conv2d_wgrad(const lbc_conv_desc* d, const float* x, const float* dy,
+                     const float* pre_scale, const float* pre_shift, int pre_relu,
+                     float* dw, float beta, void* workspace, lbc_stream_t stream)
+{
+    LBC_REQUIRE(d && workspace, "conv2d_wgrad: null desc/workspace");
+    WgradArgs a = conv_wgrad_args(d);
+    a.p = dy; a.q = x; a.partial = (float*)workspace;
+    a.q_scale = pre_scale; a.q_shift = pre_shift; a.q_relu = pre_relu;
+    int rc = lbc_wgrad_launch(a, (hipStream_t)stream);
+    if (rc) return rc;
+    return lbc_splitk_reduce(a.partial, a.nsplit, (long long)a.CP * a.KH * a.KW * a.CQ, dw, beta, (hipStream_t)stream);
+}
+
+// ConvTranspose2d wgrad: dw[c][kh][kw][k] = sum x'[n,iy,ix,c] * dy[n,2iy-1+kh,2ix-1+kw,k]
+// == Conv2d wgrad with P-side = x (dense rows) and Q-side = dy gathered with stride 2.
+static WgradArgs deconv_wgrad_args(const lbc_conv_desc* d)
+{
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = d->N; a.OH = d->H; a.OW = d->W; a.CP = d->C;
+    a.H = 2 * d->H; a.W = 2 * d->W; a.CQ = d->K;
+    a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
+    a.nsplit = lbc_wgrad_pick_split(a);
+    return a;
+}
+
+size_t lbc_deconv3x3s2_wgrad_workspace(const lbc_conv_desc* d)
+{
+    if (!d) return 0;
+    WgradArgs a = deconv_wgrad_args(d);
+    return (size_t)a.nsplit * (size_t)a.CP * 9 * (size_t)a.CQ * sizeof(float);
+}
+
+int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const float* x, const float* dy,
+                          const float* pre_scale, const float* pre_shift, int pre_relu,
+                          float* dw, float beta, void* workspace, lbc_stream_t stream)
+{
+    LBC_REQUIRE(d && workspace, "deconv_wgrad: null desc/workspace");
+    LBC_REQUIRE(pre_scale == nullptr, "deconv_wgrad: fused BN-on-load of the dense operand is not supported; pass the normalised x");
+    (void)pre_shift; (void)pre_relu;
+    WgradArgs a = deconv_wgrad_args(d);
+    a.p = x; a.q = dy; a.partial = (float*)workspace;
+    int rc = lbc_wgrad_launch(a, (hipStream_t)stream);
+    if (rc) return rc;
+    return lbc_splitk_reduce(a.partial, a.nsplit, (long long)a.CP * 9 * a.CQ, dw, beta, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -1,0 +1,231 @@
+// Weight-gradient GEMM for gfx950, fp32 MFMA (v_mfma_f32_32x32x2_f32).
+//   out[p][tap][q] = sum over pixels m of  P[m][p] * Q[gather(m, tap)][q]
+// which is the dW of nn.Conv2d (P = dy, Q = x; reference call sites
+// bird_view/models/resnet.py:15-22,102) and, with the roles of input and output
+// gradient swapped, of nn.ConvTranspose2d (P = x, Q = dy; image.py:39,42,45).
+// The reduction runs over N*OH*OW pixels (up to ~10^6) into a small
+// [CP][T][CQ] result, so the pixel range is split across workgroups; each split
+// writes its own partial slab and lbc_splitk_reduce adds the slabs in a fixed
+// order (deterministic, no atomics).
+//
+// Both operands are pixel-major in HBM (NHWC), i.e. "depth-outer" for this GEMM,
+// so LDS tiles are [pixel][channel] and MFMA fragments are ds_read_b32 reads of
+// 32 consecutive channels (conflict free); one MFMA consumes two pixels.
+#include "lbc_common.hpp"
+
+namespace {
+
+constexpr int BR = 32;   // pixels per chunk
+
+template <int BP, int BQ>
+__global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_split)
+{
+    constexpr int WM = 2, WN = 2;
+    constexpr int MT = BP / WM / 32;
+    constexpr int NT = BQ / WN / 32;
+    constexpr int LP = BP + 4, LQ = BQ + 4;
+    constexpr int RP = BP / 32, RQ = BQ / 32;   // float4 loads per thread per chunk
+
+    __shared__ __attribute__((aligned(16))) float sP[2][BR * LP];
+    __shared__ __attribute__((aligned(16))) float sQ[2][BR * LQ];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    const int split = blockIdx.x;
+    const int qtiles = a.CQ / BQ;
+    const int tp = blockIdx.y / qtiles;
+    const int tq = blockIdx.y - tp * qtiles;
+    const int p0 = tp * BP, q0 = tq * BQ;
+    const int tap = blockIdx.z;
+    const int r = tap / a.KW, s = tap - r * a.KW;
+    const int T = a.KH * a.KW;
+
+    const int M = a.N * a.OH * a.OW;
+    const int mbeg = split * rows_per_split;
+    const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+    const int nchunk = (mend > mbeg) ? (mend - mbeg + BR - 1) / BR : 0;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    float4 rp[RP], rq[RQ];
+
+    auto load_chunk = [&](int ch) {
+        const int mc = mbeg + ch * BR;
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (BP / 4);
+            const int sg = idx - row * (BP / 4);
+            const int m = mc + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < mend) v = *reinterpret_cast<const float4*>(a.p + (size_t)m * (size_t)a.CP + (size_t)(p0 + sg * 4));
+            rp[j] = v;
+        }
+#pragma unroll
+        for (int j = 0; j < RQ; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (BQ / 4);
+            const int sg = idx - row * (BQ / 4);
+            const int m = mc + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < mend) {
+                const int ohw = a.OH * a.OW;
+                const int n = m / ohw;
+                const int rem = m - n * ohw;
+                const int oy = rem / a.OW;
+                const int ox = rem - oy * a.OW;
+                const int iy = oy * a.S + r - a.P;
+                const int ix = ox * a.S + s - a.P;
+                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
+                    const int c = q0 + sg * 4;
+                    v = *reinterpret_cast<const float4*>(a.q + (size_t)((n * a.H + iy) * a.W + ix) * (size_t)a.CQ + (size_t)c);
+                    if (a.q_scale) {
+                        const float4 ps = *reinterpret_cast<const float4*>(a.q_scale + c);
+                        const float4 pt = *reinterpret_cast<const float4*>(a.q_shift + c);
+                        v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y;
+                        v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w;
+                        if (a.q_relu) {
+                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
+                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+                        }
+                    }
+                }
+            }
+            rq[j] = v;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < RP; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (BP / 4);
+            const int sg = idx - row * (BP / 4);
+            *reinterpret_cast<float4*>(&sP[buf][row * LP + sg * 4]) = rp[j];
+        }
+#pragma unroll
+        for (int j = 0; j < RQ; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx / (BQ / 4);
+            const int sg = idx - row * (BQ / 4);
+            *reinterpret_cast<float4*>(&sQ[buf][row * LQ + sg * 4]) = rq[j];
+        }
+    };
+    auto compute = [&](int buf) {
+#pragma unroll
+        for (int st = 0; st < BR / 2; ++st) {
+            const int k = 2 * st + kh;
+            float af[MT], bf[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) af[i] = sP[buf][k * LP + (wm * MT + i) * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < NT; ++j) bf[j] = sQ[buf][k * LQ + (wn * NT + j) * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    if (nchunk > 0) {
+        load_chunk(0);
+        store_chunk(0);
+    }
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const bool more = ch + 1 < nchunk;
+        if (more) load_chunk(ch + 1);
+        compute(ch & 1);
+        if (more) store_chunk((ch + 1) & 1);
+        __syncthreads();
+    }
+
+    float* out = a.partial + (size_t)split * (size_t)a.CP * (size_t)T * (size_t)a.CQ;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int prow = p0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int qcol = q0 + (wn * NT + j) * 32 + l31;
+                out[((size_t)prow * (size_t)T + (size_t)tap) * (size_t)a.CQ + (size_t)qcol] = acc[i][j][e];
+            }
+        }
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict__ partial, int nsplit, long long count4,
+                                                         float* __restrict__ out, float beta)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += stride) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k = 0; k < nsplit; ++k) {
+            const float4 v = reinterpret_cast<const float4*>(partial)[(long long)k * count4 + i];
+            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+        }
+        float4* o = reinterpret_cast<float4*>(out) + i;
+        if (beta != 0.f) {
+            const float4 p = *o;
+            s.x += beta * p.x; s.y += beta * p.y; s.z += beta * p.z; s.w += beta * p.w;
+        }
+        *o = s;
+    }
+}
+
+inline bool big_tile(const WgradArgs& a) { return a.CP % 128 == 0 && a.CQ % 128 == 0; }
+
+}  // namespace
+
+int lbc_wgrad_pick_split(const WgradArgs& a)
+{
+    const int bp = big_tile(a) ? 128 : 64;
+    const long long tiles = (long long)(a.CP / bp) * (a.CQ / bp) * a.KH * a.KW;
+    const long long M = (long long)a.N * a.OH * a.OW;
+    const long long chunks = (M + BR - 1) / BR;
+    long long ns = 1536 / tiles;
+    if (ns < 1) ns = 1;
+    if (ns > 256) ns = 256;
+    // keep at least 8 chunks (256 pixels) of reduction per split
+    const long long maxns = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (ns > maxns) ns = maxns;
+    return (int)ns;
+}
+
+int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.CP % 64 == 0 && a.CQ % 64 == 0, "wgrad: channels (%d,%d) must be multiples of 64", a.CP, a.CQ);
+    LBC_REQUIRE(a.nsplit >= 1, "wgrad: nsplit %d", a.nsplit);
+    const long long M = (long long)a.N * a.OH * a.OW;
+    LBC_REQUIRE(M > 0 && M * a.CP < (1ll << 31) && (long long)a.N * a.H * a.W * a.CQ < (1ll << 31), "wgrad: bad tensor size");
+    const long long chunks = (M + BR - 1) / BR;
+    const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * BR;
+    if (big_tile(a)) {
+        dim3 grid((unsigned)a.nsplit, (unsigned)((a.CP / 128) * (a.CQ / 128)), (unsigned)(a.KH * a.KW));
+        hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
+    } else {
+        dim3 grid((unsigned)a.nsplit, (unsigned)((a.CP / 64) * (a.CQ / 64)), (unsigned)(a.KH * a.KW));
+        hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
+    }
+    return lbc_check_launch("conv_wgrad_f32");
+}
+
+int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* out, float beta, hipStream_t s)
+{
+    LBC_REQUIRE(count % 4 == 0, "splitk_reduce: count %lld not a multiple of 4", count);
+    const long long c4 = count / 4;
+    long long blocks = (c4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(splitk_reduce_f32, dim3((unsigned)blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta);
+    return lbc_check_launch("splitk_reduce_f32");
+}
