@@ -66,6 +66,58 @@ int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const float* x, const float* d
                           const float* pre_scale, const float* pre_shift, int pre_relu,
                           float* dw, float beta, void* workspace, lbc_stream_t stream);
 
+
+/* ------------------------------------------------------------------------------------------
+ * Whole-network executor: the LbC policy networks behind the reference's module API
+ * (bird_view/models/image.py:22-89 ImagePolicyModelSS, birdview.py:47-79 BirdViewPolicyModelSS).
+ * The executor keeps no device memory of its own: parameters/buffers are bound by pointer
+ * under the reference's state_dict names, activations live in one caller-provided workspace.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct lbc_net_desc {
+    int arch;          /* 18 or 34 (BasicBlock ResNets; reference resnet.py:162-168) */
+    int in_channels;   /* 3 (RGB, ImageNet-normalised on load) or 7 (bird-view) */
+    int H, W;          /* input image size, multiples of 32 (160x384 / 192x192) */
+    int normalize;     /* 1: (x-mean)/std with the ImageNet constants of image.py:32-35 */
+    int max_batch;
+} lbc_net_desc;
+typedef struct lbc_net lbc_net;
+
+int lbc_net_create(const lbc_net_desc* d, lbc_net** out);
+void lbc_net_destroy(lbc_net* net);
+int lbc_net_num_tensors(const lbc_net* net);
+/* kind: 0 = parameter (fp32), 1 = buffer fp32, 2 = buffer int64.  name = state_dict key. */
+int lbc_net_tensor_info(const lbc_net* net, int i, char* name, int name_cap, int* kind, int* ndim, int* shape4);
+size_t lbc_net_workspace_bytes(const lbc_net* net);
+/* tensor_ptrs[i] / grad_ptrs[i] in lbc_net_tensor_info order; grad_ptrs may be NULL (inference only)
+ * and its entries for buffers are ignored.  4-D weights must be in channels_last memory order. */
+int lbc_net_bind(lbc_net* net, void* workspace, void* const* tensor_ptrs, float* const* grad_ptrs);
+/* forward(image, velocity, command) of the reference modules.  image: NCHW fp32 [N,C,H,W] (the
+ * reference signature); velocity [N]; command [N,4] one-hot.  Outputs: pred_sel [N,5,2] and
+ * pred_all [N,4,5,2] (normalised [-1,1] camera/map coordinates).  train != 0: batch statistics,
+ * running-stat update, activations kept for backward. */
+int lbc_net_forward(lbc_net* net, int N, int train, const float* image, const float* velocity,
+                    const float* command, float* pred_sel, float* pred_all, lbc_stream_t stream);
+/* Backward of the last training-mode forward: gradients of a scalar wrt pred_sel / pred_all
+ * (either may be NULL) -> every bound parameter gradient (overwritten, not accumulated).
+ * stage = -1 runs everything; stages 0..lbc_net_num_stages()-1 run in order (head+decoder,
+ * layer4, layer3, layer2, layer1, stem) so gradient buckets can be all-reduced while the
+ * remaining stages execute. */
+int lbc_net_num_stages(void);
+int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream);
+
+/* Losses (forward value per sample + gradient wrt pred), reference training/train_image_phase1.py:35-70,
+ * train_image_phase0.py:36-89, train_birdview.py:33-54.  kind: 0 phase-0, 1 phase-1, 2 bird-view L1.
+ * rows = waypoints per sample (5 or 20).  dpred = grad_scale * d(sum_n loss[n])/dpred. */
+typedef struct lbc_camera { float w, h, fov, world_y, fixed_offset, pixels_per_meter, crop_size; } lbc_camera;
+int lbc_loss(int kind, const lbc_camera* cam, const float* pred, const float* target, int N, int rows,
+             float grad_scale, float* loss_per_sample, float* dpred, lbc_stream_t stream);
+
+/* Multi-tensor Adam (torch.optim.Adam semantics; reference training/train_image_phase1.py:252).
+ * chunk table lives in device memory: see lbc_adam_chunk. */
+typedef struct lbc_adam_chunk { float* p; const float* g; float* m; float* v; int n; int pad; } lbc_adam_chunk;
+int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, float lr, float beta1, float beta2,
+                  float eps, float weight_decay, int step, lbc_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,114 @@
+"""ctypes binding of the C ABI in include/lbc_hip.h (learningbycheating_amd/liblbc_hip.so).
+
+The product path has NO fallback: if the gfx950 library is missing or a kernel launch
+fails, a RuntimeError is raised.  (tests/emu injects a CPU-emulated build of the same
+kernel sources through _inject_for_tests(); nothing in the package does.)
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblbc_hip.so")
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "C", "K", "KH", "KW", "S", "P", "relu")]
+
+
+class NetDesc(ctypes.Structure):
+    _fields_ = [(n, c_int) for n in ("arch", "in_channels", "H", "W", "normalize", "max_batch")]
+
+
+class Camera(ctypes.Structure):
+    _fields_ = [(n, c_float) for n in ("w", "h", "fov", "world_y", "fixed_offset", "pixels_per_meter", "crop_size")]
+
+
+class AdamChunk(ctypes.Structure):
+    _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int), ("pad", c_int)]
+
+
+_SIGNATURES = {
+    "lbc_last_error": (c_char_p, []),
+    "lbc_backend": (c_char_p, []),
+    "lbc_version": (c_int, []),
+    "lbc_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p]),
+    "lbc_conv2d_dgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5),
+    "lbc_conv2d_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "lbc_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "lbc_deconv3x3s2_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p]),
+    "lbc_deconv3x3s2_dgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4),
+    "lbc_deconv3x3s2_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
+    "lbc_deconv3x3s2_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
+    "lbc_net_create": (c_int, [ctypes.POINTER(NetDesc), ctypes.POINTER(c_void_p)]),
+    "lbc_net_destroy": (None, [c_void_p]),
+    "lbc_net_num_tensors": (c_int, [c_void_p]),
+    "lbc_net_tensor_info": (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
+    "lbc_net_workspace_bytes": (c_size_t, [c_void_p]),
+    "lbc_net_bind": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
+    "lbc_net_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),
+    "lbc_net_num_stages": (c_int, []),
+    "lbc_net_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lbc_loss": (c_int, [c_int, ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "lbc_adam_step": (c_int, [c_void_p, c_int, c_float, c_float, c_float, c_float, c_float, c_int, c_void_p]),
+}
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def _declare(lib):
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = the library does not export what include/lbc_hip.h declares
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+def load(path=None):
+    """Load the gfx950 library (built by __graft_entry__.build() / csrc/Makefile)."""
+    global _lib
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        raise RuntimeError(
+            "learningbycheating_amd: %s not found. Build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    _lib = _declare(ctypes.CDLL(path))
+    return _lib
+
+
+def get():
+    return _lib if _lib is not None else load()
+
+
+def _inject_for_tests(lib):
+    """tests/emu only: use a CPU-emulated build of the kernel sources."""
+    global _lib
+    _lib = _declare(lib) if lib is not None else None
+    return _lib
+
+
+def backend():
+    return get().lbc_backend().decode()
+
+
+def check(rc, what=""):
+    if rc != 0:
+        raise RuntimeError("lbc_hip %s failed (%d): %s" % (what, rc, get().lbc_last_error().decode()))
+
+
+def ptr(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def stream_for(t):
+    import torch
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    return None
+
+
+def require_device(t):
+    """Kernels run on a ROCm device only (the emulated test build accepts CPU tensors)."""
+    if not t.is_cuda and backend() != "emu-cpu":
+        raise RuntimeError("learningbycheating_amd: tensors must live on a ROCm (cuda) device; there is no CPU path")

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/lbc_hip.h) over the internal launchers.
 #include "lbc_common.hpp"
 #include "lbc_hip.h"
+#include <string.h>
 
 extern "C" {
 
@@ -182,10 +183,10 @@ int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const float* x, const float* d
                           float* dw, float beta, void* workspace, lbc_stream_t stream)
 {
     LBC_REQUIRE(d && workspace, "deconv_wgrad: null desc/workspace");
-    LBC_REQUIRE(pre_scale == nullptr, "deconv_wgrad: fused BN-on-load of the dense operand is not supported; pass the normalised x");
-    (void)pre_shift; (void)pre_relu;
+    LBC_REQUIRE(!pre_relu, "deconv_wgrad: ReLU-on-load of the dense operand is not supported");
     WgradArgs a = deconv_wgrad_args(d);
     a.p = x; a.q = dy; a.partial = (float*)workspace;
+    a.p_scale = pre_scale; a.p_shift = pre_shift;
     int rc = lbc_wgrad_launch(a, (hipStream_t)stream);
     if (rc) return rc;
     return lbc_splitk_reduce(a.partial, a.nsplit, (long long)a.CP * 9 * a.CQ, dw, beta, (hipStream_t)stream);

@@ -67,7 +67,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
             const int sg = idx - row * (BP / 4);
             const int m = mc + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < mend) v = *reinterpret_cast<const float4*>(a.p + (size_t)m * (size_t)a.CP + (size_t)(p0 + sg * 4));
+            if (m < mend) {
+                v = *reinterpret_cast<const float4*>(a.p + (size_t)m * (size_t)a.CP + (size_t)(p0 + sg * 4));
+                if (a.p_scale) {
+                    const float4 ps = *reinterpret_cast<const float4*>(a.p_scale + p0 + sg * 4);
+                    const float4 pt = *reinterpret_cast<const float4*>(a.p_shift + p0 + sg * 4);
+                    v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y;
+                    v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w;
+                }
+            }
             rp[j] = v;
         }
 #pragma unroll

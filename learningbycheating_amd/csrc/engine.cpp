@@ -1,0 +1,667 @@
+// Network executor: plans and enqueues the forward / backward kernel sequences of the
+// LbC policy networks.  See engine.hpp for the contract; every numbered comment cites
+// the reference line whose arithmetic the kernels at that point reproduce.
+#include "engine.hpp"
+
+#include <algorithm>
+#include <string.h>
+
+namespace lbc {
+
+namespace {
+constexpr float kBnMomentum = 0.1f;   // torch.nn.BatchNorm2d defaults used throughout the reference
+constexpr float kBnEps = 1e-5f;
+size_t up64(size_t n) { return (n + 63) / 64 * 64; }
+#define LBC_TRY(expr)            \
+    do {                         \
+        int rc__ = (expr);       \
+        if (rc__) return rc__;   \
+    } while (0)
+}  // namespace
+
+int Net::add_tensor(const std::string& name, int kind, std::initializer_list<int> shape)
+{
+    TensorInfo ti;
+    ti.name = name;
+    ti.kind = kind;
+    ti.ndim = (int)shape.size();
+    ti.numel = 1;
+    int i = 0;
+    for (int s : shape) { ti.shape[i++] = s; ti.numel *= s; }
+    for (; i < 4; ++i) ti.shape[i] = 1;
+    t_.push_back(ti);
+    return (int)t_.size() - 1;
+}
+
+size_t Net::alloc(size_t nfloats)
+{
+    const size_t off = ws_floats_;
+    ws_floats_ += up64(nfloats);
+    return off;
+}
+
+BN Net::make_bn(const std::string& p, int C)
+{
+    BN bn;
+    bn.C = C;
+    bn.g = add_tensor(p + ".weight", kParam, {C});
+    bn.b = add_tensor(p + ".bias", kParam, {C});
+    bn.rm = add_tensor(p + ".running_mean", kBufferF32, {C});
+    bn.rv = add_tensor(p + ".running_var", kBufferF32, {C});
+    bn.nbt = add_tensor(p + ".num_batches_tracked", kBufferI64, {});
+    bn.scale = alloc(C); bn.shift = alloc(C); bn.mean = alloc(C); bn.invstd = alloc(C);
+    bn.cA = alloc(C); bn.cB = alloc(C); bn.cD = alloc(C);
+    return bn;
+}
+
+Conv Net::make_conv(const std::string& name, int Cin, int Cout, int H, int W, int k, int s, int p)
+{
+    Conv c;
+    c.w = add_tensor(name, kParam, {Cout, Cin, k, k});
+    c.Cin = Cin; c.Cout = Cout; c.H = H; c.W = W; c.k = k; c.s = s; c.p = p;
+    c.OH = (H + 2 * p - k) / s + 1;
+    c.OW = (W + 2 * p - k) / s + 1;
+    c.y = alloc((size_t)d_.max_batch * c.OH * c.OW * Cout);
+    return c;
+}
+
+Net::Net(const lbc_net_desc& d) : d_(d)
+{
+    const size_t NB = (size_t)d.max_batch;
+    const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
+
+    // ---- stem (resnet.py:102-106) ----
+    stem_w_ = add_tensor("conv.conv1.weight", kParam, {64, Cin, 7, 7});
+    stem_bn_ = make_bn("conv.bn1", 64);
+    xp_ = alloc(NB * (H0 + 6) * (W0 + 6) * Cin);
+    y0_ = alloc(NB * (H0 / 2) * (W0 / 2) * 64);
+    H1_ = H0 / 4; W1_ = W0 / 4;
+    p0_ = alloc(NB * H1_ * W1_ * 64);
+    idx_ = alloc(NB * H1_ * W1_ * 64 / 4);
+
+    // ---- residual layers (resnet.py:107-110,124-146,162-168) ----
+    const int n34[4] = {3, 4, 6, 3}, n18[4] = {2, 2, 2, 2};
+    const int* nb = d.arch == 34 ? n34 : n18;
+    int inpl = 64, h = H1_, w = W1_;
+    size_t max_act = NB * H1_ * W1_ * 64;
+    for (int li = 0; li < 4; ++li) {
+        const int planes = 64 << li;
+        stage_first_block_.push_back((int)blocks_.size());
+        for (int bi = 0; bi < nb[li]; ++bi) {
+            const int stride = (li > 0 && bi == 0) ? 2 : 1;
+            const std::string pre = "conv.layer" + std::to_string(li + 1) + "." + std::to_string(bi);
+            Block b;
+            b.c1 = make_conv(pre + ".conv1.weight", inpl, planes, h, w, 3, stride, 1);
+            b.b1 = make_bn(pre + ".bn1", planes);
+            const int oh = b.c1.OH, ow = b.c1.OW;
+            b.c2 = make_conv(pre + ".conv2.weight", planes, planes, oh, ow, 3, 1, 1);
+            b.b2 = make_bn(pre + ".bn2", planes);
+            if (stride != 1 || inpl != planes) {
+                b.has_ds = true;
+                b.ds = make_conv(pre + ".downsample.0.weight", inpl, planes, h, w, 1, stride, 0);
+                b.bd = make_bn(pre + ".downsample.1", planes);
+            }
+            b.z1 = alloc(NB * oh * ow * planes);
+            b.out = alloc(NB * oh * ow * planes);
+            blocks_.push_back(b);
+            inpl = planes; h = oh; w = ow;
+        }
+    }
+
+    // ---- velocity fusion + decoder (image.py:37-47,77-80) ----
+    hcat_ = alloc(NB * h * w * 640);
+    const int dc[4] = {640, 256, 128, 64};
+    const char* bn_name[3] = {"deconv.0", "deconv.3", "deconv.6"};
+    const char* ct_name[3] = {"deconv.1", "deconv.4", "deconv.7"};
+    int dh = h, dw = w;
+    for (int i = 0; i < 3; ++i) {
+        Deconv& D = dec_[i];
+        D.bn = make_bn(bn_name[i], dc[i]);
+        D.w = add_tensor(std::string(ct_name[i]) + ".weight", kParam, {dc[i], dc[i + 1], 3, 3});
+        D.bias = add_tensor(std::string(ct_name[i]) + ".bias", kParam, {dc[i + 1]});
+        D.Cin = dc[i]; D.Cout = dc[i + 1]; D.H = dh; D.W = dw;
+        D.u = alloc(NB * (2 * dh) * (2 * dw) * dc[i + 1]);
+        dh *= 2; dw *= 2;
+        max_act = std::max(max_act, NB * dh * dw * (size_t)dc[i + 1]);
+    }
+    HH_ = dh; HW_ = dw;
+
+    // ---- 4 command branches (image.py:54-60) ----
+    for (int b = 0; b < 4; ++b) {
+        const std::string pre = "location_pred." + std::to_string(b);
+        head_bn_[b] = make_bn(pre + ".0", 64);
+        head_w_[b] = add_tensor(pre + ".1.weight", kParam, {5, 64, 1, 1});
+        head_b_[b] = add_tensor(pre + ".1.bias", kParam, {5});
+        head_px_[b] = add_tensor(pre + ".2.pos_x", kBufferF32, {HH_ * HW_});
+        head_py_[b] = add_tensor(pre + ".2.pos_y", kBufferF32, {HH_ * HW_});
+    }
+    head_stats_ = alloc(2 * 64);   // shared batch mean / invstd of the decoder output
+    head_coef_ = alloc(3 * 64);
+    head_partial_ = alloc(NB * 20 * 65);
+    pred_all_ = alloc(NB * 40);
+    rowstat_ = alloc(NB * 40);
+    cmd_ = alloc(NB * 4);
+
+    // ---- scratch: statistics partials, split-K slabs, gradient ping-pong buffers ----
+    size_t pf = 1024 * 2 * 640;                                              // channel_reduce rows <= 1024
+    pf = std::max(pf, (size_t)lbc_cdiv((long long)NB * (H0 / 2) * (W0 / 2), 128) * 128);   // stem epilogue
+    for (const Block& b : blocks_) {
+        pf = std::max(pf, (size_t)lbc_cdiv((long long)NB * b.c1.OH * b.c1.OW, 64) * 2 * b.c1.Cout);
+    }
+    for (int i = 0; i < 3; ++i)
+        pf = std::max(pf, (size_t)4 * lbc_cdiv((long long)NB * dec_[i].H * dec_[i].W, 64) * 2 * dec_[i].Cout);
+    partial_floats_ = pf;
+    partial_ = alloc(pf);
+    partial2_ = alloc(64 * 2 * 640);
+
+    size_t wg = 0;
+    auto wg_need = [&](int N, int OH, int OW, int CP, int Hq, int Wq, int CQ, int k, int s, int p) {
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.N = N; a.OH = OH; a.OW = OW; a.CP = CP; a.H = Hq; a.W = Wq; a.CQ = CQ; a.KH = k; a.KW = k; a.S = s; a.P = p;
+        return (size_t)lbc_wgrad_pick_split(a) * CP * k * k * CQ;
+    };
+    for (const Block& b : blocks_) {
+        wg = std::max(wg, wg_need((int)NB, b.c1.OH, b.c1.OW, b.c1.Cout, b.c1.H, b.c1.W, b.c1.Cin, 3, b.c1.s, 1));
+        wg = std::max(wg, wg_need((int)NB, b.c2.OH, b.c2.OW, b.c2.Cout, b.c2.H, b.c2.W, b.c2.Cin, 3, 1, 1));
+        if (b.has_ds) wg = std::max(wg, wg_need((int)NB, b.ds.OH, b.ds.OW, b.ds.Cout, b.ds.H, b.ds.W, b.ds.Cin, 1, b.ds.s, 0));
+    }
+    for (int i = 0; i < 3; ++i)
+        wg = std::max(wg, wg_need((int)NB, dec_[i].H, dec_[i].W, dec_[i].Cin, 2 * dec_[i].H, 2 * dec_[i].W, dec_[i].Cout, 3, 2, 1));
+    wg = std::max(wg, (size_t)lbc_stem_wgrad_split((int)NB, H0, W0) * 64 * 49 * Cin);
+    wg_partial_ = alloc(wg);
+
+    gD_ = alloc(max_act); gE_ = alloc(max_act); gF_ = alloc(max_act); gG_ = alloc(max_act);
+    g0_ = alloc(NB * (H0 / 2) * (W0 / 2) * 64);
+}
+
+int Net::check_bound(bool need_grads) const
+{
+    if (!ws_) { lbc_set_error("net: workspace not bound"); return LBC_ESTATE; }
+    for (const TensorInfo& t : t_) {
+        if (!t.ptr) { lbc_set_error("net: tensor %s not bound", t.name.c_str()); return LBC_ESTATE; }
+        if (need_grads && t.kind == kParam && !t.grad) { lbc_set_error("net: gradient of %s not bound", t.name.c_str()); return LBC_ESTATE; }
+    }
+    return LBC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s)
+{
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = x; a.w = P(c.w); a.y = W(c.y);
+    a.N = N; a.H = c.H; a.W = c.W; a.C = c.Cin;
+    a.OH = c.OH; a.OW = c.OW; a.K = c.Cout;
+    a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
+    a.M = N * c.OH * c.OW; a.LH = c.OH; a.LW = c.OW; a.ostep = 1;
+    const int cfg = lbc_igemm_pick(a.M, a.K);
+    *rows = lbc_igemm_rows(a, cfg);
+    a.stats = stats ? W(partial_) : nullptr;
+    return lbc_igemm_launch(a, 1, 0, cfg, s);
+}
+
+int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running)
+{
+    const float* part = W(partial_);
+    if (train && rows > 64) {
+        LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * bn.C, W(partial2_), 64, s));
+        part = W(partial2_);
+        rows = 64;
+    }
+    BnFinalizeArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partial = part; f.rows = rows; f.C = bn.C; f.count = count;
+    f.gamma = P(bn.g); f.beta = P(bn.b);
+    f.running_mean = (train && !update_running) ? nullptr : P(bn.rm);
+    f.running_var = (train && !update_running) ? nullptr : P(bn.rv);
+    f.num_batches_tracked = (train && update_running) ? static_cast<long long*>(t_[bn.nbt].ptr) : nullptr;
+    f.momentum = kBnMomentum; f.eps = kBnEps; f.train = train;
+    f.scale = W(bn.scale); f.shift = W(bn.shift); f.save_mean = W(bn.mean); f.save_invstd = W(bn.invstd);
+    return lbc_bn_finalize(f, s);
+}
+
+int Net::forward(int N, int train, const float* image, const float* velocity, const float* command, float* pred_sel,
+                 float* pred_all, hipStream_t s)
+{
+    LBC_REQUIRE(N >= 1 && N <= d_.max_batch, "net.forward: batch %d outside [1,%d]", N, d_.max_batch);
+    LBC_REQUIRE(image && velocity && command && pred_all, "net.forward: null argument");
+    LBC_TRY(check_bound(false));
+    lastN_ = N; last_train_ = train;
+    const int H0 = d_.H, W0 = d_.W, Cin = d_.in_channels;
+    const bool tr = train != 0;
+    int rows = 0;
+
+    if (hipMemcpyAsync(W(cmd_), command, sizeof(float) * 4 * N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        lbc_set_error("net.forward: command copy failed");
+        return LBC_ELAUNCH;
+    }
+    // image.py:71 / common.py:108-109: (x - mean) / std, fused into the NCHW -> padded NHWC repack
+    NormConst nc;
+    memset(&nc, 0, sizeof(nc));
+    nc.enabled = d_.normalize;
+    const float m3[3] = {0.485f, 0.456f, 0.406f}, s3[3] = {0.229f, 0.224f, 0.225f};
+    for (int i = 0; i < 3; ++i) { nc.mean[i] = m3[i]; nc.stdv[i] = s3[i]; }
+    LBC_TRY(lbc_prep_input(image, W(xp_), N, Cin, H0, W0, nc, s));
+
+    // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
+    StemArgs st;
+    st.xp = W(xp_); st.w = P(stem_w_); st.y = W(y0_); st.stats = tr ? W(partial_) : nullptr;
+    st.N = N; st.H = H0; st.W = W0; st.Cin = Cin;
+    LBC_TRY(lbc_stem_fwd(st, s));
+    LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), train, s));
+    PoolFwdArgs pf;
+    pf.y = W(y0_); pf.scale = W(stem_bn_.scale); pf.shift = W(stem_bn_.shift); pf.p = W(p0_);
+    pf.idx = reinterpret_cast<unsigned char*>(W(idx_));
+    pf.N = N; pf.H = H0 / 2; pf.W = W0 / 2; pf.C = 64;
+    LBC_TRY(lbc_bn_relu_maxpool_fwd(pf, s));
+
+    // resnet.py:38-54 BasicBlock.forward x 8/16
+    const float* x = W(p0_);
+    for (Block& b : blocks_) {
+        const long long pix = (long long)N * b.c1.OH * b.c1.OW;
+        LBC_TRY(conv_fwd(b.c1, x, N, tr, &rows, s));
+        LBC_TRY(bn_finalize(b.b1, rows, pix, train, s));
+        BnApplyArgs ap;
+        memset(&ap, 0, sizeof(ap));
+        ap.x = W(b.c1.y); ap.y = W(b.z1); ap.pixels = pix; ap.C = b.c1.Cout;
+        ap.scale = W(b.b1.scale); ap.shift = W(b.b1.shift); ap.relu = 1;
+        LBC_TRY(lbc_bn_apply(ap, s));
+        LBC_TRY(conv_fwd(b.c2, W(b.z1), N, tr, &rows, s));
+        LBC_TRY(bn_finalize(b.b2, rows, pix, train, s));
+        memset(&ap, 0, sizeof(ap));
+        ap.x = W(b.c2.y); ap.y = W(b.out); ap.pixels = pix; ap.C = b.c2.Cout;
+        ap.scale = W(b.b2.scale); ap.shift = W(b.b2.shift); ap.relu = 1;
+        if (b.has_ds) {
+            LBC_TRY(conv_fwd(b.ds, x, N, tr, &rows, s));
+            LBC_TRY(bn_finalize(b.bd, rows, pix, train, s));
+            ap.resid = W(b.ds.y); ap.rscale = W(b.bd.scale); ap.rshift = W(b.bd.shift);
+        } else {
+            ap.resid = x;
+        }
+        LBC_TRY(lbc_bn_apply(ap, s));
+        x = W(b.out);
+    }
+
+    // image.py:77-79 velocity late fusion; image.py:37-47 decoder (BN -> ConvT -> ReLU) x 3
+    const Block& last = blocks_.back();
+    const int th = last.c2.OH, tw = last.c2.OW;
+    LBC_TRY(lbc_concat_velocity(x, velocity, W(hcat_), N, th * tw, 512, 128, s));
+    if (tr) {
+        ChanReduceArgs cr;
+        memset(&cr, 0, sizeof(cr));
+        cr.x = W(hcat_); cr.partial = W(partial_); cr.pixels = (long long)N * th * tw; cr.C = 640;
+        LBC_TRY(lbc_chan_reduce(cr, 0, s));
+        rows = lbc_chan_reduce_rows(cr.pixels, 640);
+    }
+    LBC_TRY(bn_finalize(dec_[0].bn, rows, (long long)N * th * tw, train, s));
+    const float* din = W(hcat_);
+    for (int i = 0; i < 3; ++i) {
+        Deconv& D = dec_[i];
+        IgemmArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = din; a.w = P(D.w); a.y = W(D.u); a.bias = P(D.bias); a.relu = 1;
+        a.pre_scale = W(D.bn.scale); a.pre_shift = W(D.bn.shift);
+        a.N = N; a.H = D.H; a.W = D.W; a.C = D.Cin;
+        a.OH = 2 * D.H; a.OW = 2 * D.W; a.K = D.Cout;
+        a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
+        a.LH = D.H; a.LW = D.W; a.ostep = 2;
+        a.M = N * D.H * D.W;
+        a.stats = tr ? W(partial_) : nullptr;
+        const int cfg = lbc_igemm_pick(a.M, a.K);
+        const int per = lbc_igemm_rows(a, cfg);
+        for (int ph = 0; ph < 4; ++ph) {
+            a.oy0 = ph >> 1; a.ox0 = ph & 1; a.stat_row0 = ph * per;
+            LBC_TRY(lbc_igemm_launch(a, 0, 1, cfg, s));
+        }
+        const long long opix = (long long)N * 4 * D.H * D.W;
+        if (i < 2) {
+            LBC_TRY(bn_finalize(dec_[i + 1].bn, 4 * per, opix, train, s));
+        } else {
+            // image.py:54-60: the four branch BatchNorms see the same tensor -> same batch statistics
+            for (int b = 0; b < 4; ++b) LBC_TRY(bn_finalize(head_bn_[b], 4 * per, opix, train, s));
+        }
+        din = W(D.u);
+    }
+
+    // image.py:82-84 + common.py:29-35,136-152
+    HeadArgs ha;
+    memset(&ha, 0, sizeof(ha));
+    ha.h = W(dec_[2].u);
+    for (int b = 0; b < 4; ++b) {
+        ha.mean[b] = W(head_bn_[tr ? 0 : b].mean);
+        ha.invstd[b] = W(head_bn_[tr ? 0 : b].invstd);
+        ha.gamma[b] = P(head_bn_[b].g); ha.beta[b] = P(head_bn_[b].b);
+        ha.w[b] = P(head_w_[b]); ha.bias[b] = P(head_b_[b]);
+        ha.pos_x[b] = P(head_px_[b]); ha.pos_y[b] = P(head_py_[b]);
+    }
+    ha.cmd = W(cmd_);
+    ha.pred_all = W(pred_all_); ha.pred_sel = pred_sel; ha.rowstat = W(rowstat_);
+    ha.N = N; ha.OH = HH_; ha.OW = HW_;
+    LBC_TRY(lbc_head_fwd(ha, s));
+    if (hipMemcpyAsync(pred_all, W(pred_all_), sizeof(float) * 40 * N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
+        lbc_set_error("net.forward: output copy failed");
+        return LBC_ELAUNCH;
+    }
+    return LBC_OK;
+}
+
+// ---------------------------------------------------------------------------------------
+// BatchNorm backward: reduce (sum g, sum g*xhat) -> dgamma/dbeta + coefficients -> dx
+int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
+                     float* dx, int Cout, hipStream_t s)
+{
+    ChanReduceArgs r;
+    memset(&r, 0, sizeof(r));
+    r.x = x; r.dz = dz; r.mask = mask; r.g_out = g_out; r.mean = W(bn.mean); r.invstd = W(bn.invstd);
+    r.partial = W(partial_); r.pixels = pixels; r.C = bn.C;
+    LBC_TRY(lbc_chan_reduce(r, 1, s));
+    int rows = lbc_chan_reduce_rows(pixels, bn.C);
+    const float* part = W(partial_);
+    if (rows > 64) {
+        LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * bn.C, W(partial2_), 64, s));
+        part = W(partial2_); rows = 64;
+    }
+    BnBwdFinalizeArgs f;
+    memset(&f, 0, sizeof(f));
+    f.partial = part; f.rows = rows; f.C = bn.C; f.count = pixels;
+    f.gamma = P(bn.g); f.mean = W(bn.mean); f.invstd = W(bn.invstd); f.train = 1;
+    f.dgamma = G(bn.g); f.dbeta = G(bn.b);
+    f.coefA = W(bn.cA); f.coefB = W(bn.cB); f.coefD = W(bn.cD);
+    LBC_TRY(lbc_bn_bwd_finalize(f, s));
+    BnBwdApplyArgs ap;
+    memset(&ap, 0, sizeof(ap));
+    ap.g = g_out ? g_out : dz; ap.mask = g_out ? nullptr : mask; ap.x = x;
+    ap.coefA = W(bn.cA); ap.coefB = W(bn.cB); ap.coefD = W(bn.cD);
+    ap.mean = W(bn.mean); ap.invstd = W(bn.invstd);
+    ap.dx = dx; ap.pixels = pixels; ap.C = bn.C; ap.Cout = Cout;
+    return lbc_bn_bwd_apply(ap, s);
+}
+
+int Net::conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s)
+{
+    WgradArgs a;
+    memset(&a, 0, sizeof(a));
+    a.p = dy; a.q = x; a.partial = W(wg_partial_);
+    a.N = N; a.OH = c.OH; a.OW = c.OW; a.CP = c.Cout;
+    a.H = c.H; a.W = c.W; a.CQ = c.Cin;
+    a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
+    a.nsplit = lbc_wgrad_pick_split(a);
+    LBC_TRY(lbc_wgrad_launch(a, s));
+    return lbc_splitk_reduce(a.partial, a.nsplit, (long long)c.Cout * c.k * c.k * c.Cin, G(c.w), 0.f, s);
+}
+
+// dx[N,H,W,Cin] = dgrad(dy) (+ resid).  For the 1x1/2 downsample only the even-even phase is touched.
+int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s)
+{
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.x = dy; a.w = P(c.w); a.y = dx; a.resid = resid;
+    a.N = N; a.H = c.OH; a.W = c.OW; a.C = c.Cout;
+    a.OH = c.H; a.OW = c.W; a.K = c.Cin;
+    a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
+    if (c.s == 1) {
+        a.LH = c.H; a.LW = c.W; a.ostep = 1;
+        a.M = N * c.H * c.W;
+        return lbc_igemm_launch(a, 0, 1, lbc_igemm_pick(a.M, a.K), s);
+    }
+    a.LH = c.H / 2; a.LW = c.W / 2; a.ostep = 2;
+    a.M = N * a.LH * a.LW;
+    const int cfg = lbc_igemm_pick(a.M, a.K);
+    const int nph = c.k == 1 ? 1 : 4;
+    for (int ph = 0; ph < nph; ++ph) {
+        a.oy0 = ph >> 1; a.ox0 = ph & 1;
+        LBC_TRY(lbc_igemm_launch(a, 0, 1, cfg, s));
+    }
+    return LBC_OK;
+}
+
+// D: gradient wrt the block output (consumed; becomes the masked gradient); on return D points at the
+// gradient wrt the block input.
+int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s)
+{
+    const int N = lastN_;
+    const long long pix = (long long)N * b.c1.OH * b.c1.OW;
+    const float* xin = (&b == &blocks_.front()) ? W(p0_) : W((&b - 1)->out);
+    // out = relu(bn2(y2) + identity): mask by out, keep masked gradient in D for the identity path
+    LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E, b.b2.C, s));        // E = dY2
+    LBC_TRY(conv_wgrad(b.c2, W(b.z1), E, N, s));
+    LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                                   // F = dZ1
+    LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E, b.b1.C, s));          // E = dY1
+    LBC_TRY(conv_wgrad(b.c1, xin, E, N, s));
+    if (!b.has_ds) {
+        LBC_TRY(conv_dgrad(b.c1, E, D, Gbuf, N, s));                                  // G = dgrad + identity gradient
+    } else {
+        LBC_TRY(conv_dgrad(b.c1, E, nullptr, Gbuf, N, s));
+        LBC_TRY(bn_backward(b.bd, D, nullptr, nullptr, W(b.ds.y), pix, F, b.bd.C, s)); // F = dYd
+        LBC_TRY(conv_wgrad(b.ds, xin, F, N, s));
+        LBC_TRY(conv_dgrad(b.ds, F, Gbuf, Gbuf, N, s));                               // G += dgrad_1x1 (even pixels)
+    }
+    std::swap(D, Gbuf);
+    return LBC_OK;
+}
+
+int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t s)
+{
+    LBC_REQUIRE(lastN_ > 0 && last_train_, "net.backward: needs a preceding training-mode forward");
+    LBC_REQUIRE(stage >= -1 && stage < kNumStages, "net.backward: bad stage %d", stage);
+    LBC_TRY(check_bound(true));
+    const int N = lastN_;
+    float* E = W(gE_);
+    float* F = W(gF_);
+
+    if (stage == -1 || stage == 0) {
+        bwd_D_ = W(gD_); bwd_G_ = W(gG_);
+        // ---- head ----
+        HeadBwdArgs hb;
+        memset(&hb, 0, sizeof(hb));
+        HeadArgs& ha = hb.f;
+        ha.h = W(dec_[2].u);
+        for (int b = 0; b < 4; ++b) {
+            ha.mean[b] = W(head_bn_[0].mean); ha.invstd[b] = W(head_bn_[0].invstd);
+            ha.gamma[b] = P(head_bn_[b].g); ha.beta[b] = P(head_bn_[b].b);
+            ha.w[b] = P(head_w_[b]); ha.bias[b] = P(head_b_[b]);
+            ha.pos_x[b] = P(head_px_[b]); ha.pos_y[b] = P(head_py_[b]);
+        }
+        ha.cmd = W(cmd_); ha.pred_all = W(pred_all_); ha.rowstat = W(rowstat_);
+        ha.N = N; ha.OH = HH_; ha.OW = HW_;
+        hb.d_all = d_all; hb.d_sel = d_sel; hb.s_partial = W(head_partial_); hb.dh = E; hb.chan_coef = W(head_coef_);
+        LBC_TRY(lbc_head_bwd_reduce(hb, s));
+        HeadBwdFinalizeArgs hf;
+        memset(&hf, 0, sizeof(hf));
+        hf.s_partial = W(head_partial_); hf.rows = N; hf.count = (long long)N * HH_ * HW_;
+        for (int b = 0; b < 4; ++b) {
+            hf.gamma[b] = P(head_bn_[b].g); hf.beta[b] = P(head_bn_[b].b); hf.w[b] = P(head_w_[b]);
+            hf.dgamma[b] = G(head_bn_[b].g); hf.dbeta[b] = G(head_bn_[b].b);
+            hf.dw[b] = G(head_w_[b]); hf.dbias[b] = G(head_b_[b]);
+        }
+        hf.mean = W(head_bn_[0].mean); hf.invstd = W(head_bn_[0].invstd); hf.chan_coef = W(head_coef_);
+        LBC_TRY(lbc_head_bwd_finalize(hf, s));
+        LBC_TRY(lbc_head_bwd_apply(hb, s));   // E = dU3
+
+        // ---- decoder, last to first ----
+        for (int i = 2; i >= 0; --i) {
+            Deconv& D = dec_[i];
+            const float* xin = i == 0 ? W(hcat_) : W(dec_[i - 1].u);
+            const long long opix = (long long)N * 4 * D.H * D.W;
+            const long long ipix = (long long)N * D.H * D.W;
+            // ReLU backward in place + bias gradient
+            ChanReduceArgs r;
+            memset(&r, 0, sizeof(r));
+            r.dz = E; r.mask = W(D.u); r.g_out = E; r.partial = W(partial_); r.pixels = opix; r.C = D.Cout;
+            LBC_TRY(lbc_chan_reduce(r, 1, s));
+            int rows = lbc_chan_reduce_rows(opix, D.Cout);
+            const float* part = W(partial_);
+            if (rows > 64) {
+                LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * D.Cout, W(partial2_), 64, s));
+                part = W(partial2_); rows = 64;
+            }
+            BnBwdFinalizeArgs f;
+            memset(&f, 0, sizeof(f));
+            f.partial = part; f.rows = rows; f.C = D.Cout; f.count = opix; f.dbeta = G(D.bias);
+            LBC_TRY(lbc_bn_bwd_finalize(f, s));
+            // weight gradient: P = bn(x) (dense), Q = g gathered with stride 2
+            WgradArgs wa;
+            memset(&wa, 0, sizeof(wa));
+            wa.p = xin; wa.q = E; wa.partial = W(wg_partial_);
+            wa.p_scale = W(D.bn.scale); wa.p_shift = W(D.bn.shift);
+            wa.N = N; wa.OH = D.H; wa.OW = D.W; wa.CP = D.Cin;
+            wa.H = 2 * D.H; wa.W = 2 * D.W; wa.CQ = D.Cout; wa.KH = 3; wa.KW = 3; wa.S = 2; wa.P = 1;
+            wa.nsplit = lbc_wgrad_pick_split(wa);
+            LBC_TRY(lbc_wgrad_launch(wa, s));
+            LBC_TRY(lbc_splitk_reduce(wa.partial, wa.nsplit, (long long)D.Cin * 9 * D.Cout, G(D.w), 0.f, s));
+            // input gradient: a stride-2 gather convolution over g with the same weight tensor
+            IgemmArgs a;
+            memset(&a, 0, sizeof(a));
+            a.x = E; a.w = P(D.w); a.y = F;
+            a.N = N; a.H = 2 * D.H; a.W = 2 * D.W; a.C = D.Cout;
+            a.OH = D.H; a.OW = D.W; a.K = D.Cin; a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
+            a.M = N * D.H * D.W; a.LH = D.H; a.LW = D.W; a.ostep = 1;
+            LBC_TRY(lbc_igemm_launch(a, 1, 0, lbc_igemm_pick(a.M, a.K), s));   // F = d bn(x)
+            // BatchNorm backward; for the first decoder stage only the 512 trunk channels carry on
+            float* dst = i == 0 ? bwd_D_ : E;
+            LBC_TRY(bn_backward(D.bn, F, nullptr, nullptr, xin, ipix, dst, i == 0 ? 512 : D.Cin, s));
+        }
+    }
+
+    for (int li = 3; li >= 0; --li) {
+        const int st = 4 - li;   // layer4 -> stage 1 ... layer1 -> stage 4
+        if (stage != -1 && stage != st) continue;
+        const int first = stage_first_block_[li];
+        const int lastb = li == 3 ? (int)blocks_.size() : stage_first_block_[li + 1];
+        for (int bi = lastb - 1; bi >= first; --bi) LBC_TRY(block_backward(blocks_[bi], bwd_D_, bwd_G_, E, F, s));
+    }
+
+    if (stage == -1 || stage == 5) {
+        // resnet.py:149-152 backward: maxpool -> relu -> bn1 -> conv1 weight gradient
+        const int H0 = d_.H, W0 = d_.W;
+        PoolBwdArgs pb;
+        memset(&pb, 0, sizeof(pb));
+        pb.dp = bwd_D_; pb.idx = reinterpret_cast<const unsigned char*>(W(idx_)); pb.y = W(y0_);
+        pb.scale = W(stem_bn_.scale); pb.shift = W(stem_bn_.shift);
+        pb.mean = W(stem_bn_.mean); pb.invstd = W(stem_bn_.invstd);
+        pb.g = W(g0_); pb.partial = W(partial_);
+        pb.N = N; pb.H = H0 / 2; pb.W = W0 / 2; pb.C = 64;
+        LBC_TRY(lbc_maxpool_relu_bwd_reduce(pb, s));
+        int rows = lbc_pool_bwd_rows(N, H0 / 2, W0 / 2, 64);
+        const long long pix = (long long)N * (H0 / 2) * (W0 / 2);
+        const float* part = W(partial_);
+        if (rows > 64) {
+            LBC_TRY(lbc_partial_reduce(W(partial_), rows, 128, W(partial2_), 64, s));
+            part = W(partial2_); rows = 64;
+        }
+        BnBwdFinalizeArgs f;
+        memset(&f, 0, sizeof(f));
+        f.partial = part; f.rows = rows; f.C = 64; f.count = pix;
+        f.gamma = P(stem_bn_.g); f.mean = W(stem_bn_.mean); f.invstd = W(stem_bn_.invstd); f.train = 1;
+        f.dgamma = G(stem_bn_.g); f.dbeta = G(stem_bn_.b);
+        f.coefA = W(stem_bn_.cA); f.coefB = W(stem_bn_.cB); f.coefD = W(stem_bn_.cD);
+        LBC_TRY(lbc_bn_bwd_finalize(f, s));
+        BnBwdApplyArgs ap;
+        memset(&ap, 0, sizeof(ap));
+        ap.g = W(g0_); ap.x = W(y0_); ap.coefA = W(stem_bn_.cA); ap.coefB = W(stem_bn_.cB); ap.coefD = W(stem_bn_.cD);
+        ap.mean = W(stem_bn_.mean); ap.invstd = W(stem_bn_.invstd);
+        ap.dx = W(g0_); ap.pixels = pix; ap.C = 64; ap.Cout = 64;
+        LBC_TRY(lbc_bn_bwd_apply(ap, s));
+        StemWgradArgs sw;
+        sw.xp = W(xp_); sw.dy = W(g0_); sw.partial = W(wg_partial_);
+        sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels;
+        sw.nsplit = lbc_stem_wgrad_split(N, H0, W0);
+        LBC_TRY(lbc_stem_wgrad(sw, s));
+        LBC_TRY(lbc_splitk_reduce(sw.partial, sw.nsplit, (long long)64 * 49 * d_.in_channels, G(stem_w_), 0.f, s));
+    }
+    return LBC_OK;
+}
+
+}  // namespace lbc
+
+// ---------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------
+struct lbc_net { lbc::Net impl; explicit lbc_net(const lbc_net_desc& d) : impl(d) {} };
+
+extern "C" {
+
+int lbc_net_create(const lbc_net_desc* d, lbc_net** out)
+{
+    LBC_REQUIRE(d && out, "net_create: null argument");
+    LBC_REQUIRE(d->arch == 18 || d->arch == 34, "net_create: arch %d unsupported (BasicBlock ResNet-18/34 only)", d->arch);
+    LBC_REQUIRE(d->in_channels == 3 || d->in_channels == 7, "net_create: in_channels %d unsupported", d->in_channels);
+    LBC_REQUIRE(d->H > 0 && d->W > 0 && d->H % 32 == 0 && d->W % 32 == 0, "net_create: image %dx%d must be a multiple of 32", d->H, d->W);
+    LBC_REQUIRE(d->max_batch >= 1, "net_create: max_batch %d", d->max_batch);
+    LBC_REQUIRE(!d->normalize || d->in_channels == 3, "net_create: ImageNet normalisation needs 3 channels");
+    LBC_REQUIRE((long long)d->max_batch * (d->H / 2) * (d->W / 2) * 64 < (1ll << 31), "net_create: batch too large for 32-bit indexing");
+    *out = new lbc_net(*d);
+    return LBC_OK;
+}
+void lbc_net_destroy(lbc_net* net) { delete net; }
+int lbc_net_num_tensors(const lbc_net* net) { return net ? (int)const_cast<lbc_net*>(net)->impl.tensors().size() : 0; }
+int lbc_net_tensor_info(const lbc_net* net, int i, char* name, int name_cap, int* kind, int* ndim, int* shape4)
+{
+    LBC_REQUIRE(net, "tensor_info: null net");
+    auto& ts = const_cast<lbc_net*>(net)->impl.tensors();
+    LBC_REQUIRE(i >= 0 && i < (int)ts.size(), "tensor_info: index %d out of range", i);
+    const lbc::TensorInfo& t = ts[(size_t)i];
+    if (name && name_cap > 0) { strncpy(name, t.name.c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    if (kind) *kind = t.kind;
+    if (ndim) *ndim = t.ndim;
+    if (shape4) for (int k = 0; k < 4; ++k) shape4[k] = t.shape[k];
+    return LBC_OK;
+}
+size_t lbc_net_workspace_bytes(const lbc_net* net) { return net ? net->impl.workspace_bytes() : 0; }
+int lbc_net_bind(lbc_net* net, void* workspace, void* const* tensor_ptrs, float* const* grad_ptrs)
+{
+    LBC_REQUIRE(net && workspace && tensor_ptrs, "net_bind: null argument");
+    net->impl.set_workspace(workspace);
+    auto& ts = net->impl.tensors();
+    for (size_t i = 0; i < ts.size(); ++i) {
+        ts[i].ptr = tensor_ptrs[i];
+        ts[i].grad = (grad_ptrs && ts[i].kind == lbc::kParam) ? grad_ptrs[i] : nullptr;
+    }
+    return LBC_OK;
+}
+int lbc_net_forward(lbc_net* net, int N, int train, const float* image, const float* velocity, const float* command,
+                    float* pred_sel, float* pred_all, lbc_stream_t stream)
+{
+    LBC_REQUIRE(net, "net_forward: null net");
+    return net->impl.forward(N, train, image, velocity, command, pred_sel, pred_all, (hipStream_t)stream);
+}
+int lbc_net_num_stages(void) { return lbc::Net::kNumStages; }
+int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream)
+{
+    LBC_REQUIRE(net, "net_backward: null net");
+    return net->impl.backward(d_sel, d_all, stage, (hipStream_t)stream);
+}
+
+int lbc_loss(int kind, const lbc_camera* cam, const float* pred, const float* target, int N, int rows, float grad_scale,
+             float* loss_per_sample, float* dpred, lbc_stream_t stream)
+{
+    LBC_REQUIRE(pred && target && loss_per_sample, "loss: null argument");
+    LossArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pred = pred; a.target = target; a.loss_per_sample = loss_per_sample; a.dpred = dpred;
+    a.N = N; a.R = rows; a.grad_scale = grad_scale;
+    if (cam) {
+        a.w = cam->w; a.h = cam->h; a.fov = cam->fov; a.world_y = cam->world_y; a.fixed_offset = cam->fixed_offset;
+        a.pixels_per_meter = cam->pixels_per_meter; a.crop_size = cam->crop_size;
+    }
+    if (kind == 1) { LBC_REQUIRE(cam, "loss: phase-1 needs a camera"); return lbc_loss_phase1(a, (hipStream_t)stream); }
+    if (kind == 0) { LBC_REQUIRE(cam, "loss: phase-0 needs a camera"); return lbc_loss_phase0(a, (hipStream_t)stream); }
+    if (kind == 2) {
+        // train_birdview.py:48-52: gt / (0.5*size) - 1 with w = h = crop_size
+        LBC_REQUIRE(cam, "loss: bird-view L1 needs crop_size");
+        return lbc_loss_l1(a, 1.f / (0.5f * cam->crop_size), -1.f, (hipStream_t)stream);
+    }
+    lbc_set_error("loss: unknown kind %d", kind);
+    return LBC_EINVAL;
+}
+
+int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, lbc_stream_t stream)
+{
+    static_assert(sizeof(lbc_adam_chunk) == sizeof(AdamChunk), "chunk layout");
+    return lbc_adam_launch(reinterpret_cast<const AdamChunk*>(chunks_dev), nchunks, lr, beta1, beta2, eps, weight_decay,
+                           step, (hipStream_t)stream);
+}
+
+}  // extern "C"

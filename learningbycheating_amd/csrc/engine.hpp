@@ -1,0 +1,121 @@
+// Native executor of the LbC policy networks (ImagePolicyModelSS / BirdViewPolicyModelSS:
+// ResNet-18/34 BasicBlock trunk + velocity late fusion + 3 x (BN, ConvTranspose, ReLU)
+// decoder + 4 command branches of (BN, 1x1 conv, spatial softmax)).
+// reference topology: bird_view/models/image.py:22-89, birdview.py:34-79, resnet.py:95-159.
+//
+// The executor owns nothing but a plan: tensor table (names = the reference's
+// state_dict keys), per-layer geometry and offsets into ONE caller-provided HBM
+// workspace.  forward()/backward() enqueue the whole kernel sequence on the given
+// stream with no host synchronisation, so a training step can be graph-captured.
+#pragma once
+#include <string>
+#include <vector>
+
+#include "lbc_common.hpp"
+#include "lbc_hip.h"
+#include "lbc_kernels.hpp"
+
+namespace lbc {
+
+enum TensorKind { kParam = 0, kBufferF32 = 1, kBufferI64 = 2 };
+
+struct TensorInfo {
+    std::string name;
+    int kind;
+    int ndim;
+    int shape[4];
+    long long numel;
+    void* ptr = nullptr;     // bound device pointer
+    float* grad = nullptr;   // bound gradient pointer (params only)
+};
+
+struct BN {
+    int C = 0;
+    int g = -1, b = -1, rm = -1, rv = -1, nbt = -1;          // tensor indices
+    size_t scale = 0, shift = 0, mean = 0, invstd = 0;       // workspace offsets (floats)
+    size_t cA = 0, cB = 0, cD = 0;
+};
+
+struct Conv {   // nn.Conv2d without bias
+    int w = -1;
+    int Cin = 0, Cout = 0, H = 0, W = 0, k = 0, s = 1, p = 0, OH = 0, OW = 0;
+    size_t y = 0;            // raw output (pre-BN)
+};
+
+struct Block {
+    Conv c1, c2, ds;
+    BN b1, b2, bd;
+    bool has_ds = false;
+    size_t z1 = 0, out = 0;
+};
+
+struct Deconv {   // BN -> ConvTranspose2d(k3,s2,p1,op1) -> ReLU
+    BN bn;
+    int w = -1, bias = -1;
+    int Cin = 0, Cout = 0, H = 0, W = 0;   // input spatial size
+    size_t u = 0;                          // relu output [N,2H,2W,Cout]
+};
+
+class Net {
+public:
+    explicit Net(const lbc_net_desc& d);
+    const lbc_net_desc& desc() const { return d_; }
+    std::vector<TensorInfo>& tensors() { return t_; }
+    size_t workspace_bytes() const { return ws_floats_ * sizeof(float); }
+    void set_workspace(void* p) { ws_ = static_cast<float*>(p); }
+    int check_bound(bool need_grads) const;
+
+    int forward(int N, int train, const float* image_nchw, const float* velocity, const float* command, float* pred_sel,
+                float* pred_all, hipStream_t s);
+    // stage: -1 = everything; otherwise 0 = head+decoder, 1..4 = layer4..layer1, 5 = stem (call in order)
+    int backward(const float* d_sel, const float* d_all, int stage, hipStream_t s);
+    static const int kNumStages = 6;
+
+private:
+    int add_tensor(const std::string& name, int kind, std::initializer_list<int> shape);
+    size_t alloc(size_t nfloats);
+    BN make_bn(const std::string& prefix, int C);
+    Conv make_conv(const std::string& name, int Cin, int Cout, int H, int W, int k, int s, int p);
+    float* W(size_t off) const { return ws_ + off; }
+    float* P(int ti) const { return static_cast<float*>(t_[ti].ptr); }
+    float* G(int ti) const { return t_[ti].grad; }
+
+    int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s);
+    int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
+    int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
+                    float* dx, int Cout, hipStream_t s);
+    int conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s);
+    int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s);
+    int block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s);
+
+    lbc_net_desc d_;
+    std::vector<TensorInfo> t_;
+    size_t ws_floats_ = 0;
+    float* ws_ = nullptr;
+
+    // topology
+    int stem_w_ = -1;
+    BN stem_bn_;
+    int H1_ = 0, W1_ = 0;                  // after stem + pool
+    std::vector<Block> blocks_;
+    std::vector<int> stage_first_block_;   // index of the first block of layer1..4
+    Deconv dec_[3];
+    BN head_bn_[4];
+    int head_w_[4], head_b_[4], head_px_[4], head_py_[4];
+    int HH_ = 0, HW_ = 0;                  // head map size
+
+    // workspace offsets
+    size_t xp_ = 0, y0_ = 0, p0_ = 0, idx_ = 0, hcat_ = 0, cmd_ = 0;
+    size_t partial_ = 0, partial2_ = 0, wg_partial_ = 0, head_partial_ = 0, head_coef_ = 0, head_stats_ = 0;
+    size_t pred_all_ = 0, rowstat_ = 0;
+    size_t gD_ = 0, gE_ = 0, gF_ = 0, gG_ = 0, g0_ = 0;
+    size_t partial_floats_ = 0;
+
+    // state of the last forward
+    int lastN_ = 0;
+    int last_train_ = 0;
+    float* bwd_D_ = nullptr;   // running "gradient wrt block output" buffer between stages
+    float* bwd_G_ = nullptr;
+};
+
+}  // namespace lbc

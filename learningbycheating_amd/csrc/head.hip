@@ -1,0 +1,404 @@
+// Conditional-branch waypoint head for gfx950: for each of the 4 command branches
+//   BatchNorm2d(64) -> Conv2d(64,5,1) -> SpatialSoftmax -> (x^, y^) per step,
+// stacked to (N,4,5,2) and reduced with the one-hot command to (N,5,2).
+// reference: bird_view/models/image.py:54-60,82-84 ; birdview.py:53-58,72-75 ;
+// common.py:29-35 (select_branch), 112-152 (SpatialSoftmax).
+//
+// The BatchNorm is folded into the 1x1 weights per workgroup (64x5 per branch), the
+// decoder output is streamed once through LDS in 256-pixel tiles, and the softmax
+// expectation is computed online (running max / sum / sum*pos), so no logit map is
+// ever written to HBM.  The backward recomputes the logits from the same tiles.
+//
+// Backward algebra (training mode: the 4 BatchNorms see the same batch statistics
+// but have their own gamma/beta).  With xh = (h-mean)*invstd, G = upstream gradient
+// of (x^,y^) incl. the branch-select term, p = softmax probability:
+//   dlogit[b,s,pix] = p * ((Gx*px + Gy*py) - (Gx*x^ + Gy*y^))
+//   S0[b,s] = sum dlogit ,  S1[b,s,c] = sum dlogit * xh[c]
+//   dW = gamma*S1 + beta*S0 ; dbias = S0 ; dgamma_b = sum_s W*S1 ; dbeta_b = sum_s W*S0
+//   dh[pix,c] = sum_{b,s} dlogit * (W*gamma*invstd) - invstd*(k1 + k2*xh[pix,c])
+//   k1 = sum_b gamma_b*dbeta_b / n, k2 = sum_b gamma_b*dgamma_b / n.
+#include "lbc_common.hpp"
+#include "lbc_kernels.hpp"
+
+namespace {
+
+constexpr int TP = 256;        // pixels per tile
+constexpr int LDH = 68;        // padded LDS row of 64 channels
+
+struct SoftAcc { float m, l, sx, sy; };
+
+__device__ __forceinline__ void soft_merge(SoftAcc& a, const SoftAcc& b)
+{
+    const float M = fmaxf(a.m, b.m);
+    if (M == -INFINITY) return;
+    const float fa = __expf(a.m - M), fb = __expf(b.m - M);
+    a.l = a.l * fa + b.l * fb;
+    a.sx = a.sx * fa + b.sx * fb;
+    a.sy = a.sy * fa + b.sy * fb;
+    a.m = M;
+}
+
+__device__ __forceinline__ void load_tile(const float* __restrict__ h, float* sH, int n, int HW, int tile, int tid)
+{
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int idx = tid + 256 * j;
+        const int row = idx >> 4, sg = idx & 15;
+        const int p = tile * TP + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p < HW) v = *reinterpret_cast<const float4*>(h + ((size_t)n * HW + (size_t)p) * 64 + (size_t)(sg * 4));
+        *reinterpret_cast<float4*>(&sH[row * LDH + sg * 4]) = v;
+    }
+}
+
+// folded weights of one branch: Wf[s][c] = W*gamma*invstd, bf[s] = bias + sum_c W*(beta - gamma*mean*invstd)
+__device__ __forceinline__ void fold_branch(const HeadArgs& a, int b, float* sW /*[5*64]*/, float* sB /*[5]*/, int tid, int nthr)
+{
+    const float* mean = a.mean[b];
+    const float* inv = a.invstd[b];
+    for (int idx = tid; idx < 320; idx += nthr) {
+        const int c = idx & 63;
+        sW[idx] = a.w[b][idx] * a.gamma[b][c] * inv[c];
+    }
+    if (tid < 5) {
+        float t = a.bias[b][tid];
+        for (int c = 0; c < 64; ++c)
+            t += a.w[b][tid * 64 + c] * (a.beta[b][c] - a.gamma[b][c] * mean[c] * inv[c]);
+        sB[tid] = t;
+    }
+}
+
+__global__ __launch_bounds__(256) void head_fwd_k(HeadArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sH[TP * LDH];
+    __shared__ __attribute__((aligned(16))) float sW[320];
+    __shared__ float sB[8];
+    __shared__ float sRed[4 * 5 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x, b = blockIdx.y;
+    const int HW = a.OH * a.OW;
+    fold_branch(a, b, sW, sB, tid, 256);
+    __syncthreads();
+
+    SoftAcc st[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) { st[s].m = -INFINITY; st[s].l = 0.f; st[s].sx = 0.f; st[s].sy = 0.f; }
+
+    const int ntile = (HW + TP - 1) / TP;
+    for (int tile = 0; tile < ntile; ++tile) {
+        load_tile(a.h, sH, n, HW, tile, tid);
+        __syncthreads();
+        const int p = tile * TP + tid;
+        if (p < HW) {
+            float lg[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) lg[s] = sB[s];
+#pragma unroll
+            for (int c4 = 0; c4 < 16; ++c4) {
+                const float4 f = *reinterpret_cast<const float4*>(&sH[tid * LDH + c4 * 4]);
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    const float4 w = *reinterpret_cast<const float4*>(&sW[s * 64 + c4 * 4]);
+                    lg[s] += f.x * w.x + f.y * w.y + f.z * w.z + f.w * w.w;
+                }
+            }
+            const float px = a.pos_x[b][p], py = a.pos_y[b][p];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                SoftAcc o; o.m = lg[s]; o.l = 1.f; o.sx = px; o.sy = py;
+                soft_merge(st[s], o);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) {
+            SoftAcc o;
+            o.m = __shfl_xor(st[s].m, off); o.l = __shfl_xor(st[s].l, off);
+            o.sx = __shfl_xor(st[s].sx, off); o.sy = __shfl_xor(st[s].sy, off);
+            soft_merge(st[s], o);
+        }
+        if (lane == 0) {
+            sRed[(wave * 5 + s) * 4 + 0] = st[s].m; sRed[(wave * 5 + s) * 4 + 1] = st[s].l;
+            sRed[(wave * 5 + s) * 4 + 2] = st[s].sx; sRed[(wave * 5 + s) * 4 + 3] = st[s].sy;
+        }
+    }
+    __syncthreads();
+    if (tid < 5) {
+        SoftAcc t; t.m = sRed[tid * 4]; t.l = sRed[tid * 4 + 1]; t.sx = sRed[tid * 4 + 2]; t.sy = sRed[tid * 4 + 3];
+        for (int w = 1; w < 4; ++w) {
+            SoftAcc o; o.m = sRed[(w * 5 + tid) * 4]; o.l = sRed[(w * 5 + tid) * 4 + 1];
+            o.sx = sRed[(w * 5 + tid) * 4 + 2]; o.sy = sRed[(w * 5 + tid) * 4 + 3];
+            soft_merge(t, o);
+        }
+        const size_t o2 = (((size_t)n * 4 + b) * 5 + tid) * 2;
+        a.pred_all[o2] = t.sx / t.l;
+        a.pred_all[o2 + 1] = t.sy / t.l;
+        if (a.rowstat) { a.rowstat[o2] = t.m; a.rowstat[o2 + 1] = t.l; }
+    }
+}
+
+__global__ __launch_bounds__(256) void select_branch_k(const float* __restrict__ all, const float* __restrict__ cmd,
+                                                       float* __restrict__ sel, int N)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;   // over N*10
+    if (i >= N * 10) return;
+    const int n = i / 10, r = i - n * 10;
+    float t = 0.f;
+    for (int b = 0; b < 4; ++b) t += cmd[n * 4 + b] * all[(n * 4 + b) * 10 + r];
+    sel[i] = t;
+}
+
+// upstream gradient of one (n, b, s) row incl. the branch-select path
+__device__ __forceinline__ void row_grad(const HeadBwdArgs& a, int n, int b, int s, float& gx, float& gy)
+{
+    gx = 0.f; gy = 0.f;
+    if (a.d_all) { gx = a.d_all[((n * 4 + b) * 5 + s) * 2]; gy = a.d_all[((n * 4 + b) * 5 + s) * 2 + 1]; }
+    if (a.d_sel) {
+        const float cm = a.f.cmd[n * 4 + b];
+        gx += cm * a.d_sel[(n * 5 + s) * 2]; gy += cm * a.d_sel[(n * 5 + s) * 2 + 1];
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_reduce_k(HeadBwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sH[TP * LDH];
+    __shared__ __attribute__((aligned(16))) float sW[320];
+    __shared__ float sB[8];
+    __shared__ float sRow[5 * 5];        // per step: Gx, Gy, cst, M, 1/l
+    __shared__ float sD[5 * TP];
+    __shared__ float sAcc[4 * 5 * 64];
+    __shared__ float sS0[4 * 5];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x, b = blockIdx.y;
+    const int HW = a.f.OH * a.f.OW;
+    fold_branch(a.f, b, sW, sB, tid, 256);
+    if (tid < 5) {
+        float gx, gy;
+        row_grad(a, n, b, tid, gx, gy);
+        const size_t o2 = (((size_t)n * 4 + b) * 5 + tid) * 2;
+        sRow[tid * 5 + 0] = gx; sRow[tid * 5 + 1] = gy;
+        sRow[tid * 5 + 2] = gx * a.f.pred_all[o2] + gy * a.f.pred_all[o2 + 1];
+        sRow[tid * 5 + 3] = a.f.rowstat[o2];
+        sRow[tid * 5 + 4] = 1.f / a.f.rowstat[o2 + 1];
+    }
+    __syncthreads();
+
+    const int c = tid & 63, q = tid >> 6;
+    float acc[5], s0[5];
+#pragma unroll
+    for (int s = 0; s < 5; ++s) { acc[s] = 0.f; s0[s] = 0.f; }
+
+    const int ntile = (HW + TP - 1) / TP;
+    for (int tile = 0; tile < ntile; ++tile) {
+        load_tile(a.f.h, sH, n, HW, tile, tid);
+        __syncthreads();
+        const int p = tile * TP + tid;
+        float dl[5];
+#pragma unroll
+        for (int s = 0; s < 5; ++s) dl[s] = 0.f;
+        if (p < HW) {
+            float lg[5];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) lg[s] = sB[s];
+#pragma unroll
+            for (int c4 = 0; c4 < 16; ++c4) {
+                const float4 f = *reinterpret_cast<const float4*>(&sH[tid * LDH + c4 * 4]);
+#pragma unroll
+                for (int s = 0; s < 5; ++s) {
+                    const float4 w = *reinterpret_cast<const float4*>(&sW[s * 64 + c4 * 4]);
+                    lg[s] += f.x * w.x + f.y * w.y + f.z * w.z + f.w * w.w;
+                }
+            }
+            const float px = a.f.pos_x[b][p], py = a.f.pos_y[b][p];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) {
+                const float pr = __expf(lg[s] - sRow[s * 5 + 3]) * sRow[s * 5 + 4];
+                dl[s] = pr * ((sRow[s * 5 + 0] * px + sRow[s * 5 + 1] * py) - sRow[s * 5 + 2]);
+                s0[s] += dl[s];
+            }
+        }
+#pragma unroll
+        for (int s = 0; s < 5; ++s) sD[s * TP + tid] = dl[s];
+        __syncthreads();
+        for (int pp = q * 64; pp < q * 64 + 64; ++pp) {
+            const float hv = sH[pp * LDH + c];
+#pragma unroll
+            for (int s = 0; s < 5; ++s) acc[s] += sD[s * TP + pp] * hv;
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int s = 0; s < 5; ++s) {
+        sAcc[(q * 5 + s) * 64 + c] = acc[s];
+        float t = s0[s];
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) t += __shfl_xor(t, off);
+        if (lane == 0) sS0[wave * 5 + s] = t;
+    }
+    __syncthreads();
+    float* out = a.s_partial + (size_t)n * (20 * 65) + (size_t)(b * 5) * 65;
+    for (int idx = tid; idx < 320; idx += 256) {
+        const int s = idx >> 6, cc = idx & 63;
+        out[s * 65 + cc] = sAcc[(0 * 5 + s) * 64 + cc] + sAcc[(1 * 5 + s) * 64 + cc] + sAcc[(2 * 5 + s) * 64 + cc] +
+                           sAcc[(3 * 5 + s) * 64 + cc];
+    }
+    if (tid < 5) out[tid * 65 + 64] = sS0[tid] + sS0[5 + tid] + sS0[10 + tid] + sS0[15 + tid];
+}
+
+__global__ __launch_bounds__(256) void head_bwd_finalize_k(HeadBwdFinalizeArgs a)
+{
+    __shared__ float sS[20 * 65];
+    __shared__ float sDG[4 * 64], sDB[4 * 64];
+    const int tid = threadIdx.x;
+    for (int idx = tid; idx < 20 * 65; idx += 256) {
+        double t = 0.0;
+        for (int r = 0; r < a.rows; ++r) t += (double)a.s_partial[(size_t)r * (20 * 65) + idx];
+        sS[idx] = (float)t;
+    }
+    __syncthreads();
+    // H1 -> S1 = invstd * (H1 - mean * S0)
+    for (int idx = tid; idx < 20 * 64; idx += 256) {
+        const int bs = idx >> 6, c = idx & 63;
+        const float s0 = sS[bs * 65 + 64];
+        sS[bs * 65 + c] = a.invstd[c] * (sS[bs * 65 + c] - a.mean[c] * s0);
+    }
+    __syncthreads();
+    for (int idx = tid; idx < 20 * 64; idx += 256) {
+        const int bs = idx >> 6, c = idx & 63, b = bs / 5;
+        a.dw[b][(bs - b * 5) * 64 + c] = a.gamma[b][c] * sS[bs * 65 + c] + a.beta[b][c] * sS[bs * 65 + 64];
+    }
+    if (tid < 20) a.dbias[tid / 5][tid % 5] = sS[tid * 65 + 64];
+    {
+        const int b = tid >> 6, c = tid & 63;   // 256 threads = 4 x 64
+        float dg = 0.f, db = 0.f;
+        for (int s = 0; s < 5; ++s) {
+            const float w = a.w[b][s * 64 + c];
+            dg += w * sS[(b * 5 + s) * 65 + c];
+            db += w * sS[(b * 5 + s) * 65 + 64];
+        }
+        a.dgamma[b][c] = dg; a.dbeta[b][c] = db;
+        sDG[tid] = dg; sDB[tid] = db;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double k1 = 0.0, k2 = 0.0;
+        for (int b = 0; b < 4; ++b) {
+            k1 += (double)a.gamma[b][tid] * (double)sDB[b * 64 + tid];
+            k2 += (double)a.gamma[b][tid] * (double)sDG[b * 64 + tid];
+        }
+        k1 /= (double)a.count; k2 /= (double)a.count;
+        const double inv = (double)a.invstd[tid];
+        a.chan_coef[tid] = (float)(inv * k1);
+        a.chan_coef[64 + tid] = (float)(inv * k2);
+    }
+}
+
+__global__ __launch_bounds__(256) void head_bwd_apply_k(HeadBwdArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float sH[TP * LDH];
+    __shared__ __attribute__((aligned(16))) float sW[20 * 64];
+    __shared__ float sB[4 * 8];
+    __shared__ float sRow[20 * 5];
+    __shared__ float sD[20 * TP];
+    const int tid = threadIdx.x;
+    const int n = blockIdx.x, tile = blockIdx.y;
+    const int HW = a.f.OH * a.f.OW;
+    for (int b = 0; b < 4; ++b) fold_branch(a.f, b, sW + b * 320, sB + b * 8, tid, 256);
+    if (tid < 20) {
+        const int b = tid / 5, s = tid - b * 5;
+        float gx, gy;
+        row_grad(a, n, b, s, gx, gy);
+        const size_t o2 = (((size_t)n * 4 + b) * 5 + s) * 2;
+        sRow[tid * 5 + 0] = gx; sRow[tid * 5 + 1] = gy;
+        sRow[tid * 5 + 2] = gx * a.f.pred_all[o2] + gy * a.f.pred_all[o2 + 1];
+        sRow[tid * 5 + 3] = a.f.rowstat[o2];
+        sRow[tid * 5 + 4] = 1.f / a.f.rowstat[o2 + 1];
+    }
+    load_tile(a.f.h, sH, n, HW, tile, tid);
+    __syncthreads();
+    const int p = tile * TP + tid;
+    {
+        float lg[20];
+#pragma unroll
+        for (int bs = 0; bs < 20; ++bs) lg[bs] = sB[(bs / 5) * 8 + (bs % 5)];
+        if (p < HW) {
+#pragma unroll
+            for (int c4 = 0; c4 < 16; ++c4) {
+                const float4 f = *reinterpret_cast<const float4*>(&sH[tid * LDH + c4 * 4]);
+#pragma unroll
+                for (int bs = 0; bs < 20; ++bs) {
+                    const float4 w = *reinterpret_cast<const float4*>(&sW[bs * 64 + c4 * 4]);
+                    lg[bs] += f.x * w.x + f.y * w.y + f.z * w.z + f.w * w.w;
+                }
+            }
+        }
+#pragma unroll
+        for (int bs = 0; bs < 20; ++bs) {
+            float d = 0.f;
+            if (p < HW) {
+                const int b = bs / 5;
+                const float px = a.f.pos_x[b][p], py = a.f.pos_y[b][p];
+                const float pr = __expf(lg[bs] - sRow[bs * 5 + 3]) * sRow[bs * 5 + 4];
+                d = pr * ((sRow[bs * 5 + 0] * px + sRow[bs * 5 + 1] * py) - sRow[bs * 5 + 2]);
+            }
+            sD[bs * TP + tid] = d;
+        }
+    }
+    __syncthreads();
+    const int c = tid & 63, q = tid >> 6;
+    float wf[20];
+#pragma unroll
+    for (int bs = 0; bs < 20; ++bs) wf[bs] = sW[bs * 64 + c];
+    const float c1 = a.chan_coef[c], c2 = a.chan_coef[64 + c];
+    const float mu = a.f.mean[0][c], iv = a.f.invstd[0][c];
+    for (int pp = q * 64; pp < q * 64 + 64; ++pp) {
+        const int pg = tile * TP + pp;
+        if (pg >= HW) break;
+        float o = -c1 - c2 * ((sH[pp * LDH + c] - mu) * iv);
+#pragma unroll
+        for (int bs = 0; bs < 20; ++bs) o += sD[bs * TP + pp] * wf[bs];
+        a.dh[((size_t)n * HW + (size_t)pg) * 64 + c] = o;
+    }
+}
+
+}  // namespace
+
+int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
+    hipLaunchKernelGGL(head_fwd_k, dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
+    int rc = lbc_check_launch("head_fwd");
+    if (rc) return rc;
+    if (a.pred_sel) {
+        hipLaunchKernelGGL(select_branch_k, dim3((unsigned)lbc_cdiv(a.N * 10, 256)), dim3(256), 0, s, a.pred_all, a.cmd,
+                           a.pred_sel, a.N);
+        rc = lbc_check_launch("select_branch");
+    }
+    return rc;
+}
+
+int lbc_head_bwd_rows(int N) { return N; }
+
+int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.f.mean[0] == a.f.mean[1] && a.f.mean[0] == a.f.mean[2] && a.f.mean[0] == a.f.mean[3],
+                "head backward requires training-mode (shared batch) statistics");
+    hipLaunchKernelGGL(head_bwd_reduce_k, dim3((unsigned)a.f.N, 4), dim3(256), 0, s, a);
+    return lbc_check_launch("head_bwd_reduce");
+}
+
+int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s)
+{
+    hipLaunchKernelGGL(head_bwd_finalize_k, dim3(1), dim3(256), 0, s, a);
+    return lbc_check_launch("head_bwd_finalize");
+}
+
+int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s)
+{
+    const int HW = a.f.OH * a.f.OW;
+    hipLaunchKernelGGL(head_bwd_apply_k, dim3((unsigned)a.f.N, (unsigned)lbc_cdiv(HW, TP)), dim3(256), 0, s, a);
+    return lbc_check_launch("head_bwd_apply");
+}

@@ -74,7 +74,9 @@ struct WgradArgs {
     const float* p;
     const float* q;
     float* partial;       // [nsplit][CP][T][CQ]
-    // optional fused transform of q on load (BatchNorm apply [+relu]) per q channel
+    // optional fused transforms on load (BatchNorm apply [+relu]) per channel
+    const float* p_scale;
+    const float* p_shift;
     const float* q_scale;
     const float* q_shift;
     int q_relu;

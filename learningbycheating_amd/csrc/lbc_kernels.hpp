@@ -1,0 +1,172 @@
+// Internal launcher interfaces of the HBM-bound kernels (bn.hip, pool.hip, head.hip,
+// loss.hip, adam.hip, stem.hip).  All tensors NHWC fp32 unless stated otherwise.
+#pragma once
+#include "lbc_common.hpp"
+
+// ---- BatchNorm forward -----------------------------------------------------------
+struct BnFinalizeArgs {
+    const float* partial;        // [rows][2][C] (sum, sum^2); unused in eval
+    int rows, C;
+    long long count;             // N*H*W
+    const float* gamma;          // nullable (=1)
+    const float* beta;           // nullable (=0)
+    float* running_mean;         // train: updated (nullable); eval: read
+    float* running_var;
+    long long* num_batches_tracked;   // nullable
+    float momentum, eps;
+    int train;
+    float* scale;                // out: gamma*invstd
+    float* shift;                // out: beta - mean*scale
+    float* save_mean;            // out (nullable)
+    float* save_invstd;
+};
+int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s);
+int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
+
+struct BnApplyArgs {
+    const float* x; float* y;
+    long long pixels; int C;
+    const float* scale; const float* shift;
+    const float* resid;          // nullable
+    const float* rscale;         // nullable: residual is itself BatchNorm'ed (downsample path)
+    const float* rshift;
+    int relu;
+};
+int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s);
+
+// ---- per-channel reductions --------------------------------------------------------
+struct ChanReduceArgs {
+    const float* x;              // op0: tensor to take statistics of; op1: pre-BN activation (nullable)
+    const float* dz;             // op1: upstream gradient
+    const float* mask;           // op1: ReLU mask source (g = dz where mask > 0), nullable
+    float* g_out;                // op1: optional store of the masked gradient (may alias dz)
+    const float* mean;           // op1: nullable
+    const float* invstd;
+    float* partial;              // [rows][2][C]
+    long long pixels; int C;
+    long long pix_per_block;     // filled by the launcher
+};
+int lbc_chan_reduce_rows(long long pixels, int C);
+int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s);
+
+struct BnBwdFinalizeArgs {
+    const float* partial; int rows, C; long long count;
+    const float* gamma; const float* mean; const float* invstd;
+    int train;
+    float* dgamma; float* dbeta;          // nullable
+    float* coefA; float* coefB; float* coefD;   // nullable (all or none): A = gamma*invstd, k1, k2
+};
+int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
+
+struct BnBwdApplyArgs {
+    const float* g; const float* mask; const float* x;
+    const float* coefA; const float* coefB; const float* coefD;   // A, k1, k2
+    const float* mean; const float* invstd;
+    float* dx;                   // [pixels][Cout]
+    long long pixels; int C, Cout;
+    int accum;                   // dx += ...
+};
+int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
+
+int lbc_concat_velocity(const float* t, const float* vel, float* h, int N, int hw, int Ct, int Cv, hipStream_t s);
+
+// ---- stem: input preparation, 7x7/2 convolution, BN+ReLU+maxpool -------------------
+// prep: NCHW fp32 image -> (optionally ImageNet-normalised) NHWC fp32 with a 3-pixel
+// zero border: xp[N][H+6][W+6][C]
+struct NormConst { float mean[8]; float stdv[8]; int enabled; };
+int lbc_prep_input(const float* img_nchw, float* xp, int N, int C, int H, int W, const NormConst& nc, hipStream_t s);
+struct StemArgs {
+    const float* xp;             // [N][H+6][W+6][Cin]
+    const float* w;              // [64][7][7][Cin]
+    float* y;                    // [N][H/2][W/2][64]
+    float* stats;                // [rows][2][64] or nullptr
+    int N, H, W, Cin;
+};
+int lbc_stem_rows(const StemArgs& a);
+int lbc_stem_fwd(const StemArgs& a, hipStream_t s);
+struct StemWgradArgs {
+    const float* xp; const float* dy; float* partial;   // partial [nsplit][64][7][7*Cin]
+    int N, H, W, Cin, nsplit;
+};
+int lbc_stem_wgrad_split(int N, int H, int W);
+int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s);
+
+struct PoolFwdArgs {
+    const float* y;              // [N][H][W][C] pre-BN stem output
+    const float* scale; const float* shift;
+    float* p;                    // [N][H/2][W/2][C]
+    unsigned char* idx;          // [N][H/2][W/2][C] arg-max tap (0..8), nullable
+    int N, H, W, C;
+};
+int lbc_bn_relu_maxpool_fwd(const PoolFwdArgs& a, hipStream_t s);
+struct PoolBwdArgs {
+    const float* dp;             // [N][H/2][W/2][C]
+    const unsigned char* idx;
+    const float* y;              // [N][H][W][C]
+    const float* scale; const float* shift;   // forward BN affine (ReLU mask)
+    const float* mean; const float* invstd;
+    float* g;                    // [N][H][W][C] masked gradient wrt the BN output
+    float* partial;              // [rows][2][C]
+    int N, H, W, C;
+    long long pix_per_block;
+};
+int lbc_pool_bwd_rows(int N, int H, int W, int C);
+int lbc_maxpool_relu_bwd_reduce(PoolBwdArgs a, hipStream_t s);
+
+// ---- waypoint head: 4 x (BN64 -> 1x1 conv 64->5 -> spatial softmax) + branch select --
+struct HeadArgs {
+    const float* h;              // [N][HW][64] decoder output
+    const float* mean[4];        // per branch BatchNorm statistics [64] (train: all four point at the batch stats)
+    const float* invstd[4];
+    const float* gamma[4];       // [64]
+    const float* beta[4];
+    const float* w[4];           // [5][64]
+    const float* bias[4];        // [5]
+    const float* cmd;            // [N][4] one-hot command
+    const float* pos_x[4];       // SpatialSoftmax buffers of each branch, [OH*OW]
+    const float* pos_y[4];
+    float* pred_all;             // [N][4][5][2]
+    float* pred_sel;             // [N][5][2] (nullable)
+    float* rowstat;              // [N][4][5][2] (max, sum exp) saved for backward (nullable)
+    int N, OH, OW;               // softmax map is OH x OW (pos_x over OW, pos_y over OH)
+};
+int lbc_head_fwd(const HeadArgs& a, hipStream_t s);
+struct HeadBwdArgs {
+    HeadArgs f;
+    const float* d_all;          // [N][4][5][2] nullable
+    const float* d_sel;          // [N][5][2] nullable
+    float* s_partial;            // [N][20*65] : per (branch,step): sum dlogit*h[c] (64) and sum dlogit
+    float* dh;                   // [N][HW][64]
+    const float* chan_coef;      // pass 2: [2][64] per-channel coefficients (see head.hip)
+};
+int lbc_head_bwd_rows(int N);
+int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s);
+struct HeadBwdFinalizeArgs {
+    const float* s_partial; int rows; long long count;   // count = N*HW
+    const float* gamma[4]; const float* beta[4]; const float* w[4];
+    const float* mean; const float* invstd;              // shared batch statistics [64]
+    float* dgamma[4]; float* dbeta[4]; float* dw[4]; float* dbias[4];
+    float* chan_coef;            // [2][64]: invstd*k1, invstd*k2
+};
+int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s);
+int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s);
+
+// ---- losses (phase 0 / phase 1 / bird-view) -------------------------------------------
+struct LossArgs {
+    const float* pred;           // student output, normalised [-1,1]
+    const float* target;         // teacher output / targets
+    float* loss_per_sample;      // [N]
+    float* dpred;                // gradient of mean(loss) * grad_scale wrt pred
+    int N, R;                    // R = rows per sample (5 or 20), each row = (x, y)
+    float grad_scale;            // 1/N (times 1/world_size under data parallelism)
+    // camera model (reference training/train_image_phase{0,1}.py CoordConverter)
+    float w, h, fov, world_y, fixed_offset, pixels_per_meter, crop_size;
+};
+int lbc_loss_phase1(const LossArgs& a, hipStream_t s);   // differentiable unprojection + L1 in map space
+int lbc_loss_phase0(const LossArgs& a, hipStream_t s);   // teacher map -> image projection (clip) + L1 in image space
+int lbc_loss_l1(const LossArgs& a, float target_scale, float target_shift, hipStream_t s);   // bird-view BC loss
+
+// ---- Adam (multi-tensor) ------------------------------------------------------------------
+struct AdamChunk { float* p; const float* g; float* m; float* v; int n; int pad; };
+int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, float lr, float beta1, float beta2, float eps,
+                  float weight_decay, int step, hipStream_t s);

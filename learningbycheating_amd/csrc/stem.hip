@@ -1,0 +1,258 @@
+// ResNet stem for gfx950: input preparation, the 7x7/2 convolution (Cin = 3 RGB or
+// 7 bird-view channels -> 64) and its weight gradient, on the exact-f32 MFMA.
+// reference: bird_view/models/resnet.py:102-103,148 (conv1), common.py:101-109
+// (NormalizeV2), image.py:71.
+//
+// Data layout trick: the image is held NHWC with a 3-pixel zero border
+// (xp[N][H+6][W+6][Cin]), so one filter ROW of one output pixel is 7*Cin
+// *contiguous* floats starting at xp[n][2oy+r][2ox][0] and needs no bounds checks.
+// The implicit GEMM therefore walks depth as 7 chunks (r = 0..6) of L = 7*Cin
+// channels (padded to a multiple of 8 with zeros in LDS); the weight tensor in
+// channels_last order [64][7][7][Cin] has exactly the same [r][L] structure.
+// There is no input gradient (the image is a leaf).
+#include "lbc_common.hpp"
+#include "lbc_kernels.hpp"
+
+namespace {
+
+__global__ __launch_bounds__(256) void prep_input_k(const float* __restrict__ img, float* __restrict__ xp, int N, int C,
+                                                    int H, int W, NormConst nc)
+{
+    const long long total = (long long)N * H * W;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    const int Hp = H + 6, Wp = W + 6;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int x = (int)(i % W);
+        const long long t = i / W;
+        const int y = (int)(t % H);
+        const int n = (int)(t / H);
+        float* dst = xp + ((size_t)(n * Hp + y + 3) * Wp + (size_t)(x + 3)) * C;
+        for (int c = 0; c < C; ++c) {
+            float v = img[((size_t)(n * C + c) * H + y) * W + x];
+            if (nc.enabled) v = (v - nc.mean[c]) / nc.stdv[c];
+            dst[c] = v;
+        }
+    }
+}
+
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
+{
+    constexpr int L = 7 * CIN;
+    constexpr int L8 = (L + 7) / 8 * 8;
+    constexpr int LD = L8 + 4;
+    constexpr int BM = 128, BN = 64, MT = 2;
+    __shared__ __attribute__((aligned(16))) float sA[BM * LD];
+    __shared__ __attribute__((aligned(16))) float sB[BN * LD];
+    __shared__ int sRow[BM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int OH = a.H / 2, OW = a.W / 2;
+    const int Hp = a.H + 6, Wp = a.W + 6;
+    const int M = a.N * OH * OW;
+    const int m0 = blockIdx.x * BM;
+
+    if (tid < BM) {
+        const int m = m0 + tid;
+        int base = -1;
+        if (m < M) {
+            const int n = m / (OH * OW);
+            const int rem = m - n * OH * OW;
+            const int oy = rem / OW, ox = rem - oy * OW;
+            base = ((n * Hp + 2 * oy) * Wp + 2 * ox) * CIN;
+        }
+        sRow[tid] = base;
+    }
+    __syncthreads();
+
+    f32x16 acc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+
+    for (int r = 0; r < 7; ++r) {
+        for (int idx = tid; idx < BM * L8; idx += 256) {
+            const int row = idx / L8, j = idx - row * L8;
+            const int base = sRow[row];
+            float v = 0.f;
+            if (j < L && base >= 0) v = a.xp[(size_t)base + (size_t)(r * Wp * CIN + j)];
+            sA[row * LD + j] = v;
+        }
+        for (int idx = tid; idx < BN * L8; idx += 256) {
+            const int row = idx / L8, j = idx - row * L8;
+            float v = 0.f;
+            if (j < L) v = a.w[(size_t)row * (7 * L) + (size_t)(r * L + j)];
+            sB[row * LD + j] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int g = 0; g < L8 / 8; ++g) {
+            f32x4 af[MT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+                af[i] = *reinterpret_cast<const f32x4*>(&sA[((wm * MT + i) * 32 + l31) * LD + g * 8 + kh * 4]);
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(&sB[(wn * 32 + l31) * LD + g * 8 + kh * 4]);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][i], bf[i], acc[mi], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    float s1 = 0.f, s2 = 0.f;
+    const int col = wn * 32 + l31;
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int row = (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            const int m = m0 + row;
+            if (m < M) {
+                const float v = acc[mi][e];
+                a.y[(size_t)m * BN + col] = v;
+                s1 += v; s2 += v * v;
+            }
+        }
+    if (a.stats) {
+        float* red = sA;   // [2 wm][2][64]
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (kh == 0) { red[(wm * 2 + 0) * BN + col] = s1; red[(wm * 2 + 1) * BN + col] = s2; }
+        __syncthreads();
+        if (tid < BN) {
+            float* dst = a.stats + (size_t)blockIdx.x * 2 * BN;
+            dst[tid] = red[tid] + red[2 * BN + tid];
+            dst[BN + tid] = red[BN + tid] + red[3 * BN + tid];
+        }
+    }
+}
+
+// dW[co][r][j] = sum_m dy[m][co] * xp_row(m, r)[j]; grid (split, r)
+template <int CIN>
+__global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_per_split)
+{
+    constexpr int L = 7 * CIN;
+    constexpr int LQ = (L + 31) / 32 * 32;   // 32 or 64
+    constexpr int QT = LQ / 32;              // q tiles
+    constexpr int BR = 32;
+    constexpr int LDP = 64 + 4, LDQ = LQ + 4;
+    __shared__ __attribute__((aligned(16))) float sP[BR * LDP];
+    __shared__ __attribute__((aligned(16))) float sQ[BR * LDQ];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int pt = wave & 1;        // which 32 output channels
+    const int qt = wave >> 1;       // which 32 columns of the filter row
+    const bool active = qt < QT;
+    const int OH = a.H / 2, OW = a.W / 2;
+    const int Hp = a.H + 6, Wp = a.W + 6;
+    const int M = a.N * OH * OW;
+    const int split = blockIdx.x, r = blockIdx.y;
+    const int mbeg = split * rows_per_split;
+    const int mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
+    const int nchunk = mend > mbeg ? (mend - mbeg + BR - 1) / BR : 0;
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int mc = mbeg + ch * BR;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int idx = tid + 256 * j;
+            const int row = idx >> 4, sg = idx & 15;
+            const int m = mc + row;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < mend) v = *reinterpret_cast<const float4*>(a.dy + (size_t)m * 64 + (size_t)(sg * 4));
+            *reinterpret_cast<float4*>(&sP[row * LDP + sg * 4]) = v;
+        }
+        for (int idx = tid; idx < BR * LQ; idx += 256) {
+            const int row = idx / LQ, j = idx - row * LQ;
+            const int m = mc + row;
+            float v = 0.f;
+            if (j < L && m < mend) {
+                const int n = m / (OH * OW);
+                const int rem = m - n * OH * OW;
+                const int oy = rem / OW, ox = rem - oy * OW;
+                v = a.xp[(size_t)(((n * Hp + 2 * oy + r) * Wp + 2 * ox) * CIN) + (size_t)j];
+            }
+            sQ[row * LDQ + j] = v;
+        }
+        __syncthreads();
+        if (active) {
+#pragma unroll
+            for (int st = 0; st < BR / 2; ++st) {
+                const int k = 2 * st + kh;
+                const float af = sP[k * LDP + pt * 32 + l31];
+                const float bf = sQ[k * LDQ + qt * 32 + l31];
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    if (active) {
+        float* out = a.partial + (size_t)split * 64 * 7 * L;
+        const int j = qt * 32 + l31;
+        if (j < L) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                out[(size_t)co * (7 * L) + (size_t)(r * L + j)] = acc[e];
+            }
+        }
+    }
+}
+
+}  // namespace
+
+int lbc_prep_input(const float* img_nchw, float* xp, int N, int C, int H, int W, const NormConst& nc, hipStream_t s)
+{
+    LBC_REQUIRE(C <= 8, "prep_input: at most 8 channels");
+    const size_t bytes = (size_t)N * (H + 6) * (W + 6) * C * sizeof(float);
+    if (hipMemsetAsync(xp, 0, bytes, s) != hipSuccess) { lbc_set_error("prep_input: memset failed"); return LBC_ELAUNCH; }
+    const long long total = (long long)N * H * W;
+    long long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(prep_input_k, dim3((unsigned)blocks), dim3(256), 0, s, img_nchw, xp, N, C, H, W, nc);
+    return lbc_check_launch("prep_input");
+}
+
+int lbc_stem_rows(const StemArgs& a) { return lbc_cdiv((long long)a.N * (a.H / 2) * (a.W / 2), 128); }
+
+int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.Cin == 3 || a.Cin == 7, "stem: Cin=%d unsupported (3 or 7)", a.Cin);
+    LBC_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, "stem: odd image size");
+    LBC_REQUIRE((long long)a.N * (a.H + 6) * (a.W + 6) * a.Cin < (1ll << 31), "stem: input too large");
+    const dim3 grid((unsigned)lbc_stem_rows(a));
+    if (a.Cin == 3) hipLaunchKernelGGL((stem_fwd_k<3>), grid, dim3(256), 0, s, a);
+    else            hipLaunchKernelGGL((stem_fwd_k<7>), grid, dim3(256), 0, s, a);
+    return lbc_check_launch("stem_fwd");
+}
+
+int lbc_stem_wgrad_split(int N, int H, int W)
+{
+    const long long chunks = ((long long)N * (H / 2) * (W / 2) + 31) / 32;
+    long long ns = chunks / 8;
+    if (ns > 256) ns = 256;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.Cin == 3 || a.Cin == 7, "stem_wgrad: Cin=%d unsupported", a.Cin);
+    const long long M = (long long)a.N * (a.H / 2) * (a.W / 2);
+    const long long chunks = (M + 31) / 32;
+    const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 32;
+    const dim3 grid((unsigned)a.nsplit, 7);
+    if (a.Cin == 3) hipLaunchKernelGGL((stem_wgrad_k<3>), grid, dim3(256), 0, s, a, rows_per_split);
+    else            hipLaunchKernelGGL((stem_wgrad_k<7>), grid, dim3(256), 0, s, a, rows_per_split);
+    return lbc_check_launch("stem_wgrad");
+}

@@ -1,0 +1,106 @@
+"""Python handle on the native network executor (csrc/engine.cpp, C ABI lbc_net_*)."""
+import ctypes
+
+import torch
+
+from . import _lib
+
+
+def is_channels_last_4d(t):
+    """True when a 4-D tensor's memory order is [d0][d2][d3][d1] (or the distinction is void)."""
+    if t.dim() != 4:
+        return True
+    o, i, kh, kw = t.shape
+    want = (kh * kw * i, 1, kw * i, i)
+    st = t.stride()
+    return all(t.shape[d] == 1 or st[d] == want[d] for d in range(4))
+
+
+class PolicyEngine:
+    """Binds an nn.Module's parameters/buffers (by state_dict name) to an lbc_net plan."""
+
+    def __init__(self, arch, in_channels, height, width, normalize, max_batch, device):
+        lib = _lib.get()
+        self.desc = _lib.NetDesc(arch, in_channels, height, width, int(normalize), max_batch)
+        h = ctypes.c_void_p()
+        _lib.check(lib.lbc_net_create(ctypes.byref(self.desc), ctypes.byref(h)), "net_create")
+        self.handle = h
+        self.device = device
+        self.max_batch = max_batch
+        n = lib.lbc_net_num_tensors(h)
+        self.names, self.kinds, self.shapes = [], [], []
+        buf = ctypes.create_string_buffer(256)
+        kind, ndim = ctypes.c_int(), ctypes.c_int()
+        shape = (ctypes.c_int * 4)()
+        for i in range(n):
+            _lib.check(lib.lbc_net_tensor_info(h, i, buf, 256, ctypes.byref(kind), ctypes.byref(ndim), shape), "tensor_info")
+            self.names.append(buf.value.decode())
+            self.kinds.append(kind.value)
+            self.shapes.append(tuple(shape[k] for k in range(ndim.value)))
+        self.workspace = torch.empty(lib.lbc_net_workspace_bytes(h), dtype=torch.uint8, device=device)
+        self._bound_key = None
+        self.grad_flat = None
+        self.grad_views = {}
+        self._keep = None
+
+    def __del__(self):
+        try:
+            if self.handle:
+                _lib.get().lbc_net_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # ---- binding ---------------------------------------------------------------------
+    def bind(self, tensors, with_grads, param_order=None):
+        """tensors: dict name -> tensor (parameters and buffers).  When with_grads, one flat fp32
+        gradient buffer is (re)used and every parameter gets a view of it in the parameter's own
+        memory order; param_order (names) fixes the layout of the flat buffer (bucket order)."""
+        key = (tuple(tensors[n].data_ptr() for n in self.names), bool(with_grads))
+        if key == self._bound_key:
+            return
+        for n, shape in zip(self.names, self.shapes):
+            t = tensors[n]
+            if tuple(t.shape) != shape:
+                raise RuntimeError("engine.bind: %s has shape %s, expected %s" % (n, tuple(t.shape), shape))
+            if t.dim() == 4 and not is_channels_last_4d(t):
+                raise RuntimeError("engine.bind: %s must be in channels_last memory order" % n)
+            if t.device != self.workspace.device:
+                raise RuntimeError("engine.bind: %s lives on %s, engine on %s" % (n, t.device, self.workspace.device))
+        nt = len(self.names)
+        tp = (ctypes.c_void_p * nt)(*[tensors[n].data_ptr() for n in self.names])
+        gp = None
+        if with_grads:
+            pnames = [n for n, k in zip(self.names, self.kinds) if k == 0]
+            order = [n for n in (param_order or pnames) if n in set(pnames)]
+            assert set(order) == set(pnames)
+            total = sum(tensors[n].numel() for n in order)
+            if self.grad_flat is None or self.grad_flat.numel() != total:
+                self.grad_flat = torch.zeros(total, dtype=torch.float32, device=self.workspace.device)
+            self.grad_views, self.grad_offsets, off = {}, {}, 0
+            for n in order:
+                t = tensors[n]
+                self.grad_views[n] = torch.as_strided(self.grad_flat, t.shape, t.stride(), off)
+                self.grad_offsets[n] = (off, t.numel())
+                off += t.numel()
+            gp = (ctypes.c_void_p * nt)(*[self.grad_views[n].data_ptr() if k == 0 else 0 for n, k in zip(self.names, self.kinds)])
+        _lib.check(_lib.get().lbc_net_bind(self.handle, _lib.ptr(self.workspace), tp, gp), "net_bind")
+        self._bound_key = key
+        self._keep = tensors
+
+    # ---- execution --------------------------------------------------------------------
+    def forward(self, image, velocity, command, train):
+        n = image.shape[0]
+        pred_sel = torch.empty((n, 5, 2), dtype=torch.float32, device=image.device)
+        pred_all = torch.empty((n, 4, 5, 2), dtype=torch.float32, device=image.device)
+        _lib.check(_lib.get().lbc_net_forward(self.handle, n, int(train), _lib.ptr(image), _lib.ptr(velocity), _lib.ptr(command),
+                                              _lib.ptr(pred_sel), _lib.ptr(pred_all), _lib.stream_for(image)), "net_forward")
+        return pred_sel, pred_all
+
+    def backward(self, d_sel, d_all, stage=-1):
+        ref = d_sel if d_sel is not None else d_all
+        _lib.check(_lib.get().lbc_net_backward(self.handle, _lib.ptr(d_sel), _lib.ptr(d_all), stage, _lib.stream_for(ref)), "net_backward")
+
+    @staticmethod
+    def num_stages():
+        return _lib.get().lbc_net_num_stages()
