@@ -106,7 +106,7 @@ int lbc_net_num_stages(void);
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream);
 
 /* Losses (forward value per sample + gradient wrt pred), reference training/train_image_phase1.py:35-70,
- * train_image_phase0.py:36-89, train_birdview.py:33-54.  kind: 0 phase-0, 1 phase-1, 2 bird-view L1.
+ * train_image_phase0.py:36-89, train_birdview.py:33-54.  kind: 0 phase-0, 1 phase-1, 2 bird-view L1 (pixel targets), 3 L1 vs normalised targets.
  * rows = waypoints per sample (5 or 20).  dpred = grad_scale * d(sum_n loss[n])/dpred. */
 typedef struct lbc_camera { float w, h, fov, world_y, fixed_offset, pixels_per_meter, crop_size; } lbc_camera;
 int lbc_loss(int kind, const lbc_camera* cam, const float* pred, const float* target, int N, int rows,
@@ -115,8 +115,14 @@ int lbc_loss(int kind, const lbc_camera* cam, const float* pred, const float* ta
 /* Multi-tensor Adam (torch.optim.Adam semantics; reference training/train_image_phase1.py:252).
  * chunk table lives in device memory: see lbc_adam_chunk. */
 typedef struct lbc_adam_chunk { float* p; const float* g; float* m; float* v; int n; int pad; } lbc_adam_chunk;
-int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, float lr, float beta1, float beta2,
-                  float eps, float weight_decay, int step, lbc_stream_t stream);
+int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, lbc_stream_t stream);
+
+/* Built-in launch profiler: HIP-event timing of every kernel launch on its own stream, booked per
+ * kernel class together with the launch's algorithmic flops and HBM bytes.  report() writes one
+ * line per class "name count total_ms total_flops total_bytes" and resets the log. */
+int lbc_profile_enable(int on);
+int lbc_profile_report(char* buf, int cap);
 
 #ifdef __cplusplus
 }

@@ -11,7 +11,7 @@
 namespace {
 
 __global__ __launch_bounds__(256) void adam_k(const AdamChunk* __restrict__ chunks, float lr_over_bc1, float inv_bc2_sqrt,
-                                              float beta1, float beta2, float eps, float wd)
+                                              float beta1, float beta2, float omb1, float omb2, float eps, float wd)
 {
     const AdamChunk ch = chunks[blockIdx.x];
     const int n4 = ch.n >> 2;
@@ -23,8 +23,8 @@ __global__ __launch_bounds__(256) void adam_k(const AdamChunk* __restrict__ chun
 #define LBC_ADAM1(c)                                                   \
         {                                                              \
             float gg = g.c + wd * p.c;                                 \
-            m.c = m.c + (gg - m.c) * (1.f - beta1);                    \
-            v.c = beta2 * v.c + (1.f - beta2) * gg * gg;               \
+            m.c = m.c + (gg - m.c) * omb1;                    \
+            v.c = beta2 * v.c + omb2 * gg * gg;               \
             const float denom = sqrtf(v.c) * inv_bc2_sqrt + eps;       \
             p.c = p.c - lr_over_bc1 * (m.c / denom);                   \
         }
@@ -36,8 +36,8 @@ __global__ __launch_bounds__(256) void adam_k(const AdamChunk* __restrict__ chun
     for (int i = (n4 << 2) + threadIdx.x; i < ch.n; i += 256) {
         float p = ch.p[i], m = ch.m[i], v = ch.v[i];
         const float gg = ch.g[i] + wd * p;
-        m = m + (gg - m) * (1.f - beta1);
-        v = beta2 * v + (1.f - beta2) * gg * gg;
+        m = m + (gg - m) * omb1;
+        v = beta2 * v + omb2 * gg * gg;
         const float denom = sqrtf(v) * inv_bc2_sqrt + eps;
         p = p - lr_over_bc1 * (m / denom);
         ch.p[i] = p; ch.m[i] = m; ch.v[i] = v;
@@ -46,15 +46,16 @@ __global__ __launch_bounds__(256) void adam_k(const AdamChunk* __restrict__ chun
 
 }  // namespace
 
-int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, hipStream_t s)
+int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int step, hipStream_t s)
 {
     LBC_REQUIRE(nchunks > 0 && step >= 1, "adam: bad args");
-    const double bc1 = 1.0 - pow((double)beta1, (double)step);
-    const double bc2 = 1.0 - pow((double)beta2, (double)step);
-    const float lr_over_bc1 = (float)((double)lr / bc1);
+    const double bc1 = 1.0 - pow(beta1, (double)step);
+    const double bc2 = 1.0 - pow(beta2, (double)step);
+    const float lr_over_bc1 = (float)(lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    hipLaunchKernelGGL(adam_k, dim3((unsigned)nchunks), dim3(256), 0, s, chunks_dev, lr_over_bc1, inv_bc2_sqrt, beta1, beta2,
-                       eps, weight_decay);
+    LbcProfScope prof("adam", 0.0, 0.0, s);
+    hipLaunchKernelGGL(adam_k, dim3((unsigned)nchunks), dim3(256), 0, s, chunks_dev, lr_over_bc1, inv_bc2_sqrt, (float)beta1,
+                       (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay);
     return lbc_check_launch("adam");
 }

@@ -246,6 +246,7 @@ int grid_for(long long total4)
 int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s)
 {
     dim3 grid((unsigned)lbc_cdiv(cols, 256), (unsigned)out_rows);
+    LbcProfScope prof("partial_reduce", 0.0, 4.0 * (double)rows * cols, s);
     hipLaunchKernelGGL(partial_reduce_k, grid, dim3(256), 0, s, in, rows, cols, out);
     return lbc_check_launch("partial_reduce");
 }
@@ -253,6 +254,7 @@ int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_
 int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C > 0 && a.scale && a.shift, "bn_finalize: bad args");
+    LbcProfScope prof("bn_finalize", 0.0, 4.0 * (double)a.rows * 2 * a.C, s);
     hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(64), 0, s, a);
     return lbc_check_launch("bn_finalize");
 }
@@ -260,6 +262,7 @@ int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s)
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 4 == 0 && a.pixels > 0, "bn_apply: bad shape");
+    LbcProfScope prof("bn_apply", 0.0, 4.0 * (double)a.pixels * a.C * (a.resid ? 3 : 2), s);
     hipLaunchKernelGGL(bn_apply_k, dim3((unsigned)grid_for(a.pixels * (a.C / 4))), dim3(256), 0, s, a);
     return lbc_check_launch("bn_apply");
 }
@@ -280,6 +283,8 @@ int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
     LBC_REQUIRE(a.C % 4 == 0 && a.C / 4 <= 256, "chan_reduce: C=%d unsupported", a.C);
     const int rows = lbc_chan_reduce_rows(a.pixels, a.C);
     a.pix_per_block = (a.pixels + rows - 1) / rows;
+    LbcProfScope prof(op == 0 ? "channel_stats" : "bn_bwd_reduce", 0.0,
+                      4.0 * (double)a.pixels * a.C * (op == 0 ? 1 : (1 + (a.mask ? 1 : 0) + (a.x ? 1 : 0) + (a.g_out ? 1 : 0))), s);
     if (op == 0) hipLaunchKernelGGL((channel_reduce_k<0>), dim3((unsigned)rows), dim3(256), 0, s, a);
     else         hipLaunchKernelGGL((channel_reduce_k<1>), dim3((unsigned)rows), dim3(256), 0, s, a);
     return lbc_check_launch("channel_reduce");
@@ -287,6 +292,7 @@ int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
 
 int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s)
 {
+    LbcProfScope prof("bn_bwd_finalize", 0.0, 4.0 * (double)a.rows * 2 * a.C, s);
     hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(64), 0, s, a);
     return lbc_check_launch("bn_bwd_finalize");
 }
@@ -294,6 +300,7 @@ int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s)
 int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 4 == 0 && a.Cout % 4 == 0 && a.Cout <= a.C, "bn_bwd_apply: bad channels");
+    LbcProfScope prof("bn_bwd_apply", 0.0, 4.0 * (double)a.pixels * (a.C * (a.mask ? 3.0 : 2.0) + a.Cout * (a.accum ? 2.0 : 1.0)), s);
     hipLaunchKernelGGL(bn_bwd_apply_k, dim3((unsigned)grid_for(a.pixels * (a.Cout / 4))), dim3(256), 0, s, a);
     return lbc_check_launch("bn_bwd_apply");
 }
@@ -302,6 +309,7 @@ int lbc_concat_velocity(const float* t, const float* vel, float* h, int N, int h
 {
     LBC_REQUIRE(Ct % 4 == 0 && Cv % 4 == 0, "concat_velocity: channels must be multiples of 4");
     const long long pixels = (long long)N * hw;
+    LbcProfScope prof("concat_velocity", 0.0, 4.0 * (double)pixels * (Ct + Ct + Cv), s);
     hipLaunchKernelGGL(concat_velocity_k, dim3((unsigned)grid_for(pixels * ((Ct + Cv) / 4))), dim3(256), 0, s, t, vel, h,
                        pixels, hw, Ct, Cv);
     return lbc_check_launch("concat_velocity");

@@ -317,6 +317,17 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     LBC_REQUIRE(a.M > 0, "igemm: empty launch");
     LBC_REQUIRE((long long)a.N * a.H * a.W * a.C < (1ll << 31) && (long long)a.N * a.OH * a.OW * a.K < (1ll << 31),
                 "igemm: tensor exceeds 2^31 elements");
+    // algorithmic work: 2*M*K*C per valid tap; bytes: gathered tensor + output once, weights once
+    int taps = 0;
+    for (int t = 0; t < a.KH * a.KW; ++t) {
+        const int r = t / a.KW, q = t - r * a.KW;
+        if (mode == 1 && a.S == 2 && ((((a.oy0 + a.P - r) & 1) != 0) || (((a.ox0 + a.P - q) & 1) != 0))) continue;
+        ++taps;
+    }
+    const double in_frac = (mode == 1 && a.S == 2) ? 1.0 : 1.0;
+    LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * a.K * (double)a.C * taps,
+                      4.0 * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) + (double)a.M * a.K * (a.resid ? 2 : 1) +
+                             (double)taps * a.C * a.K), s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);
         case 1: return launch_cfg<128, 128>(a, wmajor, mode, s);

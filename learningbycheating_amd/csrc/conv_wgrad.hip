@@ -217,6 +217,8 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     LBC_REQUIRE(M > 0 && M * a.CP < (1ll << 31) && (long long)a.N * a.H * a.W * a.CQ < (1ll << 31), "wgrad: bad tensor size");
     const long long chunks = (M + BR - 1) / BR;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * BR;
+    LbcProfScope prof("conv_wgrad", 2.0 * M * a.CP * (double)a.CQ * a.KH * a.KW,
+                      4.0 * ((double)M * a.CP + (double)a.N * a.H * a.W * a.CQ + (double)a.nsplit * a.CP * a.KH * a.KW * a.CQ), s);
     if (big_tile(a)) {
         dim3 grid((unsigned)a.nsplit, (unsigned)((a.CP / 128) * (a.CQ / 128)), (unsigned)(a.KH * a.KW));
         hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
@@ -234,6 +236,7 @@ int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* 
     long long blocks = (c4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     if (blocks < 1) blocks = 1;
+    LbcProfScope prof("splitk_reduce", 0.0, 4.0 * (double)count * (nsplit + 1), s);
     hipLaunchKernelGGL(splitk_reduce_f32, dim3((unsigned)blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta);
     return lbc_check_launch("splitk_reduce_f32");
 }

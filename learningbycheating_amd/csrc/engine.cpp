@@ -652,12 +652,13 @@ int lbc_loss(int kind, const lbc_camera* cam, const float* pred, const float* ta
         LBC_REQUIRE(cam, "loss: bird-view L1 needs crop_size");
         return lbc_loss_l1(a, 1.f / (0.5f * cam->crop_size), -1.f, (hipStream_t)stream);
     }
+    if (kind == 3) return lbc_loss_l1(a, 1.f, 0.f, (hipStream_t)stream);   // targets already normalised
     lbc_set_error("loss: unknown kind %d", kind);
     return LBC_EINVAL;
 }
 
-int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, lbc_stream_t stream)
+int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, double lr, double beta1, double beta2,
+                  double eps, double weight_decay, int step, lbc_stream_t stream)
 {
     static_assert(sizeof(lbc_adam_chunk) == sizeof(AdamChunk), "chunk layout");
     return lbc_adam_launch(reinterpret_cast<const AdamChunk*>(chunks_dev), nchunks, lr, beta1, beta2, eps, weight_decay,

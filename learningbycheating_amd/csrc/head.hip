@@ -369,6 +369,7 @@ __global__ __launch_bounds__(256) void head_bwd_apply_k(HeadBwdArgs a)
 int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
+    LbcProfScope prof("head_fwd", 2.0 * a.N * a.OH * a.OW * 64.0 * 20, 4.0 * a.N * (double)a.OH * a.OW * 64, s);
     hipLaunchKernelGGL(head_fwd_k, dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
     int rc = lbc_check_launch("head_fwd");
     if (rc) return rc;
@@ -386,6 +387,7 @@ int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.f.mean[0] == a.f.mean[1] && a.f.mean[0] == a.f.mean[2] && a.f.mean[0] == a.f.mean[3],
                 "head backward requires training-mode (shared batch) statistics");
+    LbcProfScope prof("head_bwd_reduce", 4.0 * a.f.N * a.f.OH * a.f.OW * 64.0 * 20, 4.0 * a.f.N * (double)a.f.OH * a.f.OW * 64, s);
     hipLaunchKernelGGL(head_bwd_reduce_k, dim3((unsigned)a.f.N, 4), dim3(256), 0, s, a);
     return lbc_check_launch("head_bwd_reduce");
 }
@@ -399,6 +401,7 @@ int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s)
 int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s)
 {
     const int HW = a.f.OH * a.f.OW;
+    LbcProfScope prof("head_bwd_apply", 4.0 * a.f.N * (double)HW * 64.0 * 20, 8.0 * a.f.N * (double)HW * 64, s);
     hipLaunchKernelGGL(head_bwd_apply_k, dim3((unsigned)a.f.N, (unsigned)lbc_cdiv(HW, TP)), dim3(256), 0, s, a);
     return lbc_check_launch("head_bwd_apply");
 }

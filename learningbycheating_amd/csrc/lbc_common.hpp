@@ -28,6 +28,20 @@ int lbc_check_launch(const char* what);
 
 static inline int lbc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Built-in launch profiler (lbc_util.cpp): when enabled through lbc_profile_enable(1) every launcher
+// brackets its kernel with two HIP events on the launch stream and books the kernel's ALGORITHMIC
+// flops / HBM bytes under a class name; lbc_profile_report() sums them.  Disabled = zero overhead.
+bool lbc_prof_on();
+void lbc_prof_begin(const char* name, double flops, double bytes, hipStream_t s);
+void lbc_prof_end(hipStream_t s);
+struct LbcProfScope {
+    hipStream_t s; bool on;
+    LbcProfScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), on(lbc_prof_on()) {
+        if (on) lbc_prof_begin(name, flops, bytes, s);
+    }
+    ~LbcProfScope() { if (on) lbc_prof_end(s); }
+};
+
 // ---------------------------------------------------------------------------
 // Implicit-GEMM convolution (conv_igemm.hip).
 //   rows    m = (n, ly, lx) over a lattice of output pixels

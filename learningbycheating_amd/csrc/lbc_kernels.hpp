@@ -168,5 +168,5 @@ int lbc_loss_l1(const LossArgs& a, float target_scale, float target_shift, hipSt
 
 // ---- Adam (multi-tensor) ------------------------------------------------------------------
 struct AdamChunk { float* p; const float* g; float* m; float* v; int n; int pad; };
-int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, float lr, float beta1, float beta2, float eps,
-                  float weight_decay, int step, hipStream_t s);
+int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, double lr, double beta1, double beta2, double eps,
+                    double weight_decay, int step, hipStream_t s);

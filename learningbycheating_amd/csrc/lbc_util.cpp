@@ -25,3 +25,54 @@ int lbc_check_launch(const char* what)
 }
 
 extern "C" const char* lbc_last_error(void) { return g_err; }
+
+// ---- launch profiler -----------------------------------------------------------------
+#include <map>
+#include <string>
+#include <vector>
+namespace {
+struct ProfRec { const char* name; double flops, bytes; hipEvent_t e0, e1; };
+bool g_prof = false;
+std::vector<ProfRec> g_recs;
+}  // namespace
+bool lbc_prof_on() { return g_prof; }
+void lbc_prof_begin(const char* name, double flops, double bytes, hipStream_t s)
+{
+    ProfRec r;
+    r.name = name; r.flops = flops; r.bytes = bytes;
+    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
+    hipEventRecord(r.e0, s);
+    g_recs.push_back(r);
+}
+void lbc_prof_end(hipStream_t s) { if (!g_recs.empty()) hipEventRecord(g_recs.back().e1, s); }
+
+extern "C" int lbc_profile_enable(int on)
+{
+    g_prof = on != 0;
+    return 0;
+}
+// Writes one line per kernel class: "name count total_ms total_flops total_bytes\n"; returns bytes written.
+extern "C" int lbc_profile_report(char* buf, int cap)
+{
+    struct Agg { long long n = 0; double ms = 0, flops = 0, bytes = 0; };
+    std::map<std::string, Agg> agg;
+    std::vector<std::string> order;
+    for (ProfRec& r : g_recs) {
+        hipEventSynchronize(r.e1);
+        float ms = 0.f;
+        hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (!agg.count(r.name)) order.push_back(r.name);
+        Agg& a = agg[r.name];
+        a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+    }
+    g_recs.clear();
+    int off = 0;
+    for (const std::string& k : order) {
+        const Agg& a = agg[k];
+        int w = snprintf(buf + off, cap > off ? (size_t)(cap - off) : 0, "%s %lld %.6f %.6e %.6e\n", k.c_str(), a.n, a.ms, a.flops, a.bytes);
+        if (w < 0 || off + w >= cap) break;
+        off += w;
+    }
+    return off;
+}

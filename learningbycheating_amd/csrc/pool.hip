@@ -133,6 +133,7 @@ int lbc_bn_relu_maxpool_fwd(const PoolFwdArgs& a, hipStream_t s)
     const long long total = (long long)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
+    LbcProfScope prof("bn_relu_maxpool_fwd", 0.0, 4.0 * total * 4 * (4.0 + 1.0 + 0.25), s);
     hipLaunchKernelGGL(bn_relu_maxpool_fwd_k, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return lbc_check_launch("bn_relu_maxpool_fwd");
 }
@@ -145,6 +146,7 @@ int lbc_maxpool_relu_bwd_reduce(PoolBwdArgs a, hipStream_t s)
     const long long pixels = (long long)a.N * a.H * a.W;
     const int rows = lbc_pool_bwd_rows(a.N, a.H, a.W, a.C);
     a.pix_per_block = (pixels + rows - 1) / rows;
+    LbcProfScope prof("maxpool_relu_bwd_reduce", 0.0, 4.0 * (double)pixels * a.C * (2.0 + 0.25 + 0.0625), s);
     hipLaunchKernelGGL(maxpool_relu_bwd_reduce_k, dim3((unsigned)rows), dim3(256), 0, s, a);
     return lbc_check_launch("maxpool_relu_bwd_reduce");
 }

@@ -219,6 +219,7 @@ int lbc_prep_input(const float* img_nchw, float* xp, int N, int C, int H, int W,
     const long long total = (long long)N * H * W;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
+    LbcProfScope prof("prep_input", 0.0, 4.0 * (2.0 * total * C + (double)N * (H + 6) * (W + 6) * C), s);
     hipLaunchKernelGGL(prep_input_k, dim3((unsigned)blocks), dim3(256), 0, s, img_nchw, xp, N, C, H, W, nc);
     return lbc_check_launch("prep_input");
 }
@@ -231,6 +232,8 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
     LBC_REQUIRE(a.H % 2 == 0 && a.W % 2 == 0, "stem: odd image size");
     LBC_REQUIRE((long long)a.N * (a.H + 6) * (a.W + 6) * a.Cin < (1ll << 31), "stem: input too large");
     const dim3 grid((unsigned)lbc_stem_rows(a));
+    const double Ms = (double)a.N * (a.H / 2) * (a.W / 2);
+    LbcProfScope prof("stem_fwd", 2.0 * Ms * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + Ms * 64), s);
     if (a.Cin == 3) hipLaunchKernelGGL((stem_fwd_k<3>), grid, dim3(256), 0, s, a);
     else            hipLaunchKernelGGL((stem_fwd_k<7>), grid, dim3(256), 0, s, a);
     return lbc_check_launch("stem_fwd");
@@ -252,6 +255,7 @@ int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s)
     const long long chunks = (M + 31) / 32;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 32;
     const dim3 grid((unsigned)a.nsplit, 7);
+    LbcProfScope prof("stem_wgrad", 2.0 * M * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (double)M * 64), s);
     if (a.Cin == 3) hipLaunchKernelGGL((stem_wgrad_k<3>), grid, dim3(256), 0, s, a, rows_per_split);
     else            hipLaunchKernelGGL((stem_wgrad_k<7>), grid, dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("stem_wgrad");

@@ -1,0 +1,66 @@
+"""Data parallelism for the LbC training step: one process per GPU, gradients all-reduced
+(sum; the loss is pre-scaled by 1/world_size) over RCCL/xGMI in per-stage buckets that are
+launched while the remaining backward stages still execute.  The reference has no
+distributed code at all (single `cuda` device, training/train_image_phase1.py:297).
+
+Buckets are contiguous ranges of the executor's flat gradient buffer, one per backward stage
+(head+decoder | layer4 | layer3 | layer2 | layer1 | stem), so no packing copies are needed.
+"""
+import torch
+import torch.distributed as dist
+
+STAGE_PREFIXES = [("deconv.", "location_pred."), ("conv.layer4.",), ("conv.layer3.",), ("conv.layer2.",), ("conv.layer1.",),
+                  ("conv.conv1.", "conv.bn1.")]
+
+
+def stage_ranges(grad_offsets):
+    """[(start, end)] element ranges of the flat gradient buffer, one per backward stage."""
+    out = []
+    for prefixes in STAGE_PREFIXES:
+        spans = [grad_offsets[n] for n in grad_offsets if n.startswith(prefixes)]
+        lo = min(o for o, _ in spans)
+        hi = max(o + c for o, c in spans)
+        assert sum(c for _, c in spans) == hi - lo, "stage parameters must be contiguous in the flat gradient buffer"
+        out.append((lo, hi))
+    return out
+
+
+class StageAllReducer:
+    def __init__(self, grad_flat, grad_offsets, group=None):
+        self.flat = grad_flat
+        self.ranges = stage_ranges(grad_offsets)
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.cuda = grad_flat.is_cuda
+        self.comm = torch.cuda.Stream(device=grad_flat.device) if self.cuda and self.world > 1 else None
+        self.pending = []
+
+    def launch(self, stage):
+        """call right after enqueueing backward stage `stage` on the current stream"""
+        if self.world == 1:
+            return
+        lo, hi = self.ranges[stage]
+        bucket = self.flat[lo:hi]
+        if self.comm is not None:
+            ev = torch.cuda.Event()
+            ev.record()
+            with torch.cuda.stream(self.comm):
+                self.comm.wait_event(ev)
+                self.pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        else:
+            self.pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def wait(self):
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
+
+def broadcast_module(module, src=0, group=None):
+    """identical initial weights/buffers on every rank"""
+    if not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return
+    for t in list(module.parameters()) + list(module.buffers()):
+        dist.broadcast(t.data, src, group=group)

@@ -1,0 +1,75 @@
+"""The LbC training step on the native executor, without autograd bookkeeping:
+    teacher forward (eval) -> student forward (train) -> loss kernel -> staged backward
+    (+ bucketed RCCL all-reduce) -> fused Adam
+= reference training/train_image_phase1.py:174-205 (phase 1), train_image_phase0.py:163-189
+(phase 0) and train_birdview.py:116-128 (bird-view behaviour cloning)."""
+import ctypes
+
+import torch
+
+from .. import _lib
+from ..engine import PolicyEngine
+from ..optim import FusedAdam
+from ..parallel import StageAllReducer
+
+CAMERA = dict(w=384.0, h=160.0, fov=90.0, world_y=1.4, fixed_offset=4.0, pixels_per_meter=5.0, crop_size=192.0)
+
+
+def camera_struct(**kw):
+    c = dict(CAMERA)
+    c.update(kw)
+    return _lib.Camera(c["w"], c["h"], c["fov"], c["world_y"], c["fixed_offset"], c["pixels_per_meter"], c["crop_size"])
+
+
+class NativeTrainer:
+    """phase: 1 (student vs teacher, all branches, map space), 0 (student vs teacher, selected branch,
+    image space), 'birdview' (privileged agent vs ground-truth waypoints), 'l1_all' (all branches vs
+    given normalised targets; used to warm-start synthetic benchmarks below the horizon)."""
+
+    def __init__(self, student, teacher, batch, image_shape, device, phase=1, lr=1e-4, world_size=1, group=None, camera=None):
+        self.student, self.teacher, self.phase, self.batch, self.world = student, teacher, phase, batch, world_size
+        self.device = device
+        student.train()
+        self.eng = student.engine((batch,) + tuple(image_shape), device, max_batch=batch, with_grads=True)
+        self.teng = None
+        if teacher is not None:
+            teacher.eval()
+            self.teng = teacher.engine((batch, 7, 192, 192), device, max_batch=batch, with_grads=False)
+        self.cam = camera or camera_struct()
+        self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
+        self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_offsets, group)
+        self.loss = torch.zeros(batch, dtype=torch.float32, device=device)
+        self.dpred_all = torch.zeros((batch, 4, 5, 2), dtype=torch.float32, device=device)
+        self.dpred_sel = torch.zeros((batch, 5, 2), dtype=torch.float32, device=device)
+        self.nstages = PolicyEngine.num_stages()
+
+    def _loss(self, kind, pred, target, rows, dpred):
+        n = pred.shape[0]
+        _lib.check(_lib.get().lbc_loss(kind, ctypes.byref(self.cam), _lib.ptr(pred), _lib.ptr(target), n, rows,
+                                       1.0 / (n * self.world), _lib.ptr(self.loss), _lib.ptr(dpred), _lib.stream_for(pred)), "loss")
+
+    def step(self, x, speed, command, birdview=None, target=None, update=True):
+        """x: student input (N,C,H,W) fp32; command one-hot (N,4); returns per-sample loss (device tensor)."""
+        n = x.shape[0]
+        if self.phase in (0, 1):
+            t_sel, t_all = self.teng.forward(birdview, speed, command, False)
+        p_sel, p_all = self.eng.forward(x, speed, command, True)
+        d_sel = d_all = None
+        if self.phase == 1:
+            self._loss(1, p_all, t_all, 20, self.dpred_all); d_all = self.dpred_all[:n]
+        elif self.phase == 0:
+            self._loss(0, p_sel, t_sel, 5, self.dpred_sel); d_sel = self.dpred_sel[:n]
+        elif self.phase == "birdview":
+            self._loss(2, p_sel, target, 5, self.dpred_sel); d_sel = self.dpred_sel[:n]
+        elif self.phase == "l1_all":
+            self._loss(3, p_all, target, 20, self.dpred_all); d_all = self.dpred_all[:n]
+        else:
+            raise ValueError(self.phase)
+        if update:
+            for st in range(self.nstages):
+                self.eng.backward(d_sel, d_all, st)
+                self.reducer.launch(st)
+            self.reducer.wait()
+            self.opt.step()
+        self.last_pred = (p_sel, p_all)
+        return self.loss[:n]

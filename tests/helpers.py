@@ -1,0 +1,123 @@
+import ctypes
+
+import torch
+import torch.nn.functional as F
+
+from learningbycheating_amd import _lib
+
+
+def nhwc(t):
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(t):
+    return t.permute(0, 3, 1, 2).contiguous()
+
+
+def guarded(shape, device, fill=float("nan")):
+    """tensor placed in the middle of a NaN-filled buffer: out-of-range writes/reads show up"""
+    n = 1
+    for s in shape:
+        n *= s
+    pad = 256
+    buf = torch.full((n + 2 * pad,), fill, dtype=torch.float32, device=device)
+    return buf, buf[pad:pad + n].view(shape)
+
+
+def check_guard(buf, n):
+    pad = 256
+    assert torch.isnan(buf[:pad]).all() and torch.isnan(buf[pad + n:]).all(), "kernel wrote outside its output"
+
+
+class Conv:
+    def __init__(self, device):
+        self.dev = device
+        self.lib = _lib.get()
+
+    def desc(self, N, H, W, C, K, k, s, p, relu=0):
+        return _lib.ConvDesc(N, H, W, C, K, k, k, s, p, relu)
+
+    def fwd(self, x, w, stride, pad, bias=None, resid=None, pre=None, relu=0, stats=False):
+        N, C, H, W = x.shape
+        K, _, k, _ = w.shape
+        d = self.desc(N, H, W, C, K, k, stride, pad, relu)
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        xh, wh = nhwc(x).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        buf, y = guarded((N, OH, OW, K), self.dev)
+        rows = ctypes.c_int(0)
+        _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
+        st = torch.zeros((rows.value, 2, K), device=self.dev) if stats else None
+        keep = [t.to(self.dev) if t is not None else None for t in (bias, nhwc(resid) if resid is not None else None,
+                                                                      pre[0] if pre else None, pre[1] if pre else None)]
+        _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(wh), _lib.ptr(keep[0]), _lib.ptr(keep[1]),
+                                           _lib.ptr(keep[2]), _lib.ptr(keep[3]), 1 if (pre and pre[2]) else 0, _lib.ptr(y),
+                                           _lib.ptr(st), ctypes.byref(rows), _lib.stream_for(xh)))
+        check_guard(buf, y.numel())
+        return nchw(y).cpu(), (st.cpu() if stats else None)
+
+    def dgrad(self, dy, w, H, W, stride, pad, resid=None):
+        N, K = dy.shape[:2]
+        _, C, k, _ = w.shape
+        d = self.desc(N, H, W, C, K, k, stride, pad)
+        dyh, wh = nhwc(dy).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        r = nhwc(resid).to(self.dev) if resid is not None else None
+        buf, dx = guarded((N, H, W, C), self.dev)
+        _lib.check(self.lib.lbc_conv2d_dgrad(ctypes.byref(d), _lib.ptr(dyh), _lib.ptr(wh), _lib.ptr(r), _lib.ptr(dx), _lib.stream_for(dyh)))
+        check_guard(buf, dx.numel())
+        return nchw(dx).cpu()
+
+    def wgrad(self, x, dy, k, stride, pad, pre=None, beta=0.0, dw0=None):
+        N, C, H, W = x.shape
+        K = dy.shape[1]
+        d = self.desc(N, H, W, C, K, k, stride, pad)
+        ws = torch.empty(self.lib.lbc_conv2d_wgrad_workspace(ctypes.byref(d)) // 4 + 1, device=self.dev)
+        xh, dyh = nhwc(x).to(self.dev), nhwc(dy).to(self.dev)
+        buf, dw = guarded((K, k, k, C), self.dev)
+        if dw0 is not None:
+            dw.copy_(dw0.permute(0, 2, 3, 1))
+        keep = [pre[0].to(self.dev), pre[1].to(self.dev)] if pre else [None, None]
+        _lib.check(self.lib.lbc_conv2d_wgrad(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(dyh), _lib.ptr(keep[0]), _lib.ptr(keep[1]),
+                                             1 if (pre and pre[2]) else 0, _lib.ptr(dw), beta, _lib.ptr(ws), _lib.stream_for(xh)))
+        check_guard(buf, dw.numel())
+        return dw.permute(0, 3, 1, 2).contiguous().cpu()
+
+    def deconv_all(self, x, w, bias, pre, relu):
+        """fwd, dgrad and wgrad of ConvTranspose2d(k3,s2,p1,op1) with BN-on-load; returns (y, stats, fn(dy)->(dx, dw))"""
+        N, C, H, W = x.shape
+        K = w.shape[1]
+        d = self.desc(N, H, W, C, K, 3, 2, 1, relu)
+        xh, wh = nhwc(x).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        ps, pt, b = pre[0].to(self.dev), pre[1].to(self.dev), bias.to(self.dev)
+        rows = ctypes.c_int(0)
+        _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(d), None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
+        st = torch.zeros((rows.value, 2, K), device=self.dev)
+        buf, y = guarded((N, 2 * H, 2 * W, K), self.dev)
+        _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(wh), _lib.ptr(b), _lib.ptr(ps), _lib.ptr(pt), 0,
+                                                _lib.ptr(y), _lib.ptr(st), ctypes.byref(rows), _lib.stream_for(xh)))
+        check_guard(buf, y.numel())
+
+        def bwd(dy):
+            dyh = nhwc(dy).to(self.dev)
+            bufx, dx = guarded((N, H, W, C), self.dev)
+            _lib.check(self.lib.lbc_deconv3x3s2_dgrad(ctypes.byref(d), _lib.ptr(dyh), _lib.ptr(wh), _lib.ptr(dx), _lib.stream_for(dyh)))
+            check_guard(bufx, dx.numel())
+            ws = torch.empty(self.lib.lbc_deconv3x3s2_wgrad_workspace(ctypes.byref(d)) // 4 + 1, device=self.dev)
+            bufw, dw = guarded((C, 3, 3, K), self.dev)
+            _lib.check(self.lib.lbc_deconv3x3s2_wgrad(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(dyh), _lib.ptr(ps), _lib.ptr(pt), 0,
+                                                      _lib.ptr(dw), 0.0, _lib.ptr(ws), _lib.stream_for(xh)))
+            check_guard(bufw, dw.numel())
+            return nchw(dx).cpu(), dw.permute(0, 3, 1, 2).contiguous().cpu()
+        return nchw(y).cpu(), st.cpu(), bwd
+
+
+def relerr(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
+
+
+def engine_from_state_dict(sd, kind, backbone, H, W, max_batch, device):
+    from learningbycheating_amd.engine import PolicyEngine
+    eng = PolicyEngine(34 if backbone == "resnet34" else 18, 3 if kind == "image" else 7, H, W, kind == "image", max_batch, device)
+    tens = {k: (v.to(device).contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v.clone().to(device))
+            for k, v in sd.items() if k in set(eng.names)}
+    eng.bind(tens, True)
+    return eng, tens

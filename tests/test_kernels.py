@@ -1,0 +1,140 @@
+"""Per-kernel parity of the convolution family against torch CPU (conv2d / conv_transpose2d + autograd).
+Small shapes run the kernel sources under the CPU emulator (tests/emu); the gpu-marked cases run the
+real gfx950 library at the layer shapes of SURVEY.md appendix B.1 through the C ABI."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+from tests.helpers import Conv, relerr
+
+gpu = pytest.mark.gpu
+# (N, H, W, Cin, Cout, k, stride, pad)
+SMALL = [(1, 8, 8, 64, 64, 3, 1, 1), (2, 5, 12, 64, 128, 3, 1, 1), (1, 10, 12, 64, 128, 3, 2, 1), (1, 8, 12, 64, 128, 1, 2, 0),
+         (3, 6, 7, 64, 64, 3, 1, 1)]
+REAL = [pytest.param(c, marks=gpu) for c in [
+    (2, 40, 96, 64, 64, 3, 1, 1), (32, 40, 96, 64, 64, 3, 1, 1),        # layer1
+    (2, 40, 96, 64, 128, 3, 2, 1), (2, 40, 96, 64, 128, 1, 2, 0),        # layer2.0 conv1 / downsample
+    (8, 20, 48, 128, 128, 3, 1, 1),                                      # layer2
+    (2, 20, 48, 128, 256, 3, 2, 1), (8, 10, 24, 256, 256, 3, 1, 1),      # layer3
+    (2, 10, 24, 256, 512, 3, 2, 1), (32, 5, 12, 512, 512, 3, 1, 1), (2, 10, 24, 256, 512, 1, 2, 0),   # layer4
+    (3, 6, 6, 512, 512, 3, 1, 1)]]                                       # bird-view layer4 (6x6)
+
+
+def make(cfg, seed=0):
+    N, H, W, C, K, k, s, p = cfg
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = torch.randn((K, C, k, k), generator=g) * (2.0 / (C * k * k)) ** 0.5
+    return x, w
+
+
+@pytest.mark.parametrize("cfg", SMALL + [(2, 5, 5, 32, 64, 3, 1, 1)] + REAL)
+def test_conv_fwd(env, cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg)
+    ref = F.conv2d(x, w, None, s, p)
+    y, st = Conv(dev).fwd(x, w, s, p, stats=True)
+    assert relerr(y, ref) < 1e-5
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-3 * ref.abs().sum((0, 2, 3)).max().item() / 1e2)
+    assert torch.allclose(st[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), rtol=1e-4)
+
+
+@pytest.mark.parametrize("cfg", [SMALL[1], SMALL[2]] + [pytest.param((4, 20, 48, 128, 128, 3, 1, 1), marks=gpu)])
+def test_conv_fwd_fused_prologue_epilogue(env, cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg, 1)
+    g = torch.Generator().manual_seed(2)
+    ps, pt, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(K, generator=g)
+    xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    ref = F.conv2d(xin, w, b, s, p)
+    r = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + r)
+    y, st = Conv(dev).fwd(x, w, s, p, bias=b, resid=r, pre=(ps, pt, True), relu=1, stats=True)
+    assert relerr(y, ref) < 1e-5
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+
+
+@pytest.mark.parametrize("cfg", SMALL + REAL)
+def test_conv_dgrad(env, cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    if k == 1 and s == 2:
+        pytest.skip("1x1/2 dgrad is exercised with accumulation in test_conv_dgrad_residual")
+    x, w = make(cfg, 3)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(4))
+    y.backward(dy)
+    dx = Conv(dev).dgrad(dy, w, H, W, s, p)
+    assert relerr(dx, x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [SMALL[1], SMALL[3]] + [pytest.param((2, 40, 96, 64, 128, 1, 2, 0), marks=gpu)])
+def test_conv_dgrad_residual(env, cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg, 5)
+    x.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(6))
+    y.backward(dy)
+    r = torch.randn(x.shape, generator=torch.Generator().manual_seed(7))
+    dx = Conv(dev).dgrad(dy, w, H, W, s, p, resid=r)
+    assert relerr(dx, x.grad + r) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", SMALL + [(40, 5, 6, 64, 64, 3, 1, 1)] + REAL)
+def test_conv_wgrad(env, cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg, 8)
+    w.requires_grad_(True)
+    y = F.conv2d(x, w, None, s, p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(9))
+    y.backward(dy)
+    dw = Conv(dev).wgrad(x, dy, k, s, p)
+    assert relerr(dw, w.grad) < 2e-5
+
+
+def test_conv_wgrad_fused_bn_on_load_and_accumulate(env):
+    dev, _ = env
+    cfg = (3, 9, 11, 64, 128, 3, 1, 1)
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg, 10)
+    g = torch.Generator().manual_seed(11)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    w.requires_grad_(True)
+    y = F.conv2d(F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)), w, None, s, p)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    dw0 = torch.randn(w.shape, generator=g)
+    dw = Conv(dev).wgrad(x, dy, k, s, p, pre=(ps, pt, True), beta=1.0, dw0=dw0)
+    assert relerr(dw, w.grad + dw0) < 2e-5
+
+
+DEC_SMALL = [(2, 3, 4, 64, 64), (1, 5, 12, 128, 64)]
+DEC_REAL = [pytest.param(c, marks=gpu) for c in [(4, 5, 12, 640, 256), (4, 10, 24, 256, 128), (2, 20, 48, 128, 64), (2, 6, 6, 640, 256)]]
+
+
+@pytest.mark.parametrize("cfg", DEC_SMALL + DEC_REAL)
+def test_deconv_fwd_dgrad_wgrad(env, cfg):
+    """ConvTranspose2d(k3,s2,p1,op1) with the preceding BatchNorm applied on load, bias + ReLU + statistics fused"""
+    dev, _ = env
+    N, H, W, C, K = cfg
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = (torch.randn((C, K, 3, 3), generator=g) * (2.0 / (C * 2.25)) ** 0.5).requires_grad_(True)
+    b = torch.randn(K, generator=g)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xn = (x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)).requires_grad_(True)
+    u = F.conv_transpose2d(xn, w, b, 2, 1, 1)
+    ref = F.relu(u)
+    y, st, bwd = Conv(dev).deconv_all(x, w.detach(), b, (ps, pt), relu=1)
+    assert relerr(y, ref) < 1e-5
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    dy = torch.randn(u.shape, generator=g)
+    u.backward(dy)
+    dx, dw = bwd(dy)
+    assert relerr(dx, xn.grad) < 1e-5 and relerr(dw, w.grad) < 2e-5

@@ -1,0 +1,143 @@
+"""Data-parallel plumbing on CPU with gloo, world_size 2: stage buckets of the flat gradient buffer are contiguous,
+cover every parameter with a gradient, and the staged all-reduce equals the sum over ranks.  A second test runs the
+emulated executor on two ranks (local BatchNorm, loss scaled 1/world) against the single-process mean of the
+per-shard gradients."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _offsets_for_image_model():
+    from learningbycheating_amd.bird_view.models import ImagePolicyModelSS
+    net = ImagePolicyModelSS("resnet34")
+    off, out = 0, {}
+    for n, p in net.named_parameters():
+        if n.startswith("conv.fc"):
+            continue
+        out[n] = (off, p.numel())
+        off += p.numel()
+    return out, off
+
+
+def test_stage_ranges_partition_the_gradient_buffer():
+    from learningbycheating_amd.parallel import stage_ranges
+    offs, total = _offsets_for_image_model()
+    assert total == 23132180          # parameters with a gradient
+    r = stage_ranges(offs)
+    assert len(r) == 6
+    assert sorted(r) == sorted(r, key=lambda t: t[0])
+    flat = sorted(r)
+    assert flat[0][0] == 0 and flat[-1][1] == total
+    for (a, b), (c, d) in zip(flat[:-1], flat[1:]):
+        assert b == c
+    # backward order: head+decoder is the tail of the buffer, the stem its head
+    assert r[0][1] == total and r[5][0] == 0
+
+
+def _reduce_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from learningbycheating_amd.parallel import StageAllReducer
+    offs, total = _offsets_for_image_model()
+    g = torch.Generator().manual_seed(100 + rank)
+    flat = torch.randn(total, generator=g)
+    mine = flat.clone()
+    red = StageAllReducer(flat, offs)
+    for st in range(6):
+        red.launch(st)
+    red.wait()
+    q.put((rank, mine[::100003].clone(), flat[::100003].clone()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_staged_allreduce_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = res[0][1] + res[1][1]
+    assert torch.allclose(res[0][2], want) and torch.allclose(res[1][2], want)
+
+
+def _dp_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ctypes
+    from tests import emu
+    emu.activate()
+    from learningbycheating_amd import _lib
+    from learningbycheating_amd.parallel import StageAllReducer
+    from learningbycheating_amd.training.native import camera_struct
+    from oracle import lbc_oracle as O
+    from tests.helpers import engine_from_state_dict
+    h, w, n = 32, 64, 2
+    sd = O.make_state_dict("image", "resnet18", 41, h, w)
+    g = torch.Generator().manual_seed(50)
+    x = torch.rand((world * n, 3, h, w), generator=g)
+    speed = torch.rand(world * n, generator=g) * 10
+    cmd = O.one_hot(torch.randint(1, 5, (world * n,), generator=g).float())
+    tgt = torch.rand((world * n, 4, 5, 2), generator=g) * 2 - 1
+    cam = camera_struct()
+    lib = _lib.get()
+
+    def shard_grads(r, scale):
+        eng, _ = engine_from_state_dict(sd, "image", "resnet18", h, w, n, torch.device("cpu"))
+        sl = slice(r * n, (r + 1) * n)
+        _, pa = eng.forward(x[sl].contiguous(), speed[sl].contiguous(), cmd[sl].contiguous(), True)
+        loss = torch.zeros(n)
+        d = torch.zeros((n, 4, 5, 2))
+        t = tgt[sl].contiguous()
+        _lib.check(lib.lbc_loss(3, ctypes.byref(cam), _lib.ptr(pa), _lib.ptr(t), n, 20, scale, _lib.ptr(loss), _lib.ptr(d), None))
+        return eng, d
+
+    eng, d = shard_grads(rank, 1.0 / (n * world))
+    red = StageAllReducer(eng.grad_flat, eng.grad_offsets)
+    for st in range(6):
+        eng.backward(None, d, st)
+        red.launch(st)
+    red.wait()
+    got = eng.grad_flat.clone()
+    if rank == 0:
+        want = torch.zeros_like(got)
+        for r in range(world):
+            e2, d2 = shard_grads(r, 1.0 / (n * world))
+            e2.backward(None, d2)
+            want += e2.grad_flat
+        q.put((float((got - want).abs().max()), float(want.abs().max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_data_parallel_gradients_emulated_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    err, scale = q.get(timeout=600)
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert err <= 1e-6 * scale + 1e-12, (err, scale)
