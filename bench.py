@@ -52,7 +52,9 @@ def build_models(device, seed=0):
 def cpu_baseline(seconds_budget=25.0, batch=8):
     """oracle (port of the reference step onto torch-CPU functional ops) timed on the host cores"""
     from oracle import lbc_oracle as O
-    cores = os.cpu_count() or 1
+    # intra-op threads: all cores up to 64 (a 23 M-parameter CNN at batch 8 stops scaling, and slows down, far below
+    # the 256 hardware threads of the GPU host); `cores` reports the threads actually used
+    cores = min(os.cpu_count() or 1, 64)
     torch.set_num_threads(cores)
     ssd = O.as_params(O.make_state_dict("image", "resnet34", 1, trained_like=False))
     tsd = O.make_state_dict("birdview", "resnet18", 2)

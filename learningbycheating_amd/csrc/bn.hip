@@ -104,9 +104,14 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
     float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
     if (pl < rl) {
         float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), inv = make_float4(1.f, 1.f, 1.f, 1.f);
+        float4 msc = make_float4(1.f, 1.f, 1.f, 1.f), msh = make_float4(0.f, 0.f, 0.f, 0.f);
         if (OP == 1 && a.mean) {
             mean = *reinterpret_cast<const float4*>(a.mean + c);
             inv = *reinterpret_cast<const float4*>(a.invstd + c);
+        }
+        if (OP == 1 && a.mask_scale) {
+            msc = *reinterpret_cast<const float4*>(a.mask_scale + c);
+            msh = *reinterpret_cast<const float4*>(a.mask_shift + c);
         }
         const long long p0 = (long long)blockIdx.x * a.pix_per_block;
         long long p1 = p0 + a.pix_per_block;
@@ -120,7 +125,11 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
             } else {                  // backward: g = dz * (mask > 0); sum g, sum g * xhat
                 float4 g = reinterpret_cast<const float4*>(a.dz)[i];
                 if (a.mask) {
-                    const float4 m = reinterpret_cast<const float4*>(a.mask)[i];
+                    float4 m = reinterpret_cast<const float4*>(a.mask)[i];
+                    if (a.mask_scale) {
+                        m.x = m.x * msc.x + msh.x; m.y = m.y * msc.y + msh.y;
+                        m.z = m.z * msc.z + msh.z; m.w = m.w * msc.w + msh.w;
+                    }
                     g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
                     g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
                 }

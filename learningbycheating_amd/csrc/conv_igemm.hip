@@ -280,6 +280,25 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
     }
 }
 
+// w[A][T][B] -> wt[B][T][A] (per tap a 2-D transpose through a padded 32x32 LDS tile).  Used to hand the
+// input-gradient GEMM a depth-contiguous weight operand (the fast ds_read_b128 fragment path).
+__global__ __launch_bounds__(256) void weight_transpose_k(const float* __restrict__ w, float* __restrict__ wt, int A, int T, int B)
+{
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int a0 = blockIdx.y * 32, b0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    for (int j = ty; j < 32; j += 8) {
+        const int a = a0 + j, b = b0 + tx;
+        tile[j][tx] = (a < A && b < B) ? w[((size_t)a * T + t) * B + b] : 0.f;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int b = b0 + j, a = a0 + tx;
+        if (a < A && b < B) wt[((size_t)b * T + t) * A + a] = tile[tx][j];
+    }
+}
+
 template <int BM, int BN>
 int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
@@ -295,6 +314,13 @@ const int kCfgBM[3] = {128, 128, 64};
 const int kCfgBN[3] = {64, 128, 64};
 
 }  // namespace
+
+int lbc_weight_transpose(const float* w, float* wt, int A, int T, int B, hipStream_t s)
+{
+    LbcProfScope prof("weight_transpose", 0.0, 8.0 * A * T * B, s);
+    hipLaunchKernelGGL(weight_transpose_k, dim3((unsigned)lbc_cdiv(B, 32), (unsigned)lbc_cdiv(A, 32), (unsigned)T), dim3(256), 0, s, w, wt, A, T, B);
+    return lbc_check_launch("weight_transpose");
+}
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kCfgBM[cfg]); }
 

@@ -58,6 +58,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
 
     float4 rp[RP], rq[RQ];
 
+    // pixel coordinates of this thread's Q rows, advanced by BR per chunk (no integer divisions in the loop)
+    int qn[RQ], qy[RQ], qx[RQ];
+#pragma unroll
+    for (int j = 0; j < RQ; ++j) {
+        const int row = (tid + 256 * j) / (BQ / 4);
+        const int m = mbeg + row;
+        const int ohw = a.OH * a.OW;
+        qn[j] = m / ohw;
+        const int rem = m - qn[j] * ohw;
+        qy[j] = rem / a.OW;
+        qx[j] = rem - qy[j] * a.OW;
+    }
+
     auto load_chunk = [&](int ch) {
         const int mc = mbeg + ch * BR;
 #pragma unroll
@@ -86,16 +99,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
             const int m = mc + row;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < mend) {
-                const int ohw = a.OH * a.OW;
-                const int n = m / ohw;
-                const int rem = m - n * ohw;
-                const int oy = rem / a.OW;
-                const int ox = rem - oy * a.OW;
-                const int iy = oy * a.S + r - a.P;
-                const int ix = ox * a.S + s - a.P;
+                const int iy = qy[j] * a.S + r - a.P;
+                const int ix = qx[j] * a.S + s - a.P;
                 if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
                     const int c = q0 + sg * 4;
-                    v = *reinterpret_cast<const float4*>(a.q + (size_t)((n * a.H + iy) * a.W + ix) * (size_t)a.CQ + (size_t)c);
+                    v = *reinterpret_cast<const float4*>(a.q + (size_t)((qn[j] * a.H + iy) * a.W + ix) * (size_t)a.CQ + (size_t)c);
                     if (a.q_scale) {
                         const float4 ps = *reinterpret_cast<const float4*>(a.q_scale + c);
                         const float4 pt = *reinterpret_cast<const float4*>(a.q_shift + c);
@@ -109,6 +117,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
                 }
             }
             rq[j] = v;
+            qx[j] += BR;
+            while (qx[j] >= a.OW) { qx[j] -= a.OW; ++qy[j]; }
+            while (qy[j] >= a.OH) { qy[j] -= a.OH; ++qn[j]; }
         }
     };
     auto store_chunk = [&](int buf) {

@@ -4,6 +4,7 @@
 #include "engine.hpp"
 
 #include <algorithm>
+#include <stdlib.h>
 #include <string.h>
 
 namespace lbc {
@@ -69,6 +70,8 @@ Net::Net(const lbc_net_desc& d) : d_(d)
 {
     const size_t NB = (size_t)d.max_batch;
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
+    if (const char* e = getenv("LBC_NO_FUSE_Z1")) fuse_z1_ = !(e[0] == '1');
+    if (const char* e = getenv("LBC_NO_DGRAD_WT")) dgrad_wt_ = !(e[0] == '1');
 
     // ---- stem (resnet.py:102-106) ----
     stem_w_ = add_tensor("conv.conv1.weight", kParam, {64, Cin, 7, 7});
@@ -101,7 +104,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
                 b.ds = make_conv(pre + ".downsample.0.weight", inpl, planes, h, w, 1, stride, 0);
                 b.bd = make_bn(pre + ".downsample.1", planes);
             }
-            b.z1 = alloc(NB * oh * ow * planes);
+            b.z1 = fuse_z1_ ? 0 : alloc(NB * oh * ow * planes);
             b.out = alloc(NB * oh * ow * planes);
             blocks_.push_back(b);
             inpl = planes; h = oh; w = ow;
@@ -171,6 +174,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     wg = std::max(wg, (size_t)lbc_stem_wgrad_split((int)NB, H0, W0) * 64 * 49 * Cin);
     wg_partial_ = alloc(wg);
 
+    wt_ = alloc((size_t)512 * 512 * 9);
     gD_ = alloc(max_act); gE_ = alloc(max_act); gF_ = alloc(max_act); gG_ = alloc(max_act);
     g0_ = alloc(NB * (H0 / 2) * (W0 / 2) * 64);
 }
@@ -186,11 +190,12 @@ int Net::check_bound(bool need_grads) const
 }
 
 // ---------------------------------------------------------------------------------------
-int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s)
+int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre)
 {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = x; a.w = P(c.w); a.y = W(c.y);
+    if (pre) { a.pre_scale = W(pre->scale); a.pre_shift = W(pre->shift); a.pre_relu = 1; }
     a.N = N; a.H = c.H; a.W = c.W; a.C = c.Cin;
     a.OH = c.OH; a.OW = c.OW; a.K = c.Cout;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
@@ -263,11 +268,15 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
         LBC_TRY(conv_fwd(b.c1, x, N, tr, &rows, s));
         LBC_TRY(bn_finalize(b.b1, rows, pix, train, s));
         BnApplyArgs ap;
-        memset(&ap, 0, sizeof(ap));
-        ap.x = W(b.c1.y); ap.y = W(b.z1); ap.pixels = pix; ap.C = b.c1.Cout;
-        ap.scale = W(b.b1.scale); ap.shift = W(b.b1.shift); ap.relu = 1;
-        LBC_TRY(lbc_bn_apply(ap, s));
-        LBC_TRY(conv_fwd(b.c2, W(b.z1), N, tr, &rows, s));
+        if (fuse_z1_) {
+            LBC_TRY(conv_fwd(b.c2, W(b.c1.y), N, tr, &rows, s, &b.b1));
+        } else {
+            memset(&ap, 0, sizeof(ap));
+            ap.x = W(b.c1.y); ap.y = W(b.z1); ap.pixels = pix; ap.C = b.c1.Cout;
+            ap.scale = W(b.b1.scale); ap.shift = W(b.b1.shift); ap.relu = 1;
+            LBC_TRY(lbc_bn_apply(ap, s));
+            LBC_TRY(conv_fwd(b.c2, W(b.z1), N, tr, &rows, s));
+        }
         LBC_TRY(bn_finalize(b.b2, rows, pix, train, s));
         memset(&ap, 0, sizeof(ap));
         ap.x = W(b.c2.y); ap.y = W(b.out); ap.pixels = pix; ap.C = b.c2.Cout;
@@ -349,11 +358,12 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
 // ---------------------------------------------------------------------------------------
 // BatchNorm backward: reduce (sum g, sum g*xhat) -> dgamma/dbeta + coefficients -> dx
 int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
-                     float* dx, int Cout, hipStream_t s)
+                     float* dx, int Cout, hipStream_t s, const BN* mask_bn)
 {
     ChanReduceArgs r;
     memset(&r, 0, sizeof(r));
     r.x = x; r.dz = dz; r.mask = mask; r.g_out = g_out; r.mean = W(bn.mean); r.invstd = W(bn.invstd);
+    if (mask_bn) { r.mask_scale = W(mask_bn->scale); r.mask_shift = W(mask_bn->shift); }
     r.partial = W(partial_); r.pixels = pixels; r.C = bn.C;
     LBC_TRY(lbc_chan_reduce(r, 1, s));
     int rows = lbc_chan_reduce_rows(pixels, bn.C);
@@ -380,9 +390,15 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
 
 int Net::conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s)
 {
+    return conv_wgrad_pre(c, x, nullptr, dy, N, s);
+}
+
+int Net::conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s)
+{
     WgradArgs a;
     memset(&a, 0, sizeof(a));
     a.p = dy; a.q = x; a.partial = W(wg_partial_);
+    if (pre) { a.q_scale = W(pre->scale); a.q_shift = W(pre->shift); a.q_relu = 1; }
     a.N = N; a.OH = c.OH; a.OW = c.OW; a.CP = c.Cout;
     a.H = c.H; a.W = c.W; a.CQ = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
@@ -400,10 +416,17 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     a.N = N; a.H = c.OH; a.W = c.OW; a.C = c.Cout;
     a.OH = c.H; a.OW = c.W; a.K = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
+    int wmajor = 0;
+    if (dgrad_wt_ && c.k == 3) {
+        // w[Cout][T][Cin] -> wt[Cin][T][Cout]: output channel (Cin) major, gathered channel (Cout) contiguous
+        LBC_TRY(lbc_weight_transpose(P(c.w), W(wt_), c.Cout, c.k * c.k, c.Cin, s));
+        a.w = W(wt_);
+        wmajor = 1;
+    }
     if (c.s == 1) {
         a.LH = c.H; a.LW = c.W; a.ostep = 1;
         a.M = N * c.H * c.W;
-        return lbc_igemm_launch(a, 0, 1, lbc_igemm_pick(a.M, a.K), s);
+        return lbc_igemm_launch(a, wmajor, 1, lbc_igemm_pick(a.M, a.K), s);
     }
     a.LH = c.H / 2; a.LW = c.W / 2; a.ostep = 2;
     a.M = N * a.LH * a.LW;
@@ -411,7 +434,7 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     const int nph = c.k == 1 ? 1 : 4;
     for (int ph = 0; ph < nph; ++ph) {
         a.oy0 = ph >> 1; a.ox0 = ph & 1;
-        LBC_TRY(lbc_igemm_launch(a, 0, 1, cfg, s));
+        LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
     }
     return LBC_OK;
 }
@@ -425,9 +448,15 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
     const float* xin = (&b == &blocks_.front()) ? W(p0_) : W((&b - 1)->out);
     // out = relu(bn2(y2) + identity): mask by out, keep masked gradient in D for the identity path
     LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E, b.b2.C, s));        // E = dY2
-    LBC_TRY(conv_wgrad(b.c2, W(b.z1), E, N, s));
-    LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                                   // F = dZ1
-    LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E, b.b1.C, s));          // E = dY1
+    if (fuse_z1_) {
+        LBC_TRY(conv_wgrad_pre(b.c2, W(b.c1.y), &b.b1, E, N, s));
+        LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                               // F = dZ1
+        LBC_TRY(bn_backward(b.b1, F, W(b.c1.y), F, W(b.c1.y), pix, E, b.b1.C, s, &b.b1));   // E = dY1 (mask = bn1(y1) > 0)
+    } else {
+        LBC_TRY(conv_wgrad(b.c2, W(b.z1), E, N, s));
+        LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                               // F = dZ1
+        LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E, b.b1.C, s));      // E = dY1
+    }
     LBC_TRY(conv_wgrad(b.c1, xin, E, N, s));
     if (!b.has_ds) {
         LBC_TRY(conv_dgrad(b.c1, E, D, Gbuf, N, s));                                  // G = dgrad + identity gradient

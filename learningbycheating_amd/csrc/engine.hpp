@@ -80,10 +80,14 @@ private:
     float* P(int ti) const { return static_cast<float*>(t_[ti].ptr); }
     float* G(int ti) const { return t_[ti].grad; }
 
-    int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s);
+    int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre = nullptr);
+    int conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s);
+    bool dgrad_wt_ = true;   // input-gradient GEMMs read a per-step transposed copy of the weights (depth-contiguous)
+    size_t wt_ = 0;
+    bool fuse_z1_ = true;    // conv2 / wgrad2 / bn1-backward read y1 with bn1(+ReLU) applied on load; z1 is never written
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
-                    float* dx, int Cout, hipStream_t s);
+                    float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr);
     int conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s);
     int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s);
     int block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s);

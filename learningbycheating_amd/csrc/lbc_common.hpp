@@ -78,6 +78,7 @@ struct IgemmArgs {
 int lbc_igemm_rows(const IgemmArgs& a, int cfg);   // number of M tiles (= stats rows) of a launch
 int lbc_igemm_pick(long long M, int K);
 int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s);
+int lbc_weight_transpose(const float* w, float* wt, int A, int T, int B, hipStream_t s);   // w[A][T][B] -> wt[B][T][A]
 
 // Weight-gradient GEMM (conv_wgrad.hip):
 //   out[p][tap][q] = sum_m  P[m][p] * Q[gather(m, tap)][q]

@@ -39,6 +39,8 @@ struct ChanReduceArgs {
     const float* x;              // op0: tensor to take statistics of; op1: pre-BN activation (nullable)
     const float* dz;             // op1: upstream gradient
     const float* mask;           // op1: ReLU mask source (g = dz where mask > 0), nullable
+    const float* mask_scale;     // op1: optional per-channel affine applied to the mask source first
+    const float* mask_shift;     //      (mask = pre-BN activation, affine = that BN: relu(bn(y)) > 0)
     float* g_out;                // op1: optional store of the masked gradient (may alias dz)
     const float* mean;           // op1: nullable
     const float* invstd;

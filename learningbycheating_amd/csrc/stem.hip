@@ -42,9 +42,10 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
     constexpr int L8 = (L + 7) / 8 * 8;
     constexpr int LD = L8 + 4;
     constexpr int BM = 128, BN = 64, MT = 2;
-    __shared__ __attribute__((aligned(16))) float sA[BM * LD];
-    __shared__ __attribute__((aligned(16))) float sB[BN * LD];
-    __shared__ int sRow[BM];
+    constexpr int HALF = L8 / 2;          // floats per thread per row (12 or 28): 2 threads per pixel row
+    constexpr int NB = BN * L8 / 256;     // weight floats per thread per chunk (6 or 14)
+    __shared__ __attribute__((aligned(16))) float sA[2][BM * LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][BN * LD];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -54,18 +55,18 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
     const int M = a.N * OH * OW;
     const int m0 = blockIdx.x * BM;
 
-    if (tid < BM) {
-        const int m = m0 + tid;
-        int base = -1;
+    // this thread stages columns [half*HALF, half*HALF + HALF) of pixel row `arow` (8-byte aligned: every offset is even)
+    const int arow = tid >> 1, half = tid & 1;
+    long long abase = -1;
+    {
+        const int m = m0 + arow;
         if (m < M) {
             const int n = m / (OH * OW);
             const int rem = m - n * OH * OW;
             const int oy = rem / OW, ox = rem - oy * OW;
-            base = ((n * Hp + 2 * oy) * Wp + 2 * ox) * CIN;
+            abase = (long long)((n * Hp + 2 * oy) * Wp + 2 * ox) * CIN + half * HALF;
         }
-        sRow[tid] = base;
     }
-    __syncthreads();
 
     f32x16 acc[MT];
 #pragma unroll
@@ -73,34 +74,57 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
 
+    float2 ra[HALF / 2];
+    float rb[NB];
+    auto load_chunk = [&](int r) {
+#pragma unroll
+        for (int q = 0; q < HALF / 2; ++q) {
+            float2 v = make_float2(0.f, 0.f);
+            if (abase >= 0) v = *reinterpret_cast<const float2*>(a.xp + abase + (long long)(r * Wp * CIN + 2 * q));
+            const int j = half * HALF + 2 * q;     // columns >= L are padding: must be exact zeros
+            if (j >= L) v.x = 0.f;
+            if (j + 1 >= L) v.y = 0.f;
+            ra[q] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int idx = tid + 256 * q;
+            const int row = idx / L8, j = idx - row * L8;
+            rb[q] = j < L ? a.w[(size_t)row * (7 * L) + (size_t)(r * L + j)] : 0.f;
+        }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < HALF / 2; ++q)
+            *reinterpret_cast<float2*>(&sA[buf][arow * LD + half * HALF + 2 * q]) = ra[q];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) {
+            const int idx = tid + 256 * q;
+            const int row = idx / L8, j = idx - row * L8;
+            sB[buf][row * LD + j] = rb[q];
+        }
+    };
+
+    load_chunk(0);
+    store_chunk(0);
+    __syncthreads();
     for (int r = 0; r < 7; ++r) {
-        for (int idx = tid; idx < BM * L8; idx += 256) {
-            const int row = idx / L8, j = idx - row * L8;
-            const int base = sRow[row];
-            float v = 0.f;
-            if (j < L && base >= 0) v = a.xp[(size_t)base + (size_t)(r * Wp * CIN + j)];
-            sA[row * LD + j] = v;
-        }
-        for (int idx = tid; idx < BN * L8; idx += 256) {
-            const int row = idx / L8, j = idx - row * L8;
-            float v = 0.f;
-            if (j < L) v = a.w[(size_t)row * (7 * L) + (size_t)(r * L + j)];
-            sB[row * LD + j] = v;
-        }
-        __syncthreads();
+        const int buf = r & 1;
+        if (r + 1 < 7) load_chunk(r + 1);
 #pragma unroll
         for (int g = 0; g < L8 / 8; ++g) {
             f32x4 af[MT];
 #pragma unroll
             for (int i = 0; i < MT; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&sA[((wm * MT + i) * 32 + l31) * LD + g * 8 + kh * 4]);
-            const f32x4 bf = *reinterpret_cast<const f32x4*>(&sB[(wn * 32 + l31) * LD + g * 8 + kh * 4]);
+                af[i] = *reinterpret_cast<const f32x4*>(&sA[buf][((wm * MT + i) * 32 + l31) * LD + g * 8 + kh * 4]);
+            const f32x4 bf = *reinterpret_cast<const f32x4*>(&sB[buf][(wn * 32 + l31) * LD + g * 8 + kh * 4]);
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
                     acc[mi] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][i], bf[i], acc[mi], 0, 0, 0);
         }
+        if (r + 1 < 7) store_chunk(buf ^ 1);
         __syncthreads();
     }
 
@@ -119,7 +143,7 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
             }
         }
     if (a.stats) {
-        float* red = sA;   // [2 wm][2][64]
+        float* red = &sA[0][0];   // [2 wm][2][64]
         s1 += __shfl_xor(s1, 32);
         s2 += __shfl_xor(s2, 32);
         if (kh == 0) { red[(wm * 2 + 0) * BN + col] = s1; red[(wm * 2 + 1) * BN + col] = s2; }
@@ -138,17 +162,19 @@ __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_pe
 {
     constexpr int L = 7 * CIN;
     constexpr int LQ = (L + 31) / 32 * 32;   // 32 or 64
-    constexpr int QT = LQ / 32;              // q tiles
+    constexpr int QT = LQ / 32;              // q tiles (1 or 2)
+    constexpr int KS = 2 / QT;               // with one q tile the two wave pairs split the 32-pixel depth of a chunk
     constexpr int BR = 32;
     constexpr int LDP = 64 + 4, LDQ = LQ + 4;
-    __shared__ __attribute__((aligned(16))) float sP[BR * LDP];
-    __shared__ __attribute__((aligned(16))) float sQ[BR * LDQ];
+    constexpr int QPT = LQ / 8;              // floats per thread per row (4 or 8): 8 threads per pixel row
+    __shared__ __attribute__((aligned(16))) float sP[2][BR * LDP];
+    __shared__ __attribute__((aligned(16))) float sQ[2][BR * LDQ];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kh = lane >> 5;
-    const int pt = wave & 1;        // which 32 output channels
-    const int qt = wave >> 1;       // which 32 columns of the filter row
-    const bool active = qt < QT;
+    const int pt = wave & 1;                       // which 32 output channels
+    const int qt = QT == 2 ? (wave >> 1) : 0;      // which 32 filter-row columns
+    const int ks = QT == 2 ? 0 : (wave >> 1);      // which half of the chunk's pixels
     const int OH = a.H / 2, OW = a.W / 2;
     const int Hp = a.H + 6, Wp = a.W + 6;
     const int M = a.N * OH * OW;
@@ -157,46 +183,84 @@ __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_pe
     const int mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
     const int nchunk = mend > mbeg ? (mend - mbeg + BR - 1) / BR : 0;
 
+    // staging roles
+    const int qrow = tid >> 3, qseg = tid & 7;     // Q: pixel row of the chunk, 8 column segments
+    const int prow0 = tid >> 4, pseg = tid & 15;   // P: rows prow0 and prow0 + 16, 16 float4 segments
+    // pixel coordinates of Q row (mbeg + qrow), advanced by BR per chunk without divisions
+    int qn, qy, qx;
+    {
+        const int m = mbeg + qrow;
+        qn = m / (OH * OW);
+        const int rem = m - qn * OH * OW;
+        qy = rem / OW; qx = rem - qy * OW;
+    }
+
     f32x16 acc;
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
-    for (int ch = 0; ch < nchunk; ++ch) {
+    float4 rp[2];
+    float rq[QPT];
+    auto load_chunk = [&](int ch) {
         const int mc = mbeg + ch * BR;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx >> 4, sg = idx & 15;
-            const int m = mc + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < mend) v = *reinterpret_cast<const float4*>(a.dy + (size_t)m * 64 + (size_t)(sg * 4));
-            *reinterpret_cast<float4*>(&sP[row * LDP + sg * 4]) = v;
+            const int m = mc + prow0 + 16 * j;
+            rp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < mend) rp[j] = *reinterpret_cast<const float4*>(a.dy + (size_t)m * 64 + (size_t)(pseg * 4));
         }
-        for (int idx = tid; idx < BR * LQ; idx += 256) {
-            const int row = idx / LQ, j = idx - row * LQ;
-            const int m = mc + row;
-            float v = 0.f;
-            if (j < L && m < mend) {
-                const int n = m / (OH * OW);
-                const int rem = m - n * OH * OW;
-                const int oy = rem / OW, ox = rem - oy * OW;
-                v = a.xp[(size_t)(((n * Hp + 2 * oy + r) * Wp + 2 * ox) * CIN) + (size_t)j];
-            }
-            sQ[row * LDQ + j] = v;
-        }
-        __syncthreads();
-        if (active) {
+        const bool ok = (mc + qrow) < mend;
+        const long long base = (long long)((qn * Hp + 2 * qy + r) * Wp + 2 * qx) * CIN + qseg * QPT;
 #pragma unroll
-            for (int st = 0; st < BR / 2; ++st) {
-                const int k = 2 * st + kh;
-                const float af = sP[k * LDP + pt * 32 + l31];
-                const float bf = sQ[k * LDQ + qt * 32 + l31];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
-            }
+        for (int q = 0; q < QPT; q += 2) {
+            float2 v = make_float2(0.f, 0.f);
+            const int j = qseg * QPT + q;
+            if (ok && j < L) v = *reinterpret_cast<const float2*>(a.xp + base + q);   // 8-byte aligned (all offsets even)
+            if (j + 1 >= L) v.y = 0.f;
+            rq[q] = v.x; rq[q + 1] = v.y;
         }
+        qx += BR;
+        while (qx >= OW) { qx -= OW; ++qy; }
+        while (qy >= OH) { qy -= OH; ++qn; }
+    };
+    auto store_chunk = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&sP[buf][(prow0 + 16 * j) * LDP + pseg * 4]) = rp[j];
+#pragma unroll
+        for (int q = 0; q < QPT; q += 2)
+            *reinterpret_cast<float2*>(&sQ[buf][qrow * LDQ + qseg * QPT + q]) = make_float2(rq[q], rq[q + 1]);
+    };
+
+    if (nchunk > 0) { load_chunk(0); store_chunk(0); }
+    __syncthreads();
+    for (int ch = 0; ch < nchunk; ++ch) {
+        const int buf = ch & 1;
+        const bool more = ch + 1 < nchunk;
+        if (more) load_chunk(ch + 1);
+#pragma unroll
+        for (int st = 0; st < BR / 2 / KS; ++st) {
+            const int k = 2 * (st + ks * (BR / 2 / KS)) + kh;
+            const float af = sP[buf][k * LDP + pt * 32 + l31];
+            const float bf = sQ[buf][k * LDQ + qt * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af, bf, acc, 0, 0, 0);
+        }
+        if (more) store_chunk(buf ^ 1);
         __syncthreads();
     }
-    if (active) {
+    if (KS == 2) {
+        // combine the two depth halves: waves 2,3 hand their accumulators to waves 0,1 through LDS
+        float* red = &sP[0][0];   // [2 pt][16][64]
+        if (ks == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(pt * 16 + e) * 64 + lane] = acc[e];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += red[(pt * 16 + e) * 64 + lane];
+        }
+    }
+    if (ks == 0) {
         float* out = a.partial + (size_t)split * 64 * 7 * L;
         const int j = qt * 32 + l31;
         if (j < L) {

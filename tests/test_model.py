@@ -29,16 +29,28 @@ def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol):
     x, speed, cmd = _inputs(kind, n, h, w, 4)
     eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev)
     xd, sdv, cd = x.to(dev), speed.to(dev), cmd.to(dev)
+    # float64 oracle = ground truth; the float32 oracle's own distance to it measures the conditioning of the case
+    # (eval mode with synthetic running statistics lets activations grow to ~5e4, where fp32 round-off alone moves
+    # the soft-argmax by ~3e-4).  The HIP result must be within max(fwd_tol, 4x that distance) of the truth.
+    sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+
+    def check_forward(train, ps, pa, sd32):
+        with torch.no_grad():
+            o32s, o32a = O.policy_forward(sd32, kind, backbone, x, speed, cmd, train)
+            o64s, o64a = O.policy_forward({k: v.clone() for k, v in sd64.items()}, kind, backbone, x.double(), speed.double(), cmd.double(), train)
+        cond = (o32a.double() - o64a).abs().max().item()
+        tol = max(fwd_tol, 4 * cond)
+        e = max((pa.cpu().double() - o64a).abs().max().item(), (ps.cpu().double() - o64s).abs().max().item())
+        assert e < tol, ("forward train=%s" % train, e, tol, cond)
+        assert e < 1e-3, "north-star bar"
+
     # eval mode (running statistics)
     ps, pa = eng.forward(xd, sdv, cd, False)
-    with torch.no_grad():
-        ops, opa = O.policy_forward({k: v.clone() for k, v in sd.items()}, kind, backbone, x, speed, cmd, False)
-    assert (pa.cpu() - opa).abs().max() < fwd_tol and (ps.cpu() - ops).abs().max() < fwd_tol
+    check_forward(False, ps, pa, {k: v.clone() for k, v in sd.items()})
     # training mode: batch statistics, running-stat update, backward
     ps, pa = eng.forward(xd, sdv, cd, True)
-    sp = O.as_params(sd)
-    ops, opa = O.policy_forward(sp, kind, backbone, x, speed, cmd, True)
-    assert (pa.cpu() - opa).abs().max() < fwd_tol and (ps.cpu() - ops).abs().max() < fwd_tol
+    sp = {k: v.clone() for k, v in sd.items()}
+    check_forward(True, ps, pa, sp)
     for k in sd:
         if k.endswith("running_mean") or k.endswith("running_var"):
             assert torch.allclose(tens[k].cpu(), sp[k], rtol=1e-4, atol=1e-5), k
@@ -51,7 +63,6 @@ def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol):
     # two float32 evaluations (torch-CPU vs HIP) occasionally take different branches for an element that sits at a
     # kink; such a flip moves a few gradient tensors by a finite amount without either side being wrong.  Hence:
     # the typical (median) error must be at round-off level, the 90th percentile within grad_tol, and nothing gross.
-    sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
     sp64 = O.as_params(sd64)
     ops64, opa64 = O.policy_forward(sp64, kind, backbone, x.double(), speed.double(), cmd.double(), True)
     ((opa64 * d_all.double()).sum() + (ops64 * d_sel.double()).sum()).backward()
@@ -106,10 +117,17 @@ def test_modules_match_reference_fixtures(env):
         net.to(dev)
         x, speed, cmd = seeded_inputs(kind, 2, c["input_seed"])
         onehot = O.one_hot(cmd)
+        # the fixture IS a float32 evaluation; its own distance to a float64 evaluation bounds what can be asked
+        sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+        with torch.no_grad():
+            _, o64 = O.policy_forward(sd64, kind, backbone, x.double(), speed.double(), onehot.double(), False)
+        cond = (c["eval_preds"].double() - o64).abs().max().item()
         net.eval()
         with torch.no_grad():
             p, pa = net(x.to(dev), speed.to(dev), onehot.to(dev))
-        assert (pa.cpu() - c["eval_preds"]).abs().max() < 1e-4 and (p.cpu() - c["eval_pred"]).abs().max() < 1e-4
+        e = (pa.cpu() - c["eval_preds"]).abs().max().item()
+        assert e < max(1e-4, 5 * cond) and e < 1e-3, (name, e, cond)
+        assert (p.cpu() - c["eval_pred"]).abs().max().item() < max(1e-4, 5 * cond)
         net.train()
         with torch.no_grad():
             p, pa = net(x.to(dev), speed.to(dev), onehot.to(dev))
