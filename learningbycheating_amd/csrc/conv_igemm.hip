@@ -97,118 +97,104 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[RA], rb[RB];
+    bool aok[RA];
+    float4 lps = make_float4(1.f, 1.f, 1.f, 1.f), lpt = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float relu_floor = (a.pre_scale && a.pre_relu) ? 0.f : -INFINITY;
 
-    auto load_chunk = [&](int it) {
-        const int ti = it / cpt;
-        const int c0 = (it - ti * cpt) * BK;
-        const int tap = sTap[ti];
-        const int r = tap / a.KW, s = tap - r * a.KW;
-        float4 ps = make_float4(1.f, 1.f, 1.f, 1.f), pt = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (a.pre_scale) {
-            ps = *reinterpret_cast<const float4*>(a.pre_scale + c0 + seg * 4);
-            pt = *reinterpret_cast<const float4*>(a.pre_shift + c0 + seg * 4);
-        }
-#pragma unroll
-        for (int j = 0; j < RA; ++j) {
-            int iy, ix;
-            if (MODE == 0) { iy = ay[j] + r; ix = ax[j] + s; }
-            else if (a.S == 2) { iy = (ay[j] - r) >> 1; ix = (ax[j] - s) >> 1; }
-            else { iy = ay[j] - r; ix = ax[j] - s; }
-            const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (ok) {
-                const size_t off = (size_t)(pixbase[j] + iy * a.W + ix) * (size_t)a.C + (size_t)(c0 + seg * 4);
-                v = *reinterpret_cast<const float4*>(a.x + off);
-                if (a.pre_scale) {
-                    v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y;
-                    v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w;
-                    if (a.pre_relu) {
-                        v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                        v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                    }
-                }
-            }
-            ra[j] = v;
-        }
-        if (WMAJOR) {
-#pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const int row = arow + 32 * j;
-                const size_t off = (size_t)(n0 + row) * (size_t)(T * a.C) + (size_t)(tap * a.C + c0 + seg * 4);
-                rb[j] = *reinterpret_cast<const float4*>(a.w + off);
-            }
-        } else {
-#pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const int idx = tid + 256 * j;
-                const int krow = idx / (BN / 4);
-                const int s4 = idx - krow * (BN / 4);
-                const size_t off = (size_t)(c0 + krow) * (size_t)(T * a.K) + (size_t)(tap * a.K + n0 + s4 * 4);
-                rb[j] = *reinterpret_cast<const float4*>(a.w + off);
-            }
-        }
-    };
-
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < RA; ++j)
-            *reinterpret_cast<float4*>(&sA[buf][(arow + 32 * j) * LDK + seg * 4]) = ra[j];
-        if (WMAJOR) {
-#pragma unroll
-            for (int j = 0; j < RB; ++j)
-                *reinterpret_cast<float4*>(&sB[buf][(arow + 32 * j) * LDK + seg * 4]) = rb[j];
-        } else {
-#pragma unroll
-            for (int j = 0; j < RB; ++j) {
-                const int idx = tid + 256 * j;
-                const int krow = idx / (BN / 4);
-                const int s4 = idx - krow * (BN / 4);
-                *reinterpret_cast<float4*>(&sB[buf][krow * LDN + s4 * 4]) = rb[j];
-            }
-        }
-    };
-
+    // Software pipeline, written out once (no lambdas: the staging arrays must stay in registers):
+    //   iteration `it` issues the global loads of chunk it+1, runs the MFMAs of chunk it from LDS buffer it&1, then
+    //   applies the on-load transform to chunk it+1 and writes it to the other LDS buffer; one barrier per chunk.
+    // Loads are unconditional and branch-free (out-of-image taps read a valid dummy address and are zeroed when the
+    // tile is written to LDS) and every use of a loaded value is deferred to the store phase, so all global loads of
+    // chunk it+1 stay in flight underneath the MFMAs of chunk it.
     const int l31 = lane & 31;
     const int kh = lane >> 5;
-
-    auto compute = [&](int buf) {
-#pragma unroll
-        for (int g = 0; g < BK / 8; ++g) {
-            f32x4 af[MT], bf[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-                af[i] = *reinterpret_cast<const f32x4*>(&sA[buf][((wm * MT + i) * 32 + l31) * LDK + g * 8 + kh * 4]);
-            if (WMAJOR) {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bf[j] = *reinterpret_cast<const f32x4*>(&sB[buf][((wn * NT + j) * 32 + l31) * LDK + g * 8 + kh * 4]);
-            } else {
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-                        bf[j][i] = sB[buf][(g * 8 + kh * 4 + i) * LDN + (wn * NT + j) * 32 + l31];
+    for (int it = -1; it < nit; ++it) {
+        const bool more = it + 1 < nit;
+        if (more) {
+            const int nx = it + 1;
+            const int ti = nx / cpt;
+            const int c0 = (nx - ti * cpt) * BK;
+            const int tap = sTap[ti];
+            const int r = tap / a.KW, s = tap - r * a.KW;
+            if (a.pre_scale) {
+                lps = *reinterpret_cast<const float4*>(a.pre_scale + c0 + seg * 4);
+                lpt = *reinterpret_cast<const float4*>(a.pre_shift + c0 + seg * 4);
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int j = 0; j < RA; ++j) {
+                int iy, ix;
+                if (MODE == 0) { iy = ay[j] + r; ix = ax[j] + s; }
+                else if (a.S == 2) { iy = (ay[j] - r) >> 1; ix = (ax[j] - s) >> 1; }
+                else { iy = ay[j] - r; ix = ax[j] - s; }
+                const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int pix = ok ? (pixbase[j] + iy * a.W + ix) : 0;
+                aok[j] = ok;
+                ra[j] = *reinterpret_cast<const float4*>(a.x + ((size_t)pix * (size_t)a.C + (size_t)(c0 + seg * 4)));
+            }
 #pragma unroll
-                for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-                    for (int nj = 0; nj < NT; ++nj)
-                        acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][i], bf[nj][i], acc[mi][nj], 0, 0, 0);
+            for (int j = 0; j < RB; ++j) {
+                size_t off;
+                if (WMAJOR) {
+                    off = (size_t)(n0 + arow + 32 * j) * (size_t)(T * a.C) + (size_t)(tap * a.C + c0 + seg * 4);
+                } else {
+                    const int idx = tid + 256 * j;
+                    const int krow = idx / (BN / 4);
+                    const int s4 = idx - krow * (BN / 4);
+                    off = (size_t)(c0 + krow) * (size_t)(T * a.K) + (size_t)(tap * a.K + n0 + s4 * 4);
+                }
+                rb[j] = *reinterpret_cast<const float4*>(a.w + off);
+            }
         }
-    };
-
-    if (nit > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
-    __syncthreads();
-    for (int it = 0; it < nit; ++it) {
-        const bool more = (it + 1 < nit);
-        if (more) load_chunk(it + 1);
-        compute(it & 1);
-        if (more) store_chunk((it + 1) & 1);
+        if (it >= 0) {
+            const int buf = it & 1;
+#pragma unroll
+            for (int g = 0; g < BK / 8; ++g) {
+                f32x4 af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const f32x4*>(&sA[buf][((wm * MT + i) * 32 + l31) * LDK + g * 8 + kh * 4]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    if (WMAJOR) {
+                        bf[j] = *reinterpret_cast<const f32x4*>(&sB[buf][((wn * NT + j) * 32 + l31) * LDK + g * 8 + kh * 4]);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            bf[j][i] = sB[buf][(g * 8 + kh * 4 + i) * LDN + (wn * NT + j) * 32 + l31];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                        for (int nj = 0; nj < NT; ++nj)
+                            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][i], bf[nj][i], acc[mi][nj], 0, 0, 0);
+            }
+        }
+        if (more) {
+            const int buf = (it + 1) & 1;
+#pragma unroll
+            for (int j = 0; j < RA; ++j) {
+                float4 v = ra[j];
+                v.x = fmaxf(v.x * lps.x + lpt.x, relu_floor); v.y = fmaxf(v.y * lps.y + lpt.y, relu_floor);
+                v.z = fmaxf(v.z * lps.z + lpt.z, relu_floor); v.w = fmaxf(v.w * lps.w + lpt.w, relu_floor);
+                if (!aok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&sA[buf][(arow + 32 * j) * LDK + seg * 4]) = v;
+            }
+#pragma unroll
+            for (int j = 0; j < RB; ++j) {
+                if (WMAJOR) {
+                    *reinterpret_cast<float4*>(&sB[buf][(arow + 32 * j) * LDK + seg * 4]) = rb[j];
+                } else {
+                    const int idx = tid + 256 * j;
+                    const int krow = idx / (BN / 4);
+                    const int s4 = idx - krow * (BN / 4);
+                    *reinterpret_cast<float4*>(&sB[buf][krow * LDN + s4 * 4]) = rb[j];
+                }
+            }
+        }
         __syncthreads();
     }
 

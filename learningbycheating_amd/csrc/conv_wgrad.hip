@@ -71,100 +71,91 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
         qx[j] = rem - qy[j] * a.OW;
     }
 
-    auto load_chunk = [&](int ch) {
-        const int mc = mbeg + ch * BR;
+    bool pok[RP], qok[RQ];
+    const float relu_floor = (a.q_scale && a.q_relu) ? 0.f : -INFINITY;
+
+    // software pipeline written out once (see conv_igemm.hip): loads of chunk ch+1 -> MFMAs of chunk ch -> transform +
+    // LDS store of chunk ch+1 -> barrier.  Loads are branch-free; masking / BatchNorm-on-load happen at store time.
+    for (int ch = -1; ch < nchunk; ++ch) {
+        const bool more = ch + 1 < nchunk;
+        if (more) {
+            const int mc = mbeg + (ch + 1) * BR;
 #pragma unroll
-        for (int j = 0; j < RP; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx / (BP / 4);
-            const int sg = idx - row * (BP / 4);
-            const int m = mc + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < mend) {
-                v = *reinterpret_cast<const float4*>(a.p + (size_t)m * (size_t)a.CP + (size_t)(p0 + sg * 4));
+            for (int j = 0; j < RP; ++j) {
+                const int idx = tid + 256 * j;
+                const int row = idx / (BP / 4);
+                const int sg = idx - row * (BP / 4);
+                const int m = mc + row;
+                pok[j] = m < mend;
+                const int ms = pok[j] ? m : 0;
+                rp[j] = *reinterpret_cast<const float4*>(a.p + (size_t)ms * (size_t)a.CP + (size_t)(p0 + sg * 4));
+            }
+#pragma unroll
+            for (int j = 0; j < RQ; ++j) {
+                const int idx = tid + 256 * j;
+                const int row = idx / (BQ / 4);
+                const int sg = idx - row * (BQ / 4);
+                const int m = mc + row;
+                const int iy = qy[j] * a.S + r - a.P;
+                const int ix = qx[j] * a.S + s - a.P;
+                qok[j] = (m < mend) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                const int pix = qok[j] ? ((qn[j] * a.H + iy) * a.W + ix) : 0;
+                rq[j] = *reinterpret_cast<const float4*>(a.q + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + sg * 4));
+                qx[j] += BR;
+                while (qx[j] >= a.OW) { qx[j] -= a.OW; ++qy[j]; }
+                while (qy[j] >= a.OH) { qy[j] -= a.OH; ++qn[j]; }
+            }
+        }
+        if (ch >= 0) {
+            const int buf = ch & 1;
+#pragma unroll
+            for (int st = 0; st < BR / 2; ++st) {
+                const int k = 2 * st + kh;
+                float af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) af[i] = sP[buf][k * LP + (wm * MT + i) * 32 + l31];
+#pragma unroll
+                for (int j = 0; j < NT; ++j) bf[j] = sQ[buf][k * LQ + (wn * NT + j) * 32 + l31];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) {
+            const int buf = (ch + 1) & 1;
+#pragma unroll
+            for (int j = 0; j < RP; ++j) {
+                const int idx = tid + 256 * j;
+                const int row = idx / (BP / 4);
+                const int sg = idx - row * (BP / 4);
+                float4 v = rp[j];
                 if (a.p_scale) {
                     const float4 ps = *reinterpret_cast<const float4*>(a.p_scale + p0 + sg * 4);
                     const float4 pt = *reinterpret_cast<const float4*>(a.p_shift + p0 + sg * 4);
                     v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y;
                     v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w;
                 }
+                if (!pok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&sP[buf][row * LP + sg * 4]) = v;
             }
-            rp[j] = v;
-        }
 #pragma unroll
-        for (int j = 0; j < RQ; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx / (BQ / 4);
-            const int sg = idx - row * (BQ / 4);
-            const int m = mc + row;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < mend) {
-                const int iy = qy[j] * a.S + r - a.P;
-                const int ix = qx[j] * a.S + s - a.P;
-                if ((unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W) {
-                    const int c = q0 + sg * 4;
-                    v = *reinterpret_cast<const float4*>(a.q + (size_t)((qn[j] * a.H + iy) * a.W + ix) * (size_t)a.CQ + (size_t)c);
-                    if (a.q_scale) {
-                        const float4 ps = *reinterpret_cast<const float4*>(a.q_scale + c);
-                        const float4 pt = *reinterpret_cast<const float4*>(a.q_shift + c);
-                        v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y;
-                        v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w;
-                        if (a.q_relu) {
-                            v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f);
-                            v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-                        }
-                    }
+            for (int j = 0; j < RQ; ++j) {
+                const int idx = tid + 256 * j;
+                const int row = idx / (BQ / 4);
+                const int sg = idx - row * (BQ / 4);
+                float4 v = rq[j];
+                if (a.q_scale) {
+                    const float4 ps = *reinterpret_cast<const float4*>(a.q_scale + q0 + sg * 4);
+                    const float4 pt = *reinterpret_cast<const float4*>(a.q_shift + q0 + sg * 4);
+                    v.x = fmaxf(v.x * ps.x + pt.x, relu_floor); v.y = fmaxf(v.y * ps.y + pt.y, relu_floor);
+                    v.z = fmaxf(v.z * ps.z + pt.z, relu_floor); v.w = fmaxf(v.w * ps.w + pt.w, relu_floor);
                 }
+                if (!qok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
+                *reinterpret_cast<float4*>(&sQ[buf][row * LQ + sg * 4]) = v;
             }
-            rq[j] = v;
-            qx[j] += BR;
-            while (qx[j] >= a.OW) { qx[j] -= a.OW; ++qy[j]; }
-            while (qy[j] >= a.OH) { qy[j] -= a.OH; ++qn[j]; }
         }
-    };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int j = 0; j < RP; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx / (BP / 4);
-            const int sg = idx - row * (BP / 4);
-            *reinterpret_cast<float4*>(&sP[buf][row * LP + sg * 4]) = rp[j];
-        }
-#pragma unroll
-        for (int j = 0; j < RQ; ++j) {
-            const int idx = tid + 256 * j;
-            const int row = idx / (BQ / 4);
-            const int sg = idx - row * (BQ / 4);
-            *reinterpret_cast<float4*>(&sQ[buf][row * LQ + sg * 4]) = rq[j];
-        }
-    };
-    auto compute = [&](int buf) {
-#pragma unroll
-        for (int st = 0; st < BR / 2; ++st) {
-            const int k = 2 * st + kh;
-            float af[MT], bf[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) af[i] = sP[buf][k * LP + (wm * MT + i) * 32 + l31];
-#pragma unroll
-            for (int j = 0; j < NT; ++j) bf[j] = sQ[buf][k * LQ + (wn * NT + j) * 32 + l31];
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
-        }
-    };
-
-    if (nchunk > 0) {
-        load_chunk(0);
-        store_chunk(0);
-    }
-    __syncthreads();
-    for (int ch = 0; ch < nchunk; ++ch) {
-        const bool more = ch + 1 < nchunk;
-        if (more) load_chunk(ch + 1);
-        compute(ch & 1);
-        if (more) store_chunk((ch + 1) & 1);
         __syncthreads();
     }
 

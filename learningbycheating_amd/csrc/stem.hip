@@ -79,12 +79,8 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
     auto load_chunk = [&](int r) {
 #pragma unroll
         for (int q = 0; q < HALF / 2; ++q) {
-            float2 v = make_float2(0.f, 0.f);
-            if (abase >= 0) v = *reinterpret_cast<const float2*>(a.xp + abase + (long long)(r * Wp * CIN + 2 * q));
-            const int j = half * HALF + 2 * q;     // columns >= L are padding: must be exact zeros
-            if (j >= L) v.x = 0.f;
-            if (j + 1 >= L) v.y = 0.f;
-            ra[q] = v;
+            // unconditional load (rows past M read pixel 0); masking is deferred to store_chunk()
+            ra[q] = *reinterpret_cast<const float2*>(a.xp + (abase >= 0 ? abase : half * HALF) + (long long)(r * Wp * CIN + 2 * q));
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
@@ -95,8 +91,13 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int q = 0; q < HALF / 2; ++q)
-            *reinterpret_cast<float2*>(&sA[buf][arow * LD + half * HALF + 2 * q]) = ra[q];
+        for (int q = 0; q < HALF / 2; ++q) {
+            float2 v = ra[q];
+            const int j = half * HALF + 2 * q;     // columns >= L are padding: must be exact zeros
+            if (j >= L || abase < 0) v.x = 0.f;
+            if (j + 1 >= L || abase < 0) v.y = 0.f;
+            *reinterpret_cast<float2*>(&sA[buf][arow * LD + half * HALF + 2 * q]) = v;
+        }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
             const int idx = tid + 256 * q;

@@ -9,7 +9,7 @@ PHASES="${1:-test bench prof}"
 echo "== $(date) phases: $PHASES" > gpurun_out/summary.txt
 rocm-smi --showproductname 2>/dev/null | head -8 >> gpurun_out/summary.txt
 if [[ "$PHASES" == *test* ]]; then
-  timeout 1500 python -m pytest tests -m gpu -x -q ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
+  timeout 1500 python -m pytest tests -m gpu -q ${PYTEST_ARGS:-} > gpurun_out/pytest_gpu.log 2>&1
   echo "pytest exit $?" >> gpurun_out/summary.txt
   tail -15 gpurun_out/pytest_gpu.log >> gpurun_out/summary.txt
 fi
@@ -22,9 +22,21 @@ if [[ "$PHASES" == *bench* ]]; then
   echo "bench exit $?" >> gpurun_out/summary.txt
   tail -2 gpurun_out/bench.log >> gpurun_out/summary.txt
 fi
+if [[ "$PHASES" == *diag* ]]; then
+  for v in NONE LBC_NO_FUSE_Z1 LBC_NO_DGRAD_WT; do
+    env $v=1 timeout 600 python scripts/diag_grads.py ${DIAG_ARGS:-birdview resnet18 192 192 4} > gpurun_out/diag_$v.log 2>&1
+    echo "diag $v exit $?" >> gpurun_out/summary.txt
+  done
+fi
+if [[ "$PHASES" == *ab* ]]; then
+  for v in LBC_NO_FUSE_Z1 LBC_NO_DGRAD_WT; do
+    env $v=1 timeout 600 python bench.py --steps 5 --warmup 2 --init-steps 10 --no-cpu-baseline --breakdown gpurun_out/breakdown_$v.json > gpurun_out/bench_$v.log 2>&1
+    echo "ab $v: $(tail -1 gpurun_out/bench_$v.log | cut -c1-160)" >> gpurun_out/summary.txt
+  done
+fi
 if [[ "$PHASES" == *prof* ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats -d "$OLDPWD/gpurun_out/prof" -o lbc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --init-steps 2 --no-cpu-baseline) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o lbc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --init-steps 2 --no-cpu-baseline) > gpurun_out/prof.log 2>&1
   echo "prof exit $?" >> gpurun_out/summary.txt
   find gpurun_out/prof -name "*kernel_stats*" | head -3 >> gpurun_out/summary.txt
   # keep the (large) raw trace out of the merge budget
