@@ -67,10 +67,9 @@ def spatial_softmax_decoder():
 
 class _PolicyFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, module, image, velocity, command, *params):
+    def forward(ctx, module, need_grad, image, velocity, command, *params):
         ctx.set_materialize_grads(False)
-        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        eng = module._engine_for(image, need_grad)
+        eng = module._engine_for(image, need_grad)   # (grad mode is always off inside Function.forward: decided by the caller)
         pred_sel, pred_all = eng.forward(image, velocity, command, module.training)
         ctx.module, ctx.eng, ctx.train = module, eng, module.training
         return pred_sel, pred_all
@@ -80,7 +79,7 @@ class _PolicyFunction(torch.autograd.Function):
         if not ctx.train:
             raise RuntimeError("backward through an eval-mode (running-statistics) forward is not implemented")
         if d_sel is None and d_all is None:
-            return (None,) * (4 + len(ctx.module._param_names))
+            return (None,) * (5 + len(ctx.module._param_names))
         eng = ctx.eng
         eng.backward(None if d_sel is None else d_sel.contiguous().float(),
                      None if d_all is None else d_all.contiguous().float())
@@ -88,7 +87,7 @@ class _PolicyFunction(torch.autograd.Function):
         for n in ctx.module._param_names:
             v = eng.grad_views.get(n)
             grads.append(None if v is None else v.clone(memory_format=torch.preserve_format))
-        return (None, None, None, None) + tuple(grads)
+        return (None, None, None, None, None) + tuple(grads)
 
 
 class PolicyBase(ResnetBase):
@@ -145,4 +144,5 @@ class PolicyBase(ResnetBase):
         velocity = velocity.to(x.device).contiguous().float()
         command = command.to(x.device).contiguous().float()
         params = [p for _, p in self.named_parameters()]
-        return _PolicyFunction.apply(self, x, velocity, command, *params)
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _PolicyFunction.apply(self, need_grad, x, velocity, command, *params)

@@ -96,9 +96,9 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[RA], rb[RB];
+    f32x4 ra[RA], rb[RB];   // native vector values (HIP's float4 struct would be copied through a scratch alloca)
     bool aok[RA];
-    float4 lps = make_float4(1.f, 1.f, 1.f, 1.f), lpt = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x4 lps = {1.f, 1.f, 1.f, 1.f}, lpt = {0.f, 0.f, 0.f, 0.f};
     const float relu_floor = (a.pre_scale && a.pre_relu) ? 0.f : -INFINITY;
 
     // Software pipeline, written out once (no lambdas: the staging arrays must stay in registers):
@@ -118,8 +118,8 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
             const int tap = sTap[ti];
             const int r = tap / a.KW, s = tap - r * a.KW;
             if (a.pre_scale) {
-                lps = *reinterpret_cast<const float4*>(a.pre_scale + c0 + seg * 4);
-                lpt = *reinterpret_cast<const float4*>(a.pre_shift + c0 + seg * 4);
+                lps = *reinterpret_cast<const f32x4*>(a.pre_scale + c0 + seg * 4);
+                lpt = *reinterpret_cast<const f32x4*>(a.pre_shift + c0 + seg * 4);
             }
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
@@ -130,7 +130,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
                 const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int pix = ok ? (pixbase[j] + iy * a.W + ix) : 0;
                 aok[j] = ok;
-                ra[j] = *reinterpret_cast<const float4*>(a.x + ((size_t)pix * (size_t)a.C + (size_t)(c0 + seg * 4)));
+                ra[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)pix * (size_t)a.C + (size_t)(c0 + seg * 4)));
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
                     const int s4 = idx - krow * (BN / 4);
                     off = (size_t)(c0 + krow) * (size_t)(T * a.K) + (size_t)(tap * a.K + n0 + s4 * 4);
                 }
-                rb[j] = *reinterpret_cast<const float4*>(a.w + off);
+                rb[j] = *reinterpret_cast<const f32x4*>(a.w + off);
             }
         }
         if (it >= 0) {
@@ -177,21 +177,20 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
             const int buf = (it + 1) & 1;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
-                float4 v = ra[j];
-                v.x = fmaxf(v.x * lps.x + lpt.x, relu_floor); v.y = fmaxf(v.y * lps.y + lpt.y, relu_floor);
-                v.z = fmaxf(v.z * lps.z + lpt.z, relu_floor); v.w = fmaxf(v.w * lps.w + lpt.w, relu_floor);
-                if (!aok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(&sA[buf][(arow + 32 * j) * LDK + seg * 4]) = v;
+                f32x4 v = ra[j] * lps + lpt;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = aok[j] ? fmaxf(v[e], relu_floor) : 0.f;
+                *reinterpret_cast<f32x4*>(&sA[buf][(arow + 32 * j) * LDK + seg * 4]) = v;
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 if (WMAJOR) {
-                    *reinterpret_cast<float4*>(&sB[buf][(arow + 32 * j) * LDK + seg * 4]) = rb[j];
+                    *reinterpret_cast<f32x4*>(&sB[buf][(arow + 32 * j) * LDK + seg * 4]) = rb[j];
                 } else {
                     const int idx = tid + 256 * j;
                     const int krow = idx / (BN / 4);
                     const int s4 = idx - krow * (BN / 4);
-                    *reinterpret_cast<float4*>(&sB[buf][krow * LDN + s4 * 4]) = rb[j];
+                    *reinterpret_cast<f32x4*>(&sB[buf][krow * LDN + s4 * 4]) = rb[j];
                 }
             }
         }

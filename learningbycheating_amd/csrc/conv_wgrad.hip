@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    float4 rp[RP], rq[RQ];
+    f32x4 rp[RP], rq[RQ];   // native vector values (see conv_igemm.hip)
 
     // pixel coordinates of this thread's Q rows, advanced by BR per chunk (no integer divisions in the loop)
     int qn[RQ], qy[RQ], qx[RQ];
@@ -88,7 +88,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
                 const int m = mc + row;
                 pok[j] = m < mend;
                 const int ms = pok[j] ? m : 0;
-                rp[j] = *reinterpret_cast<const float4*>(a.p + (size_t)ms * (size_t)a.CP + (size_t)(p0 + sg * 4));
+                rp[j] = *reinterpret_cast<const f32x4*>(a.p + (size_t)ms * (size_t)a.CP + (size_t)(p0 + sg * 4));
             }
 #pragma unroll
             for (int j = 0; j < RQ; ++j) {
@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
                 const int ix = qx[j] * a.S + s - a.P;
                 qok[j] = (m < mend) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int pix = qok[j] ? ((qn[j] * a.H + iy) * a.W + ix) : 0;
-                rq[j] = *reinterpret_cast<const float4*>(a.q + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + sg * 4));
+                rq[j] = *reinterpret_cast<const f32x4*>(a.q + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + sg * 4));
                 qx[j] += BR;
                 while (qx[j] >= a.OW) { qx[j] -= a.OW; ++qy[j]; }
                 while (qy[j] >= a.OH) { qy[j] -= a.OH; ++qn[j]; }
@@ -130,30 +130,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
                 const int idx = tid + 256 * j;
                 const int row = idx / (BP / 4);
                 const int sg = idx - row * (BP / 4);
-                float4 v = rp[j];
+                f32x4 v = rp[j];
                 if (a.p_scale) {
-                    const float4 ps = *reinterpret_cast<const float4*>(a.p_scale + p0 + sg * 4);
-                    const float4 pt = *reinterpret_cast<const float4*>(a.p_shift + p0 + sg * 4);
-                    v.x = v.x * ps.x + pt.x; v.y = v.y * ps.y + pt.y;
-                    v.z = v.z * ps.z + pt.z; v.w = v.w * ps.w + pt.w;
+                    const f32x4 ps = *reinterpret_cast<const f32x4*>(a.p_scale + p0 + sg * 4);
+                    const f32x4 pt = *reinterpret_cast<const f32x4*>(a.p_shift + p0 + sg * 4);
+                    v = v * ps + pt;
                 }
-                if (!pok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(&sP[buf][row * LP + sg * 4]) = v;
+                if (!pok[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&sP[buf][row * LP + sg * 4]) = v;
             }
 #pragma unroll
             for (int j = 0; j < RQ; ++j) {
                 const int idx = tid + 256 * j;
                 const int row = idx / (BQ / 4);
                 const int sg = idx - row * (BQ / 4);
-                float4 v = rq[j];
+                f32x4 v = rq[j];
                 if (a.q_scale) {
-                    const float4 ps = *reinterpret_cast<const float4*>(a.q_scale + q0 + sg * 4);
-                    const float4 pt = *reinterpret_cast<const float4*>(a.q_shift + q0 + sg * 4);
-                    v.x = fmaxf(v.x * ps.x + pt.x, relu_floor); v.y = fmaxf(v.y * ps.y + pt.y, relu_floor);
-                    v.z = fmaxf(v.z * ps.z + pt.z, relu_floor); v.w = fmaxf(v.w * ps.w + pt.w, relu_floor);
+                    const f32x4 ps = *reinterpret_cast<const f32x4*>(a.q_scale + q0 + sg * 4);
+                    const f32x4 pt = *reinterpret_cast<const f32x4*>(a.q_shift + q0 + sg * 4);
+                    v = v * ps + pt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], relu_floor);
                 }
-                if (!qok[j]) v = make_float4(0.f, 0.f, 0.f, 0.f);
-                *reinterpret_cast<float4*>(&sQ[buf][row * LQ + sg * 4]) = v;
+                if (!qok[j]) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4*>(&sQ[buf][row * LQ + sg * 4]) = v;
             }
         }
         __syncthreads();

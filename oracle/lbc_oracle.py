@@ -126,12 +126,31 @@ def checksum(sd):
 # ----------------------------------------------------------------------------------------
 # forward (functional)
 # ----------------------------------------------------------------------------------------
+BN_MOMENTUM = 0.1   # torch default, used everywhere in the reference; tests may set it to 1.0 to calibrate running stats
+
+
 def _bn(sd, prefix, x, train):
     """nn.BatchNorm2d: momentum 0.1, eps 1e-5; training mode updates running stats in sd."""
     if train:
         sd[prefix + ".num_batches_tracked"] += 1
     return F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
-                        sd[prefix + ".bias"], train, 0.1, 1e-5)
+                        sd[prefix + ".bias"], train, BN_MOMENTUM, 1e-5)
+
+
+def calibrate_running_stats(sd, kind, backbone, x, velocity, command):
+    """Overwrite the running statistics of `sd` with the batch statistics of (x, velocity): what a trained network's
+    buffers look like.  (Seeded random running stats let eval-mode activations grow to ~5e4, an ill-conditioned case.)"""
+    global BN_MOMENTUM
+    old, BN_MOMENTUM = BN_MOMENTUM, 1.0
+    try:
+        with torch.no_grad():
+            policy_forward(sd, kind, backbone, x, velocity, command, True)
+    finally:
+        BN_MOMENTUM = old
+    for k in sd:
+        if k.endswith("num_batches_tracked"):
+            sd[k].zero_()
+    return sd
 
 
 def trunk(sd, backbone, x, train, taps=None):
