@@ -21,9 +21,38 @@ __global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict_
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
-    double s = 0.0;
-    for (int r = blockIdx.y; r < rows; r += gridDim.y) s += (double)in[(size_t)r * cols + c];
-    out[(size_t)blockIdx.y * cols + c] = (float)s;
+    // four independent accumulators keep four loads in flight (the loop is latency bound otherwise); fixed order -> deterministic
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    const int step = gridDim.y;
+    int r = blockIdx.y;
+    for (; r + 3 * step < rows; r += 4 * step) {
+        s0 += (double)in[(size_t)r * cols + c];
+        s1 += (double)in[(size_t)(r + step) * cols + c];
+        s2 += (double)in[(size_t)(r + 2 * step) * cols + c];
+        s3 += (double)in[(size_t)(r + 3 * step) * cols + c];
+    }
+    for (; r < rows; r += step) s0 += (double)in[(size_t)r * cols + c];
+    out[(size_t)blockIdx.y * cols + c] = (float)((s0 + s1) + (s2 + s3));
+}
+
+// sums column c of a [rows][2][C] partial buffer with 4 loads in flight; fixed order
+__device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int rows, int C, int c, double& o1, double& o2)
+{
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
+    int r = 0;
+    for (; r + 3 < rows; r += 4) {
+        const float* p = partial + (size_t)r * 2 * C + c;
+        a0 += (double)p[0];             b0 += (double)p[C];
+        a1 += (double)p[2 * C];         b1 += (double)p[3 * C];
+        a2 += (double)p[4 * C];         b2 += (double)p[5 * C];
+        a3 += (double)p[6 * C];         b3 += (double)p[7 * C];
+    }
+    for (; r < rows; ++r) {
+        a0 += (double)partial[(size_t)r * 2 * C + c];
+        b0 += (double)partial[(size_t)r * 2 * C + C + c];
+    }
+    o1 = (a0 + a1) + (a2 + a3);
+    o2 = (b0 + b1) + (b2 + b3);
 }
 
 // ---- forward finalize ----------------------------------------------------------
@@ -34,11 +63,8 @@ __global__ __launch_bounds__(64) void bn_finalize_k(BnFinalizeArgs a)
     if (c >= a.C) return;
     float mean, invstd;
     if (a.train) {
-        double s1 = 0.0, s2 = 0.0;
-        for (int r = 0; r < a.rows; ++r) {
-            s1 += (double)a.partial[(size_t)r * 2 * a.C + c];
-            s2 += (double)a.partial[(size_t)r * 2 * a.C + a.C + c];
-        }
+        double s1, s2;
+        sum_rows2(a.partial, a.rows, a.C, c, s1, s2);
         const double n = (double)a.count;
         const double m = s1 / n;
         double var = s2 / n - m * m;
@@ -168,11 +194,8 @@ __global__ __launch_bounds__(64) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
 {
     const int c = blockIdx.x * 64 + threadIdx.x;
     if (c >= a.C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < a.rows; ++r) {
-        s1 += (double)a.partial[(size_t)r * 2 * a.C + c];
-        s2 += (double)a.partial[(size_t)r * 2 * a.C + a.C + c];
-    }
+    double s1, s2;
+    sum_rows2(a.partial, a.rows, a.C, c, s1, s2);
     if (a.dbeta) a.dbeta[c] = (float)s1;
     if (a.dgamma) a.dgamma[c] = (float)s2;
     if (a.coefA) {

@@ -43,8 +43,19 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
     const int lane = tid & 63;
     const int wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.x * BM;
-    const int n0 = blockIdx.y * BN;
+    // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch rule; speed only, never correctness).  The
+    // remap hands every XCD one contiguous range of tiles, column tiles of the same rows first, so neighbouring tiles
+    // (shared halo rows, shared A rows across column tiles) hit in that XCD's private L2.  Bijective for any tile count.
+    const int ntn = a.K / BN;
+    int tile_id;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int mtile = tile_id / ntn;
+    const int m0 = mtile * BM;
+    const int n0 = (tile_id - mtile * ntn) * BN;
     const int T = a.KH * a.KW;
 
     if (tid == 0) {
@@ -112,9 +123,12 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
     for (int it = -1; it < nit; ++it) {
         const bool more = it + 1 < nit;
         if (more) {
+            // depth order: 32-channel slab outer, filter taps inner -- the (up to 9) shifted gathers of one slab re-read
+            // the same few KB per workgroup back to back (L1/L2 hits) instead of streaming the whole tile 9 times
             const int nx = it + 1;
-            const int ti = nx / cpt;
-            const int c0 = (nx - ti * cpt) * BK;
+            const int ci = nx / ntap;
+            const int ti = nx - ci * ntap;
+            const int c0 = ci * BK;
             const int tap = sTap[ti];
             const int r = tap / a.KW, s = tap - r * a.KW;
             if (a.pre_scale) {
@@ -258,7 +272,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
-            float* dst = a.stats + (size_t)(a.stat_row0 + blockIdx.x) * 2 * (size_t)a.K;
+            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
             dst[n0 + tid] = t1;
             dst[a.K + n0 + tid] = t2;
         }
@@ -287,7 +301,7 @@ __global__ __launch_bounds__(256) void weight_transpose_k(const float* __restric
 template <int BM, int BN>
 int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
-    dim3 grid((unsigned)lbc_cdiv(a.M, BM), (unsigned)(a.K / BN));
+    dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN)));
     if (wmajor && mode == 0)      hipLaunchKernelGGL((conv_igemm_f32<BM, BN, true, 0>), grid, dim3(256), 0, s, a);
     else if (wmajor && mode == 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, true, 1>), grid, dim3(256), 0, s, a);
     else if (!wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, false, 0>), grid, dim3(256), 0, s, a);

@@ -34,14 +34,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
 
-    const int split = blockIdx.x;
-    const int qtiles = a.CQ / BQ;
-    const int tp = blockIdx.y / qtiles;
-    const int tq = blockIdx.y - tp * qtiles;
-    const int p0 = tp * BP, q0 = tq * BQ;
-    const int tap = blockIdx.z;
-    const int r = tap / a.KW, s = tap - r * a.KW;
+    // Work decode: workgroup b runs on XCD b % 8.  The T tap-workgroups of one (split, tile) group read the same P rows
+    // and overlapping Q rows, so they are given ids b, b+8, ..., b+8(T-1): same XCD, dispatched back to back, and the
+    // operands are fetched from HBM once and re-read from that XCD's L2.  Padding ids (group >= ngroups) exit at once.
     const int T = a.KH * a.KW;
+    const int qtiles = a.CQ / BQ;
+    const int ntiles = (a.CP / BP) * qtiles;
+    const int ngroups = a.nsplit * ntiles;
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int tap = qq % T;
+    const int group = (qq / T) * 8 + xcd;
+    if (group >= ngroups) return;
+    const int split = group / ntiles;
+    const int tile = group - split * ntiles;
+    const int tp = tile / qtiles;
+    const int tq = tile - tp * qtiles;
+    const int p0 = tp * BP, q0 = tq * BQ;
+    const int r = tap / a.KW, s = tap - r * a.KW;
 
     const int M = a.N * a.OH * a.OW;
     const int mbeg = split * rows_per_split;
@@ -221,13 +230,11 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * BR;
     LbcProfScope prof("conv_wgrad", 2.0 * M * a.CP * (double)a.CQ * a.KH * a.KW,
                       4.0 * ((double)M * a.CP + (double)a.N * a.H * a.W * a.CQ + (double)a.nsplit * a.CP * a.KH * a.KW * a.CQ), s);
-    if (big_tile(a)) {
-        dim3 grid((unsigned)a.nsplit, (unsigned)((a.CP / 128) * (a.CQ / 128)), (unsigned)(a.KH * a.KW));
-        hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
-    } else {
-        dim3 grid((unsigned)a.nsplit, (unsigned)((a.CP / 64) * (a.CQ / 64)), (unsigned)(a.KH * a.KW));
-        hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
-    }
+    const int bt = big_tile(a) ? 128 : 64;
+    const long long ngroups = (long long)a.nsplit * (a.CP / bt) * (a.CQ / bt);
+    const dim3 grid((unsigned)(((ngroups + 7) / 8) * 8 * a.KH * a.KW));
+    if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
+    else             hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("conv_wgrad_f32");
 }
 

@@ -71,7 +71,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     const size_t NB = (size_t)d.max_batch;
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
     if (const char* e = getenv("LBC_NO_FUSE_Z1")) fuse_z1_ = !(e[0] == '1');
-    if (const char* e = getenv("LBC_NO_DGRAD_WT")) dgrad_wt_ = !(e[0] == '1');
+    if (const char* e = getenv("LBC_DGRAD_WT")) dgrad_wt_ = (e[0] == '1');
 
     // ---- stem (resnet.py:102-106) ----
     stem_w_ = add_tensor("conv.conv1.weight", kParam, {64, Cin, 7, 7});

@@ -82,7 +82,7 @@ private:
 
     int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre = nullptr);
     int conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s);
-    bool dgrad_wt_ = true;   // input-gradient GEMMs read a per-step transposed copy of the weights (depth-contiguous)
+    bool dgrad_wt_ = false;  // optional: input-gradient GEMMs read a per-step transposed copy of the weights (measured: no gain)
     size_t wt_ = 0;
     bool fuse_z1_ = true;    // conv2 / wgrad2 / bn1-backward read y1 with bn1(+ReLU) applied on load; z1 is never written
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);

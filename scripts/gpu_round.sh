@@ -42,4 +42,16 @@ if [[ "$PHASES" == *prof* ]]; then
   # keep the (large) raw trace out of the merge budget
   find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
 fi
+if [[ "$PHASES" == *pmc* ]]; then
+  # hardware counters: separate passes, kernel-trace only (no sys/runtime tracing together with --pmc)
+  i=0
+  for ctrs in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32" "FETCH_SIZE" "WRITE_SIZE"; do
+    i=$((i+1))
+    rm -rf gpurun_out/pmc$i
+    (cd /tmp && timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc$i" -o lbc -- python "$OLDPWD/bench.py" --steps 1 --warmup 1 --init-steps 1 --no-cpu-baseline) > gpurun_out/pmc$i.log 2>&1
+    echo "pmc$i ($ctrs) exit $?" >> gpurun_out/summary.txt
+    find gpurun_out/pmc$i -name "*kernel_trace*" -delete
+    ls -la gpurun_out/pmc$i/* 2>/dev/null | head -5 >> gpurun_out/summary.txt
+  done
+fi
 cat gpurun_out/summary.txt
