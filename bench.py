@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 FLOP_PER_IMAGE_STEP = 31.212e9      # student fwd 9.441 + bwd 18.593 + teacher fwd 3.178 GFLOP
 PEAK_FP32_MFMA_TFLOPS = 157.3       # MI355X_MICROARCH.md chip table
+PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (same table)
 PEAK_HBM_GBS = 8000.0
 
 
@@ -86,6 +87,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-batch", type=int, default=256)
+    ap.add_argument("--dtype", choices=["f32", "bf16"], default="f32",
+                    help="f32: exact-f32 MFMA everywhere (the parity path). bf16: convolution MFMA operands rounded to bf16, f32 "
+                         "accumulation, f32 master weights/activations/BatchNorm/soft-argmax/loss/Adam (BASELINE.json config 3)")
     ap.add_argument("--init-steps", type=int, default=40, help="below-horizon warm start (stands in for the phase-0 checkpoint)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel-class profile of the instrumented step here (json)")
@@ -113,6 +117,7 @@ def main():
     per_gpu = args.global_batch // world
     assert per_gpu * world == args.global_batch, "global batch must divide by the number of GPUs"
     student, teacher = build_models(device)
+    student.precision = teacher.precision = {"f32": "fp32", "bf16": "bf16"}[args.dtype]
     broadcast_module(student); broadcast_module(teacher)
     rgb, bv, speed, cmd = synthetic_batch(per_gpu, device, 1000 + rank)
     from learningbycheating_amd.bird_view.utils.train_utils import one_hot
@@ -173,8 +178,10 @@ def main():
         ms = sum(v["ms"] for v in conv); gf = sum(v["gflop"] for v in conv); n = sum(v["launches"] for v in conv)
         total_ms = sum(v["ms"] for v in breakdown.values())
         ach = gf / ms if ms > 0 else 0.0     # GFLOP / ms = TFLOP/s
-        roof = {"bound": "mfma", "kernel": "conv_igemm_f32 / conv_wgrad_f32 (fp32 MFMA 32x32x2)", "achieved": round(ach, 2),
-                "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4), "traffic": None,
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
+        kname = "conv_igemm_k / conv_wgrad_bf16_k (v_mfma_f32_32x32x16_bf16)" if args.dtype == "bf16" else "conv_igemm_k / conv_wgrad_f32 (v_mfma_f32_32x32x2_f32)"
+        roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
+                "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "gflop_per_launch": round(gf / max(n, 1), 3),
                 "share_of_step_kernel_time": round(ms / total_ms, 3) if total_ms else None}
         if args.breakdown:
@@ -186,10 +193,10 @@ def main():
         value = args.global_batch * args.steps / dt
         out = {"metric": "images/sec ImagePolicyModelSS phase-1 train @ bs256", "value": round(value, 2), "unit": "images/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
-               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "ImagePolicyModelSS(resnet34) phase-1 step vs BirdViewPolicyModelSS(resnet18) teacher, "
-                                      "160x384 RGB + 7x192x192 bird-view, global batch %d (%d/GPU), fp32 MFMA, local BatchNorm, "
-                                      "Adam lr 1e-4" % (args.global_batch, per_gpu),
+                                      "160x384 RGB + 7x192x192 bird-view, global batch %d (%d/GPU), %s, local BatchNorm, "
+                                      "Adam lr 1e-4" % (args.global_batch, per_gpu, "bf16 MFMA operands + f32 accumulate/master/BN/loss/Adam" if args.dtype == "bf16" else "exact-f32 MFMA"),
                           "global_batch": args.global_batch, "parallelism": "dp%d" % world},
                "loss": loss_mean, "loss_finite": bool(loss_mean == loss_mean and abs(loss_mean) != float("inf")),
                "algorithmic_tflops": round(value * FLOP_PER_IMAGE_STEP / 1e12, 2),

@@ -32,6 +32,9 @@ typedef struct lbc_conv_desc {
     int K;              /* output channels */
     int KH, KW, S, P;   /* filter size, stride, padding */
     int relu;           /* fuse ReLU into the epilogue */
+    int bf16;           /* 0: exact f32 MFMA.  1: MFMA operands rounded to bf16 (RNE), f32 accumulate; tensors stay f32 */
+    int w_transposed;   /* lbc_conv2d_dgrad / lbc_deconv3x3s2_fwd only: `w` is the lbc_weight_transpose()d copy (depth-
+                           contiguous for these GEMMs).  Required when bf16 = 1. */
 } lbc_conv_desc;
 
 /* nn.Conv2d forward (reference bird_view/models/resnet.py:15-22,102; image.py:57).
@@ -42,6 +45,10 @@ typedef struct lbc_conv_desc {
 int lbc_conv2d_fwd(const lbc_conv_desc* d, const float* x, const float* w, const float* bias,
                    const float* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
                    float* y, float* stats, int* stats_rows, lbc_stream_t stream);
+
+/* w[A][T][B] -> wt[B][T][A] (fp32).  Conv2d weights [K][T][C] -> [C][T][K] for lbc_conv2d_dgrad, ConvTranspose2d weights
+ * [C][T][K] -> [K][T][C] for lbc_deconv3x3s2_fwd, when lbc_conv_desc.w_transposed = 1. */
+int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc_stream_t stream);
 
 /* Input gradient of nn.Conv2d (autograd of the call sites above; loss.backward() at
  * training/train_image_phase1.py:204).  dx[N,H,W,C] = dgrad(dy[N,OH,OW,K], w) (+resid). */
@@ -79,6 +86,8 @@ typedef struct lbc_net_desc {
     int H, W;          /* input image size, multiples of 32 (160x384 / 192x192) */
     int normalize;     /* 1: (x-mean)/std with the ImageNet constants of image.py:32-35 */
     int max_batch;
+    int precision;     /* 0: f32 everywhere (exact-f32 MFMA; the parity path).  1: convolution MFMA operands rounded to
+                          bf16 with f32 accumulation; tensors, BatchNorm, softmax, loss, Adam and the stem stay f32 */
 } lbc_net_desc;
 typedef struct lbc_net lbc_net;
 

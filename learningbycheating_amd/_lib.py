@@ -15,11 +15,11 @@ c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ct
 
 
 class ConvDesc(ctypes.Structure):
-    _fields_ = [(n, c_int) for n in ("N", "H", "W", "C", "K", "KH", "KW", "S", "P", "relu")]
+    _fields_ = [(n, c_int) for n in ("N", "H", "W", "C", "K", "KH", "KW", "S", "P", "relu", "bf16", "w_transposed")]
 
 
 class NetDesc(ctypes.Structure):
-    _fields_ = [(n, c_int) for n in ("arch", "in_channels", "H", "W", "normalize", "max_batch")]
+    _fields_ = [(n, c_int) for n in ("arch", "in_channels", "H", "W", "normalize", "max_batch", "precision")]
 
 
 class Camera(ctypes.Structure):
@@ -36,6 +36,7 @@ _SIGNATURES = {
     "lbc_version": (c_int, []),
     "lbc_conv2d_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 6 + [c_int, c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p]),
     "lbc_conv2d_dgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5),
+    "lbc_weight_transpose_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "lbc_conv2d_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "lbc_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "lbc_deconv3x3s2_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p]),

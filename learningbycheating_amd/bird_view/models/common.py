@@ -93,6 +93,9 @@ class _PolicyFunction(torch.autograd.Function):
 class PolicyBase(ResnetBase):
     """Executor plumbing shared by the two policy models."""
     _normalize = False
+    #: "fp32" (default, the parity path: exact-f32 MFMA) or "bf16" (convolution MFMA operands rounded to bf16, f32
+    #: accumulation; weights, activations, BatchNorm, soft-argmax, loss and Adam stay f32).  Set before the first forward.
+    precision = "fp32"
 
     def _finish_init(self):
         # 4-D weights live in channels_last memory order: logical shapes (= checkpoint shapes) stay
@@ -115,10 +118,11 @@ class PolicyBase(ResnetBase):
 
     def _engine_for(self, image, with_grads):
         n, c, h, w = image.shape
-        key = (h, w, str(image.device))
+        prec = {"fp32": 0, "bf16": 1}[self.precision]
+        key = (h, w, str(image.device), prec)
         eng = self._engines.get(key)
         if eng is None or eng.max_batch < n:
-            eng = PolicyEngine(self._arch(), self.input_channel, h, w, self._normalize, max(n, 1), image.device)
+            eng = PolicyEngine(self._arch(), self.input_channel, h, w, self._normalize, max(n, 1), image.device, prec)
             self._engines[key] = eng
         tensors = dict(self.named_parameters())
         tensors.update(dict(self.named_buffers()))

@@ -22,6 +22,7 @@ static IgemmArgs conv_args(const lbc_conv_desc* d)
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K;
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
     a.relu = d->relu;
+    a.bf16 = d->bf16;
     return a;
 }
 
@@ -52,7 +53,7 @@ static int conv_dgrad_impl(const lbc_conv_desc* d, const float* dy, const float*
     const int OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu;
+    a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu; a.bf16 = d->bf16;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
     a.N = d->N; a.H = OH; a.W = OW; a.C = d->K;
     a.OH = d->H; a.OW = d->W; a.K = d->C;
@@ -85,12 +86,20 @@ static int conv_dgrad_impl(const lbc_conv_desc* d, const float* dy, const float*
     return LBC_OK;
 }
 
+int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc_stream_t stream)
+{
+    LBC_REQUIRE(w && wt && A > 0 && T > 0 && B > 0, "weight_transpose: bad arguments");
+    return lbc_weight_transpose(w, wt, A, T, B, (hipStream_t)stream);
+}
+
 int lbc_conv2d_dgrad(const lbc_conv_desc* d, const float* dy, const float* w, const float* resid,
                      float* dx, lbc_stream_t stream)
 {
     LBC_REQUIRE(d, "conv2d_dgrad: null desc");
-    // weights [K][T][C]: depth index (gathered channel) = k is the slow axis -> wmajor 0 with row length C
-    return conv_dgrad_impl(d, dy, w, /*wmajor=*/0, resid, nullptr, nullptr, nullptr, 0, 0, dx, nullptr, nullptr,
+    LBC_REQUIRE(!d->bf16 || d->w_transposed, "conv2d_dgrad: bf16 needs w_transposed = 1 (see lbc_weight_transpose_f32)");
+    // weights [K][T][C]: depth index (gathered channel) = k is the slow axis -> wmajor 0 with row length C;
+    // the transposed copy [C][T][K] is depth-contiguous -> wmajor 1
+    return conv_dgrad_impl(d, dy, w, /*wmajor=*/d->w_transposed ? 1 : 0, resid, nullptr, nullptr, nullptr, 0, 0, dx, nullptr, nullptr,
                            (hipStream_t)stream);
 }
 
@@ -109,8 +118,9 @@ int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const float* x, const float* w, 
                         float* y, float* stats, int* stats_rows, lbc_stream_t stream)
 {
     LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_fwd: geometry must be k3 s2 p1 op1");
+    LBC_REQUIRE(!d->bf16 || d->w_transposed, "deconv3x3s2_fwd: bf16 needs w_transposed = 1 (see lbc_weight_transpose_f32)");
     lbc_conv_desc c = deconv_as_conv(d);
-    return conv_dgrad_impl(&c, x, w, /*wmajor=*/0, nullptr, bias, pre_scale, pre_shift, pre_relu, d->relu, y, stats,
+    return conv_dgrad_impl(&c, x, w, /*wmajor=*/d->w_transposed ? 1 : 0, nullptr, bias, pre_scale, pre_shift, pre_relu, d->relu, y, stats,
                            stats_rows, (hipStream_t)stream);
 }
 
@@ -134,6 +144,7 @@ static WgradArgs conv_wgrad_args(const lbc_conv_desc* d)
     a.CP = d->K;
     a.H = d->H; a.W = d->W; a.CQ = d->C;
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
+    a.bf16 = d->bf16;
     a.nsplit = lbc_wgrad_pick_split(a);
     return a;
 }
@@ -167,6 +178,7 @@ static WgradArgs deconv_wgrad_args(const lbc_conv_desc* d)
     a.N = d->N; a.OH = d->H; a.OW = d->W; a.CP = d->C;
     a.H = 2 * d->H; a.W = 2 * d->W; a.CQ = d->K;
     a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
+    a.bf16 = d->bf16;
     a.nsplit = lbc_wgrad_pick_split(a);
     return a;
 }

@@ -17,25 +17,36 @@
 // contracts the channel pair {i, 4+i} of each 8-channel group -- A and B use the
 // same pairing, so the sum over depth is complete.
 #include "lbc_common.hpp"
+#include <type_traits>
 
 namespace {
 
-constexpr int BK = 32;          // channels per depth chunk
-constexpr int LDK = BK + 4;     // padded LDS row (floats) for [row][k] tiles
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-template <int BM, int BN, bool WMAJOR, int MODE>
-__global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
+// BF16 = false: exact-f32 MFMA (32x32x2), 32-channel chunks, float LDS tiles.
+// BF16 = true : operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when the tile is written to LDS and multiplied on
+//               v_mfma_f32_32x32x16_bf16 with f32 accumulation; activations, weights, statistics and everything outside the
+//               MFMA stay f32 in HBM.  64-channel chunks, bf16 LDS tiles ([row][k] only: weights must be depth-contiguous).
+template <int BM, int BN, bool WMAJOR, int MODE, bool BF16>
+__global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
 {
+    static_assert(!BF16 || WMAJOR, "the bf16 path needs depth-contiguous weights");
+    using lds_t = typename std::conditional<BF16, __bf16, float>::type;
+    constexpr int BK = BF16 ? 64 : 32;      // channels per depth chunk
+    constexpr int LDK = BK + (BF16 ? 8 : 4);   // padded LDS row (elements): 144-byte rows either way -> conflict-free b128 reads
+    constexpr int SEGS = BK / 4;            // float4 segments per tile row
+    constexpr int RPP = 256 / SEGS;         // tile rows staged per pass of the 256 threads
     constexpr int WM = 2, WN = 2;
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
-    constexpr int RA = BM / 32;            // A rows (float4 loads) per thread per chunk
-    constexpr int RB = BN / 32;            // B float4 loads per thread per chunk
-    constexpr int LDN = BN + 4;            // padded LDS row for [k][n] tiles
+    constexpr int RA = BM / RPP;            // A float4 loads per thread per chunk
+    constexpr int RB = WMAJOR ? BN / RPP : BK * BN / 4 / 256;
+    constexpr int LDN = BN + 4;             // padded LDS row for [k][n] tiles (f32 only)
     constexpr int SB = WMAJOR ? BN * LDK : BK * LDN;
 
-    __shared__ __attribute__((aligned(16))) float sA[2][BM * LDK];
-    __shared__ __attribute__((aligned(16))) float sB[2][SB];
+    __shared__ __attribute__((aligned(16))) lds_t sA[2][BM * LDK];
+    __shared__ __attribute__((aligned(16))) lds_t sB[2][SB];
     __shared__ int sTap[16];
     __shared__ int sNTap;
 
@@ -72,13 +83,13 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
     }
 
     // ---- per-thread A row descriptors -------------------------------------
-    const int seg = tid & 7;
-    const int arow = tid >> 3;
+    const int seg = tid % SEGS;
+    const int arow = tid / SEGS;
     int pixbase[RA];
     int ay[RA], ax[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        const int m = m0 + arow + 32 * j;
+        const int m = m0 + arow + RPP * j;
         if (m < a.M) {
             const int lhw = a.LH * a.LW;
             const int n = m / lhw;
@@ -150,7 +161,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
             for (int j = 0; j < RB; ++j) {
                 size_t off;
                 if (WMAJOR) {
-                    off = (size_t)(n0 + arow + 32 * j) * (size_t)(T * a.C) + (size_t)(tap * a.C + c0 + seg * 4);
+                    off = (size_t)(n0 + arow + RPP * j) * (size_t)(T * a.C) + (size_t)(tap * a.C + c0 + seg * 4);
                 } else {
                     const int idx = tid + 256 * j;
                     const int krow = idx / (BN / 4);
@@ -162,29 +173,47 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
         }
         if (it >= 0) {
             const int buf = it & 1;
+            if constexpr (BF16) {
 #pragma unroll
-            for (int g = 0; g < BK / 8; ++g) {
-                f32x4 af[MT], bf[NT];
+                for (int g = 0; g < BK / 16; ++g) {
+                    bf16x8 af[MT], bf[NT];
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    af[i] = *reinterpret_cast<const f32x4*>(&sA[buf][((wm * MT + i) * 32 + l31) * LDK + g * 8 + kh * 4]);
+                    for (int i = 0; i < MT; ++i)
+                        af[i] = *reinterpret_cast<const bf16x8*>(&sA[buf][((wm * MT + i) * 32 + l31) * LDK + g * 16 + kh * 8]);
 #pragma unroll
-                for (int j = 0; j < NT; ++j) {
-                    if (WMAJOR) {
-                        bf[j] = *reinterpret_cast<const f32x4*>(&sB[buf][((wn * NT + j) * 32 + l31) * LDK + g * 8 + kh * 4]);
-                    } else {
-#pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            bf[j][i] = sB[buf][(g * 8 + kh * 4 + i) * LDN + (wn * NT + j) * 32 + l31];
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 4; ++i)
+                    for (int j = 0; j < NT; ++j)
+                        bf[j] = *reinterpret_cast<const bf16x8*>(&sB[buf][((wn * NT + j) * 32 + l31) * LDK + g * 16 + kh * 8]);
 #pragma unroll
                     for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
                         for (int nj = 0; nj < NT; ++nj)
-                            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][i], bf[nj][i], acc[mi][nj], 0, 0, 0);
+                            acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[mi], bf[nj], acc[mi][nj], 0, 0, 0);
+                }
+            } else {
+#pragma unroll
+                for (int g = 0; g < BK / 8; ++g) {
+                    f32x4 af[MT], bf[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+                        af[i] = *reinterpret_cast<const f32x4*>(&sA[buf][((wm * MT + i) * 32 + l31) * LDK + g * 8 + kh * 4]);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) {
+                        if (WMAJOR) {
+                            bf[j] = *reinterpret_cast<const f32x4*>(&sB[buf][((wn * NT + j) * 32 + l31) * LDK + g * 8 + kh * 4]);
+                        } else {
+#pragma unroll
+                            for (int i = 0; i < 4; ++i)
+                                bf[j][i] = sB[buf][(g * 8 + kh * 4 + i) * LDN + (wn * NT + j) * 32 + l31];
+                        }
+                    }
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                            for (int nj = 0; nj < NT; ++nj)
+                                acc[mi][nj] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[mi][i], bf[nj][i], acc[mi][nj], 0, 0, 0);
+                }
             }
         }
         if (more) {
@@ -194,12 +223,17 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
                 f32x4 v = ra[j] * lps + lpt;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = aok[j] ? fmaxf(v[e], relu_floor) : 0.f;
-                *reinterpret_cast<f32x4*>(&sA[buf][(arow + 32 * j) * LDK + seg * 4]) = v;
+                if constexpr (BF16)
+                    *reinterpret_cast<bf16x4*>(&sA[buf][(arow + RPP * j) * LDK + seg * 4]) = __builtin_convertvector(v, bf16x4);
+                else
+                    *reinterpret_cast<f32x4*>(&sA[buf][(arow + RPP * j) * LDK + seg * 4]) = v;
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                if (WMAJOR) {
-                    *reinterpret_cast<f32x4*>(&sB[buf][(arow + 32 * j) * LDK + seg * 4]) = rb[j];
+                if constexpr (BF16) {
+                    *reinterpret_cast<bf16x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = __builtin_convertvector(rb[j], bf16x4);
+                } else if (WMAJOR) {
+                    *reinterpret_cast<f32x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = rb[j];
                 } else {
                     const int idx = tid + 256 * j;
                     const int krow = idx / (BN / 4);
@@ -253,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_igemm_f32(IgemmArgs a)
 
     if (a.stats) {
         // combine the two half-waves (rows 4*kh+...), then the two M-waves through LDS
-        float* red = &sA[0][0];   // [WM][2][BN]; the main loop's last barrier has passed
+        float* red = reinterpret_cast<float*>(&sA[0][0]);   // [WM][2][BN]; the main loop's last barrier has passed
 #pragma unroll
         for (int nj = 0; nj < NT; ++nj) {
             s1[nj] += __shfl_xor(s1[nj], 32);
@@ -302,11 +336,14 @@ template <int BM, int BN>
 int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
     dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN)));
-    if (wmajor && mode == 0)      hipLaunchKernelGGL((conv_igemm_f32<BM, BN, true, 0>), grid, dim3(256), 0, s, a);
-    else if (wmajor && mode == 1) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, true, 1>), grid, dim3(256), 0, s, a);
-    else if (!wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_f32<BM, BN, false, 0>), grid, dim3(256), 0, s, a);
-    else                          hipLaunchKernelGGL((conv_igemm_f32<BM, BN, false, 1>), grid, dim3(256), 0, s, a);
-    return lbc_check_launch("conv_igemm_f32");
+    if (a.bf16) {
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true>), grid, dim3(256), 0, s, a);
+    } else if (wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, false>), grid, dim3(256), 0, s, a);
+    else if (wmajor && mode == 1)   hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, false>), grid, dim3(256), 0, s, a);
+    else if (!wmajor && mode == 0)  hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 0, false>), grid, dim3(256), 0, s, a);
+    else                            hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 1, false>), grid, dim3(256), 0, s, a);
+    return lbc_check_launch("conv_igemm");
 }
 
 const int kCfgBM[3] = {128, 128, 64};
@@ -335,7 +372,8 @@ int lbc_igemm_pick(long long M, int K)
 int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s)
 {
     LBC_REQUIRE(cfg >= 0 && cfg < 3, "igemm: bad cfg %d", cfg);
-    LBC_REQUIRE(a.C % BK == 0, "igemm: gathered channels %d not a multiple of %d", a.C, BK);
+    LBC_REQUIRE(a.C % (a.bf16 ? 64 : 32) == 0, "igemm: gathered channels %d not a multiple of %d", a.C, a.bf16 ? 64 : 32);
+    LBC_REQUIRE(!a.bf16 || wmajor, "igemm: the bf16 path needs depth-contiguous weights (transpose first)");
     LBC_REQUIRE(a.K % kCfgBN[cfg] == 0, "igemm: output channels %d not a multiple of tile %d", a.K, kCfgBN[cfg]);
     LBC_REQUIRE(a.KH * a.KW <= 16, "igemm: too many taps");
     LBC_REQUIRE(a.S == 1 || a.S == 2, "igemm: stride %d unsupported", a.S);

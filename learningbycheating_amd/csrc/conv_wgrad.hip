@@ -182,6 +182,192 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
         }
 }
 
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// bf16-MFMA variant (v_mfma_f32_32x32x16_bf16, f32 accumulation; operands stay f32 in HBM and are rounded to bf16 when
+// the tile is written to LDS).  The contraction runs over pixels, which are the slow axis of both NHWC operands, while a
+// bf16 MFMA fragment wants 8 consecutive depth values per lane.  So every thread stages 4 consecutive pixels x 4 channels
+// micro-tiles, transposes them in registers (free) and writes four 8-byte rows [channel][4 pixels]: LDS tiles are
+// [channel][64 pixels] and fragments are plain conflict-free ds_read_b128, with no extra LDS traffic.
+template <int BP, int BQ>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_per_split)
+{
+    constexpr int BRH = 64;                 // pixels per chunk
+    constexpr int LD = BRH + 8;             // padded LDS row (bf16 elements) = 144 bytes
+    constexpr int WM = 2, WN = 2;
+    constexpr int MT = BP / WM / 32, NT = BQ / WN / 32;
+    constexpr int CGP = BP / 4, CGQ = BQ / 4;           // channel groups
+    constexpr int NP = 16 * CGP / 256, NQ = 16 * CGQ / 256;   // micro-tiles per thread (1 or 2)
+    __shared__ __attribute__((aligned(16))) __bf16 sP[2][BP * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 sQ[2][BQ * LD];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    const int T = a.KH * a.KW;
+    const int qtiles = a.CQ / BQ;
+    const int ntiles = (a.CP / BP) * qtiles;
+    const int ngroups = a.nsplit * ntiles;
+    const int xcd = blockIdx.x & 7, qq = blockIdx.x >> 3;
+    const int tap = qq % T;
+    const int group = (qq / T) * 8 + xcd;
+    if (group >= ngroups) return;
+    const int split = group / ntiles;
+    const int tile = group - split * ntiles;
+    const int tp = tile / qtiles;
+    const int tq = tile - tp * qtiles;
+    const int p0 = tp * BP, q0 = tq * BQ;
+    const int r = tap / a.KW, s = tap - r * a.KW;
+
+    const int M = a.N * a.OH * a.OW;
+    const int mbeg = split * rows_per_split;
+    const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+    const int nchunk = (mend > mbeg) ? (mend - mbeg + BRH - 1) / BRH : 0;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    f32x4 rp[NP][4], rq[NQ][4];
+    bool pok[NP][4], qok[NQ][4];
+    // coordinates of the first pixel of each Q micro-tile, advanced by BRH per chunk
+    int qn[NQ], qy[NQ], qx[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        const int pg = (tid + 256 * t) / CGQ;
+        const int m = mbeg + 4 * pg;
+        const int ohw = a.OH * a.OW;
+        qn[t] = m / ohw;
+        const int rem = m - qn[t] * ohw;
+        qy[t] = rem / a.OW;
+        qx[t] = rem - qy[t] * a.OW;
+    }
+    const float relu_floor = (a.q_scale && a.q_relu) ? 0.f : -INFINITY;
+
+    for (int ch = -1; ch < nchunk; ++ch) {
+        const bool more = ch + 1 < nchunk;
+        if (more) {
+            const int mc = mbeg + (ch + 1) * BRH;
+#pragma unroll
+            for (int t = 0; t < NP; ++t) {
+                const int u = tid + 256 * t;
+                const int cg = u % CGP, pg = u / CGP;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mc + 4 * pg + i;
+                    pok[t][i] = m < mend;
+                    const int ms = pok[t][i] ? m : 0;
+                    rp[t][i] = *reinterpret_cast<const f32x4*>(a.p + (size_t)ms * (size_t)a.CP + (size_t)(p0 + cg * 4));
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                const int u = tid + 256 * t;
+                const int cg = u % CGQ, pg = u / CGQ;
+                int n = qn[t], y = qy[t], x = qx[t];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mc + 4 * pg + i;
+                    const int iy = y * a.S + r - a.P;
+                    const int ix = x * a.S + s - a.P;
+                    qok[t][i] = (m < mend) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    const int pix = qok[t][i] ? ((n * a.H + iy) * a.W + ix) : 0;
+                    rq[t][i] = *reinterpret_cast<const f32x4*>(a.q + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + cg * 4));
+                    if (++x >= a.OW) { x = 0; if (++y >= a.OH) { y = 0; ++n; } }
+                }
+                qx[t] += BRH;
+                while (qx[t] >= a.OW) { qx[t] -= a.OW; ++qy[t]; }
+                while (qy[t] >= a.OH) { qy[t] -= a.OH; ++qn[t]; }
+            }
+        }
+        if (ch >= 0) {
+            const int buf = ch & 1;
+#pragma unroll
+            for (int g = 0; g < BRH / 16; ++g) {
+                bf16x8 af[MT], bf[NT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8*>(&sP[buf][((wm * MT + i) * 32 + l31) * LD + g * 16 + kh * 8]);
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8*>(&sQ[buf][((wn * NT + j) * 32 + l31) * LD + g * 16 + kh * 8]);
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (more) {
+            const int buf = (ch + 1) & 1;
+#pragma unroll
+            for (int t = 0; t < NP; ++t) {
+                const int u = tid + 256 * t;
+                const int cg = u % CGP, pg = u / CGP;
+                f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
+                if (a.p_scale) {
+                    ps = *reinterpret_cast<const f32x4*>(a.p_scale + p0 + cg * 4);
+                    pt = *reinterpret_cast<const f32x4*>(a.p_shift + p0 + cg * 4);
+                }
+                f32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = rp[t][i] * ps + pt;
+                    if (!pok[t][i]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 col = {v[0][c], v[1][c], v[2][c], v[3][c]};   // channel c of the 4 pixels
+                    *reinterpret_cast<bf16x4*>(&sP[buf][(cg * 4 + c) * LD + pg * 4]) = __builtin_convertvector(col, bf16x4);
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) {
+                const int u = tid + 256 * t;
+                const int cg = u % CGQ, pg = u / CGQ;
+                f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
+                if (a.q_scale) {
+                    ps = *reinterpret_cast<const f32x4*>(a.q_scale + q0 + cg * 4);
+                    pt = *reinterpret_cast<const f32x4*>(a.q_shift + q0 + cg * 4);
+                }
+                f32x4 v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = rq[t][i] * ps + pt;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[i][e] = qok[t][i] ? fmaxf(v[i][e], relu_floor) : 0.f;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 col = {v[0][c], v[1][c], v[2][c], v[3][c]};
+                    *reinterpret_cast<bf16x4*>(&sQ[buf][(cg * 4 + c) * LD + pg * 4]) = __builtin_convertvector(col, bf16x4);
+                }
+            }
+        }
+        __syncthreads();
+    }
+
+    float* out = a.partial + (size_t)split * (size_t)a.CP * (size_t)T * (size_t)a.CQ;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int prow = p0 + (wm * MT + i) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                const int qcol = q0 + (wn * NT + j) * 32 + l31;
+                out[((size_t)prow * (size_t)T + (size_t)tap) * (size_t)a.CQ + (size_t)qcol] = acc[i][j][e];
+            }
+        }
+}
+
 __global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict__ partial, int nsplit, long long count4,
                                                          float* __restrict__ out, float beta)
 {
@@ -226,15 +412,19 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     LBC_REQUIRE(a.nsplit >= 1, "wgrad: nsplit %d", a.nsplit);
     const long long M = (long long)a.N * a.OH * a.OW;
     LBC_REQUIRE(M > 0 && M * a.CP < (1ll << 31) && (long long)a.N * a.H * a.W * a.CQ < (1ll << 31), "wgrad: bad tensor size");
-    const long long chunks = (M + BR - 1) / BR;
-    const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * BR;
+    const int br = a.bf16 ? 64 : BR;
+    const long long chunks = (M + br - 1) / br;
+    const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * br;
     LbcProfScope prof("conv_wgrad", 2.0 * M * a.CP * (double)a.CQ * a.KH * a.KW,
                       4.0 * ((double)M * a.CP + (double)a.N * a.H * a.W * a.CQ + (double)a.nsplit * a.CP * a.KH * a.KW * a.CQ), s);
     const int bt = big_tile(a) ? 128 : 64;
     const long long ngroups = (long long)a.nsplit * (a.CP / bt) * (a.CQ / bt);
     const dim3 grid((unsigned)(((ngroups + 7) / 8) * 8 * a.KH * a.KW));
-    if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
-    else             hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
+    if (a.bf16) {
+        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
+        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
+    } else if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
+    else                    hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("conv_wgrad_f32");
 }
 

@@ -72,6 +72,8 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
     if (const char* e = getenv("LBC_NO_FUSE_Z1")) fuse_z1_ = !(e[0] == '1');
     if (const char* e = getenv("LBC_DGRAD_WT")) dgrad_wt_ = (e[0] == '1');
+    bf16_ = d.precision == 1;
+    if (bf16_) dgrad_wt_ = true;   // the bf16 tiles are [row][depth] only: every weight operand must be depth-contiguous
 
     // ---- stem (resnet.py:102-106) ----
     stem_w_ = add_tensor("conv.conv1.weight", kParam, {64, Cin, 7, 7});
@@ -174,7 +176,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     wg = std::max(wg, (size_t)lbc_stem_wgrad_split((int)NB, H0, W0) * 64 * 49 * Cin);
     wg_partial_ = alloc(wg);
 
-    wt_ = alloc((size_t)512 * 512 * 9);
+    wt_ = alloc((size_t)640 * 512 * 9);
     gD_ = alloc(max_act); gE_ = alloc(max_act); gF_ = alloc(max_act); gG_ = alloc(max_act);
     g0_ = alloc(NB * (H0 / 2) * (W0 / 2) * 64);
 }
@@ -203,6 +205,7 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     const int cfg = lbc_igemm_pick(a.M, a.K);
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? W(partial_) : nullptr;
+    a.bf16 = bf16_;
     return lbc_igemm_launch(a, 1, 0, cfg, s);
 }
 
@@ -317,11 +320,17 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
         a.LH = D.H; a.LW = D.W; a.ostep = 2;
         a.M = N * D.H * D.W;
         a.stats = tr ? W(partial_) : nullptr;
+        int wmajor = 0;
+        if (bf16_) {
+            // w[Cin][T][Cout] -> wt[Cout][T][Cin]: depth-contiguous for the bf16 tiles
+            LBC_TRY(lbc_weight_transpose(P(D.w), W(wt_), D.Cin, 9, D.Cout, s));
+            a.w = W(wt_); a.bf16 = 1; wmajor = 1;
+        }
         const int cfg = lbc_igemm_pick(a.M, a.K);
         const int per = lbc_igemm_rows(a, cfg);
         for (int ph = 0; ph < 4; ++ph) {
             a.oy0 = ph >> 1; a.ox0 = ph & 1; a.stat_row0 = ph * per;
-            LBC_TRY(lbc_igemm_launch(a, 0, 1, cfg, s));
+            LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
         }
         const long long opix = (long long)N * 4 * D.H * D.W;
         if (i < 2) {
@@ -399,6 +408,7 @@ int Net::conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const floa
     memset(&a, 0, sizeof(a));
     a.p = dy; a.q = x; a.partial = W(wg_partial_);
     if (pre) { a.q_scale = W(pre->scale); a.q_shift = W(pre->shift); a.q_relu = 1; }
+    a.bf16 = bf16_;
     a.N = N; a.OH = c.OH; a.OW = c.OW; a.CP = c.Cout;
     a.H = c.H; a.W = c.W; a.CQ = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
@@ -417,7 +427,8 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     a.OH = c.H; a.OW = c.W; a.K = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
     int wmajor = 0;
-    if (dgrad_wt_ && c.k == 3) {
+    a.bf16 = bf16_;
+    if (dgrad_wt_ && (c.k == 3 || bf16_)) {
         // w[Cout][T][Cin] -> wt[Cin][T][Cout]: output channel (Cin) major, gathered channel (Cout) contiguous
         LBC_TRY(lbc_weight_transpose(P(c.w), W(wt_), c.Cout, c.k * c.k, c.Cin, s));
         a.w = W(wt_);
@@ -536,6 +547,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             wa.p_scale = W(D.bn.scale); wa.p_shift = W(D.bn.shift);
             wa.N = N; wa.OH = D.H; wa.OW = D.W; wa.CP = D.Cin;
             wa.H = 2 * D.H; wa.W = 2 * D.W; wa.CQ = D.Cout; wa.KH = 3; wa.KW = 3; wa.S = 2; wa.P = 1;
+            wa.bf16 = bf16_;
             wa.nsplit = lbc_wgrad_pick_split(wa);
             LBC_TRY(lbc_wgrad_launch(wa, s));
             LBC_TRY(lbc_splitk_reduce(wa.partial, wa.nsplit, (long long)D.Cin * 9 * D.Cout, G(D.w), 0.f, s));
@@ -546,6 +558,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             a.N = N; a.H = 2 * D.H; a.W = 2 * D.W; a.C = D.Cout;
             a.OH = D.H; a.OW = D.W; a.K = D.Cin; a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
             a.M = N * D.H * D.W; a.LH = D.H; a.LW = D.W; a.ostep = 1;
+            a.bf16 = bf16_;
             LBC_TRY(lbc_igemm_launch(a, 1, 0, lbc_igemm_pick(a.M, a.K), s));   // F = d bn(x)
             // BatchNorm backward; for the first decoder stage only the 512 trunk channels carry on
             float* dst = i == 0 ? bwd_D_ : E;
@@ -619,6 +632,7 @@ int lbc_net_create(const lbc_net_desc* d, lbc_net** out)
     LBC_REQUIRE(d->H > 0 && d->W > 0 && d->H % 32 == 0 && d->W % 32 == 0, "net_create: image %dx%d must be a multiple of 32", d->H, d->W);
     LBC_REQUIRE(d->max_batch >= 1, "net_create: max_batch %d", d->max_batch);
     LBC_REQUIRE(!d->normalize || d->in_channels == 3, "net_create: ImageNet normalisation needs 3 channels");
+    LBC_REQUIRE(d->precision == 0 || d->precision == 1, "net_create: precision %d unknown (0 = f32, 1 = bf16 MFMA operands)", d->precision);
     LBC_REQUIRE((long long)d->max_batch * (d->H / 2) * (d->W / 2) * 64 < (1ll << 31), "net_create: batch too large for 32-bit indexing");
     *out = new lbc_net(*d);
     return LBC_OK;

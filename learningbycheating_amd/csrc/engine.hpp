@@ -84,6 +84,7 @@ private:
     int conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s);
     bool dgrad_wt_ = false;  // optional: input-gradient GEMMs read a per-step transposed copy of the weights (measured: no gain)
     size_t wt_ = 0;
+    bool bf16_ = false;      // precision 1: bf16 MFMA operands in the convolution family
     bool fuse_z1_ = true;    // conv2 / wgrad2 / bn1-backward read y1 with bn1(+ReLU) applied on load; z1 is never written
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,

@@ -73,6 +73,7 @@ struct IgemmArgs {
     int oy0, ox0, ostep;
     int relu;
     int stat_row0;
+    int bf16;             // 1: bf16 MFMA operands (f32 storage / accumulation), needs wmajor weights and C % 64 == 0
 };
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg);   // number of M tiles (= stats rows) of a launch
@@ -99,6 +100,7 @@ struct WgradArgs {
     int H, W, CQ;
     int KH, KW, S, P;
     int nsplit;
+    int bf16;             // 1: bf16 MFMA operands (f32 storage / accumulation)
 };
 int lbc_wgrad_pick_split(const WgradArgs& a);
 int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s);

@@ -19,9 +19,10 @@ def is_channels_last_4d(t):
 class PolicyEngine:
     """Binds an nn.Module's parameters/buffers (by state_dict name) to an lbc_net plan."""
 
-    def __init__(self, arch, in_channels, height, width, normalize, max_batch, device):
+    def __init__(self, arch, in_channels, height, width, normalize, max_batch, device, precision=0):
         lib = _lib.get()
-        self.desc = _lib.NetDesc(arch, in_channels, height, width, int(normalize), max_batch)
+        self.desc = _lib.NetDesc(arch, in_channels, height, width, int(normalize), max_batch, int(precision))
+        self.precision = int(precision)
         h = ctypes.c_void_p()
         _lib.check(lib.lbc_net_create(ctypes.byref(self.desc), ctypes.byref(h)), "net_create")
         self.handle = h

@@ -126,6 +126,39 @@ def checksum(sd):
 # ----------------------------------------------------------------------------------------
 # forward (functional)
 # ----------------------------------------------------------------------------------------
+# Emulation of the executor's optional "bf16 MFMA operand" precision (lbc_net_desc.precision = 1): every operand of a
+# trunk/decoder convolution GEMM -- activations, weights and, in the backward pass, output gradients -- is rounded to
+# bf16 (RNE) right before the multiply; accumulation, tensors and everything else stay f32.  The stem and the head's 1x1
+# convolution are not rounded.  Off by default (the reference arithmetic is f32).
+MFMA_BF16 = False
+
+
+def _rbf(t):
+    return t.to(torch.bfloat16).to(t.dtype)
+
+
+class _RoundGradBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rbf(g)
+
+
+def _conv(x, w, bias, stride, pad):
+    if MFMA_BF16:
+        return _RoundGradBF16.apply(F.conv2d(_rbf(x), _rbf(w), None, stride, pad)) + (0 if bias is None else bias.view(1, -1, 1, 1))
+    return F.conv2d(x, w, bias, stride, pad)
+
+
+def _deconv(x, w, bias):
+    if MFMA_BF16:
+        return _RoundGradBF16.apply(F.conv_transpose2d(_rbf(x), _rbf(w), None, 2, 1, 1)) + bias.view(1, -1, 1, 1)
+    return F.conv_transpose2d(x, w, bias, 2, 1, 1)
+
+
 BN_MOMENTUM = 0.1   # torch default, used everywhere in the reference; tests may set it to 1.0 to calibrate running stats
 
 
@@ -167,12 +200,12 @@ def trunk(sd, backbone, x, train, taps=None):
             p = "conv.layer%d.%d" % (li + 1, bi)
             stride = 2 if (li > 0 and bi == 0) else 1
             identity = x
-            out = F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1)
+            out = _conv(x, sd[p + ".conv1.weight"], None, stride, 1)
             out = F.relu(_bn(sd, p + ".bn1", out, train))
-            out = F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1)
+            out = _conv(out, sd[p + ".conv2.weight"], None, 1, 1)
             out = _bn(sd, p + ".bn2", out, train)
             if stride != 1 or inpl != planes:
-                identity = _bn(sd, p + ".downsample.1", F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0), train)
+                identity = _bn(sd, p + ".downsample.1", _conv(x, sd[p + ".downsample.0.weight"], None, stride, 0), train)
             x = F.relu(out + identity)
             inpl = planes
         if taps is not None:
@@ -207,7 +240,7 @@ def policy_forward(sd, kind, backbone, x, velocity, command, train, taps=None):
     h = torch.cat((h, vel), dim=1)
     for i in range(3):                                                          # image.py:37-47
         h = _bn(sd, "deconv.%d" % (3 * i), h, train)
-        h = F.conv_transpose2d(h, sd["deconv.%d.weight" % (3 * i + 1)], sd["deconv.%d.bias" % (3 * i + 1)], 2, 1, 1)
+        h = _deconv(h, sd["deconv.%d.weight" % (3 * i + 1)], sd["deconv.%d.bias" % (3 * i + 1)])
         h = F.relu(h)
     if taps is not None:
         taps["decoder"] = h

@@ -22,6 +22,11 @@ if [[ "$PHASES" == *bench* ]]; then
   echo "bench exit $?" >> gpurun_out/summary.txt
   tail -2 gpurun_out/bench.log >> gpurun_out/summary.txt
 fi
+if [[ "$PHASES" == *bf16* ]]; then
+  timeout 900 python bench.py --dtype bf16 --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --breakdown gpurun_out/breakdown_bf16.json > gpurun_out/bench_bf16.log 2>&1
+  echo "bench bf16 exit $?" >> gpurun_out/summary.txt
+  tail -1 gpurun_out/bench_bf16.log | cut -c1-900 >> gpurun_out/summary.txt
+fi
 if [[ "$PHASES" == *diag* ]]; then
   for v in NONE LBC_NO_FUSE_Z1 LBC_NO_DGRAD_WT; do
     env $v=1 timeout 600 python scripts/diag_grads.py ${DIAG_ARGS:-birdview resnet18 192 192 4} > gpurun_out/diag_$v.log 2>&1

@@ -137,7 +137,6 @@ template <typename T> static inline T __shfl(T v, int src, int width = 64) {
 // ---- MFMA -------------------------------------------------------------------
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
-typedef short emu_s16x8 __attribute__((ext_vector_type(8)));
 
 static inline emu_f32x16 emu_mfma_f32_32x32x2f32(float a, float b, emu_f32x16 c, int, int, int) {
     struct AB { float a, b; };
@@ -187,19 +186,16 @@ static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c, i
 }
 #define __builtin_amdgcn_mfma_f32_16x16x4f32 emu_mfma_f32_16x16x4f32
 
-static inline float emu_bf16_to_f32(short h) {
-    unsigned u = ((unsigned)(unsigned short)h) << 16;
-    float f;
-    memcpy(&f, &u, 4);
-    return f;
-}
-// v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31], j=0..7.
-static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c, int, int, int) {
-    struct AB { short a[8], b[8]; };
+typedef __bf16 emu_bf16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_bf16: lane l holds A[i=l&31][k=8*(l>>5)+j], B[k=8*(l>>5)+j][n=l&31], j=0..7; products are exact in
+// f32, accumulation in f32 (the hardware's internal summation order is not specified: tests use a tolerance).
+static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, emu_f32x16 c, int, int, int) {
+    struct AB { float a[8], b[8]; };
+    static_assert(sizeof(AB) <= 64, "slot");
     emu::Slot* s = emu::wave_slots_begin();
     int l = emu::lane_id();
     AB me;
-    for (int j = 0; j < 8; ++j) { me.a[j] = a[j]; me.b[j] = b[j]; }
+    for (int j = 0; j < 8; ++j) { me.a[j] = (float)a[j]; me.b[j] = (float)b[j]; }
     memcpy(s[l].b, &me, sizeof(me));
     emu::wave_rendezvous();
     emu_f32x16 d = c;
@@ -211,7 +207,7 @@ static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, em
             AB A, B;
             memcpy(&A, s[row + 32 * kh].b, sizeof(A));
             memcpy(&B, s[col + 32 * kh].b, sizeof(B));
-            for (int j = 0; j < 8; ++j) acc += emu_bf16_to_f32(A.a[j]) * emu_bf16_to_f32(B.b[j]);
+            for (int j = 0; j < 8; ++j) acc += A.a[j] * B.b[j];
         }
         d[r] = acc;
     }

@@ -34,13 +34,19 @@ class Conv:
         self.dev = device
         self.lib = _lib.get()
 
-    def desc(self, N, H, W, C, K, k, s, p, relu=0):
-        return _lib.ConvDesc(N, H, W, C, K, k, k, s, p, relu)
+    def desc(self, N, H, W, C, K, k, s, p, relu=0, bf16=0, wt=0):
+        return _lib.ConvDesc(N, H, W, C, K, k, k, s, p, relu, bf16, wt)
 
-    def fwd(self, x, w, stride, pad, bias=None, resid=None, pre=None, relu=0, stats=False):
+    def transpose(self, w3, A, T, B):
+        """w3: device tensor [A][T][B] -> [B][T][A] through the library"""
+        out = torch.empty((B, T, A), device=self.dev)
+        _lib.check(self.lib.lbc_weight_transpose_f32(_lib.ptr(w3), _lib.ptr(out), A, T, B, _lib.stream_for(w3)))
+        return out
+
+    def fwd(self, x, w, stride, pad, bias=None, resid=None, pre=None, relu=0, stats=False, bf16=0):
         N, C, H, W = x.shape
         K, _, k, _ = w.shape
-        d = self.desc(N, H, W, C, K, k, stride, pad, relu)
+        d = self.desc(N, H, W, C, K, k, stride, pad, relu, bf16)
         OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         xh, wh = nhwc(x).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
         buf, y = guarded((N, OH, OW, K), self.dev)
@@ -55,21 +61,23 @@ class Conv:
         check_guard(buf, y.numel())
         return nchw(y).cpu(), (st.cpu() if stats else None)
 
-    def dgrad(self, dy, w, H, W, stride, pad, resid=None):
+    def dgrad(self, dy, w, H, W, stride, pad, resid=None, bf16=0, transposed=False):
         N, K = dy.shape[:2]
         _, C, k, _ = w.shape
-        d = self.desc(N, H, W, C, K, k, stride, pad)
+        d = self.desc(N, H, W, C, K, k, stride, pad, 0, bf16, 1 if transposed else 0)
         dyh, wh = nhwc(dy).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        if transposed:
+            wh = self.transpose(wh.view(K, k * k, C), K, k * k, C)
         r = nhwc(resid).to(self.dev) if resid is not None else None
         buf, dx = guarded((N, H, W, C), self.dev)
         _lib.check(self.lib.lbc_conv2d_dgrad(ctypes.byref(d), _lib.ptr(dyh), _lib.ptr(wh), _lib.ptr(r), _lib.ptr(dx), _lib.stream_for(dyh)))
         check_guard(buf, dx.numel())
         return nchw(dx).cpu()
 
-    def wgrad(self, x, dy, k, stride, pad, pre=None, beta=0.0, dw0=None):
+    def wgrad(self, x, dy, k, stride, pad, pre=None, beta=0.0, dw0=None, bf16=0):
         N, C, H, W = x.shape
         K = dy.shape[1]
-        d = self.desc(N, H, W, C, K, k, stride, pad)
+        d = self.desc(N, H, W, C, K, k, stride, pad, 0, bf16)
         ws = torch.empty(self.lib.lbc_conv2d_wgrad_workspace(ctypes.byref(d)) // 4 + 1, device=self.dev)
         xh, dyh = nhwc(x).to(self.dev), nhwc(dy).to(self.dev)
         buf, dw = guarded((K, k, k, C), self.dev)
@@ -81,18 +89,20 @@ class Conv:
         check_guard(buf, dw.numel())
         return dw.permute(0, 3, 1, 2).contiguous().cpu()
 
-    def deconv_all(self, x, w, bias, pre, relu):
+    def deconv_all(self, x, w, bias, pre, relu, bf16=0):
         """fwd, dgrad and wgrad of ConvTranspose2d(k3,s2,p1,op1) with BN-on-load; returns (y, stats, fn(dy)->(dx, dw))"""
         N, C, H, W = x.shape
         K = w.shape[1]
-        d = self.desc(N, H, W, C, K, 3, 2, 1, relu)
+        d = self.desc(N, H, W, C, K, 3, 2, 1, relu, bf16)
+        dfwd = self.desc(N, H, W, C, K, 3, 2, 1, relu, bf16, 1 if bf16 else 0)
         xh, wh = nhwc(x).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        wfwd = self.transpose(wh.view(C, 9, K), C, 9, K) if bf16 else wh
         ps, pt, b = pre[0].to(self.dev), pre[1].to(self.dev), bias.to(self.dev)
         rows = ctypes.c_int(0)
-        _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(d), None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
+        _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(dfwd), None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
         st = torch.zeros((rows.value, 2, K), device=self.dev)
         buf, y = guarded((N, 2 * H, 2 * W, K), self.dev)
-        _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(wh), _lib.ptr(b), _lib.ptr(ps), _lib.ptr(pt), 0,
+        _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(dfwd), _lib.ptr(xh), _lib.ptr(wfwd), _lib.ptr(b), _lib.ptr(ps), _lib.ptr(pt), 0,
                                                 _lib.ptr(y), _lib.ptr(st), ctypes.byref(rows), _lib.stream_for(xh)))
         check_guard(buf, y.numel())
 
@@ -114,9 +124,9 @@ def relerr(a, b):
     return (a - b).abs().max().item() / (b.abs().max().item() + 1e-30)
 
 
-def engine_from_state_dict(sd, kind, backbone, H, W, max_batch, device):
+def engine_from_state_dict(sd, kind, backbone, H, W, max_batch, device, precision=0):
     from learningbycheating_amd.engine import PolicyEngine
-    eng = PolicyEngine(34 if backbone == "resnet34" else 18, 3 if kind == "image" else 7, H, W, kind == "image", max_batch, device)
+    eng = PolicyEngine(34 if backbone == "resnet34" else 18, 3 if kind == "image" else 7, H, W, kind == "image", max_batch, device, precision)
     tens = {k: (v.to(device).contiguous(memory_format=torch.channels_last) if v.dim() == 4 else v.clone().to(device))
             for k, v in sd.items() if k in set(eng.names)}
     eng.bind(tens, True)

@@ -138,3 +138,83 @@ def test_deconv_fwd_dgrad_wgrad(env, cfg):
     u.backward(dy)
     dx, dw = bwd(dy)
     assert relerr(dx, xn.grad) < 1e-5 and relerr(dw, w.grad) < 2e-5
+
+
+# ---- bf16-MFMA compute mode: operands rounded to bf16 (RNE) inside the kernel, f32 accumulation and storage --------
+def rbf(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+BF_SMALL = [(1, 8, 8, 64, 64, 3, 1, 1), (2, 5, 12, 64, 128, 3, 1, 1), (1, 10, 12, 128, 128, 3, 2, 1), (1, 8, 12, 64, 128, 1, 2, 0)]
+BF_REAL = [pytest.param(c, marks=gpu) for c in [(8, 40, 96, 64, 64, 3, 1, 1), (8, 20, 48, 128, 128, 3, 1, 1), (2, 20, 48, 128, 256, 3, 2, 1),
+                                                 (16, 5, 12, 512, 512, 3, 1, 1), (2, 10, 24, 256, 512, 1, 2, 0)]]
+
+
+@pytest.mark.parametrize("cfg", BF_SMALL + BF_REAL)
+def test_conv_fwd_bf16_mode(env, cfg):
+    """against an f32 convolution of the bf16-rounded operands (tight), and against the unrounded one (bf16-level)"""
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg, 20)
+    g = torch.Generator().manual_seed(21)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))      # BN+ReLU on load happens in f32, before the rounding
+    ref = F.conv2d(rbf(xin), rbf(w), None, s, p)
+    y, st = Conv(dev).fwd(x, w, s, p, pre=(ps, pt, True), stats=True, bf16=1)
+    assert relerr(y, ref) < 2e-5
+    assert relerr(y, F.conv2d(xin, w, None, s, p)) < 2e-2
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+
+
+@pytest.mark.parametrize("cfg", BF_SMALL + [(40, 5, 6, 64, 64, 3, 1, 1)] + BF_REAL)
+def test_conv_wgrad_bf16_mode(env, cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg, 22)
+    w = w.requires_grad_(True)
+    y = F.conv2d(rbf(x), w, None, s, p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(23))
+    y.backward(rbf(dy))
+    dw = Conv(dev).wgrad(x, dy, k, s, p, bf16=1)
+    assert relerr(dw, w.grad) < 5e-5
+
+
+@pytest.mark.parametrize("cfg", BF_SMALL[:3] + [pytest.param((4, 20, 48, 128, 128, 3, 1, 1), marks=gpu), pytest.param((2, 20, 48, 128, 256, 3, 2, 1), marks=gpu)])
+def test_conv_dgrad_bf16_mode_and_transposed_weights(env, cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    x, w = make(cfg, 24)
+    x.requires_grad_(True)
+    y = F.conv2d(x, rbf(w), None, s, p)
+    dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(25))
+    y.backward(rbf(dy))
+    dx = Conv(dev).dgrad(dy, w, H, W, s, p, bf16=1, transposed=True)
+    assert relerr(dx, x.grad) < 2e-5
+    # the transposed-weight route in exact f32 as well
+    x.grad = None
+    F.conv2d(x, w, None, s, p).backward(dy)
+    assert relerr(Conv(dev).dgrad(dy, w, H, W, s, p, bf16=0, transposed=True), x.grad) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 3, 4, 64, 64), (1, 5, 12, 128, 64)] + [pytest.param((4, 5, 12, 640, 256), marks=gpu), pytest.param((2, 20, 48, 128, 64), marks=gpu)])
+def test_deconv_bf16_mode(env, cfg):
+    dev, _ = env
+    N, H, W, C, K = cfg
+    g = torch.Generator().manual_seed(26)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = (torch.randn((C, K, 3, 3), generator=g) * (2.0 / (C * 2.25)) ** 0.5).requires_grad_(True)
+    b = torch.randn(K, generator=g)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xn = (x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)).requires_grad_(True)
+    wr = rbf(w.detach()).requires_grad_(True)
+    u = F.conv_transpose2d(rbf(xn), wr, b, 2, 1, 1)
+    ref = F.relu(u)
+    y, st, bwd = Conv(dev).deconv_all(x, w.detach(), b, (ps, pt), relu=1, bf16=1)
+    assert relerr(y, ref) < 2e-5
+    dy = torch.randn(u.shape, generator=g)
+    # reference backward with the executor's rounding points: dy rounded; dx = gather over rounded dy with rounded w;
+    # dw = rounded bn(x) x rounded dy
+    xr = rbf(xn.detach()).requires_grad_(True)
+    F.conv_transpose2d(xr, wr, None, 2, 1, 1).backward(rbf(dy))
+    dx, dw = bwd(dy)
+    assert relerr(dx, xr.grad) < 2e-5 and relerr(dw, wr.grad) < 5e-5
