@@ -22,6 +22,13 @@ if [[ "$PHASES" == *bench* ]]; then
   echo "bench exit $?" >> gpurun_out/summary.txt
   tail -2 gpurun_out/bench.log >> gpurun_out/summary.txt
 fi
+if [[ "$PHASES" == *small* ]]; then
+  # per-GPU load of the 8-GPU run (32 images / GPU) on one GPU: predicts strong-scaling efficiency
+  for dt in bf16 f32; do
+    timeout 600 python bench.py --dtype $dt --global-batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_b32_$dt.json > gpurun_out/bench_b32_$dt.log 2>&1
+    echo "bench b32 $dt: $(tail -1 gpurun_out/bench_b32_$dt.log | cut -c1-260)" >> gpurun_out/summary.txt
+  done
+fi
 if [[ "$PHASES" == *bf16* ]]; then
   timeout 900 python bench.py --dtype bf16 --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --breakdown gpurun_out/breakdown_bf16.json > gpurun_out/bench_bf16.log 2>&1
   echo "bench bf16 exit $?" >> gpurun_out/summary.txt

@@ -161,7 +161,9 @@ def test_conv_fwd_bf16_mode(env, cfg):
     xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))      # BN+ReLU on load happens in f32, before the rounding
     ref = F.conv2d(rbf(xin), rbf(w), None, s, p)
     y, st = Conv(dev).fwd(x, w, s, p, pre=(ps, pt, True), stats=True, bf16=1)
-    assert relerr(y, ref) < 2e-5
+    # not tighter: the on-load affine is an fma on the GPU and mul+add in torch, and a 1-ulp f32 difference that straddles
+    # a bf16 rounding boundary moves that operand by 2^-8 relative (measured 2e-5 .. 1.3e-4 on the layer shapes)
+    assert relerr(y, ref) < 5e-4
     assert relerr(y, F.conv2d(xin, w, None, s, p)) < 2e-2
     assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
 
@@ -176,7 +178,7 @@ def test_conv_wgrad_bf16_mode(env, cfg):
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(23))
     y.backward(rbf(dy))
     dw = Conv(dev).wgrad(x, dy, k, s, p, bf16=1)
-    assert relerr(dw, w.grad) < 5e-5
+    assert relerr(dw, w.grad) < 1e-4
 
 
 @pytest.mark.parametrize("cfg", BF_SMALL[:3] + [pytest.param((4, 20, 48, 128, 128, 3, 1, 1), marks=gpu), pytest.param((2, 20, 48, 128, 256, 3, 2, 1), marks=gpu)])
@@ -189,7 +191,7 @@ def test_conv_dgrad_bf16_mode_and_transposed_weights(env, cfg):
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(25))
     y.backward(rbf(dy))
     dx = Conv(dev).dgrad(dy, w, H, W, s, p, bf16=1, transposed=True)
-    assert relerr(dx, x.grad) < 2e-5
+    assert relerr(dx, x.grad) < 1e-4
     # the transposed-weight route in exact f32 as well
     x.grad = None
     F.conv2d(x, w, None, s, p).backward(dy)
@@ -210,11 +212,11 @@ def test_deconv_bf16_mode(env, cfg):
     u = F.conv_transpose2d(rbf(xn), wr, b, 2, 1, 1)
     ref = F.relu(u)
     y, st, bwd = Conv(dev).deconv_all(x, w.detach(), b, (ps, pt), relu=1, bf16=1)
-    assert relerr(y, ref) < 2e-5
+    assert relerr(y, ref) < 5e-4          # see test_conv_fwd_bf16_mode
     dy = torch.randn(u.shape, generator=g)
     # reference backward with the executor's rounding points: dy rounded; dx = gather over rounded dy with rounded w;
     # dw = rounded bn(x) x rounded dy
     xr = rbf(xn.detach()).requires_grad_(True)
     F.conv_transpose2d(xr, wr, None, 2, 1, 1).backward(rbf(dy))
     dx, dw = bwd(dy)
-    assert relerr(dx, xr.grad) < 2e-5 and relerr(dw, wr.grad) < 5e-5
+    assert relerr(dx, xr.grad) < 1e-4 and relerr(dw, wr.grad) < 5e-4
