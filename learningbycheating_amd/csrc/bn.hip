@@ -35,36 +35,43 @@ __global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict_
     out[(size_t)blockIdx.y * cols + c] = (float)((s0 + s1) + (s2 + s3));
 }
 
-// sums column c of a [rows][2][C] partial buffer with 4 loads in flight; fixed order
-__device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int rows, int C, int c, double& o1, double& o2)
+// Sums column c of a [rows][2][C] partial buffer.  The finalize kernels run 256 threads = 64 channels x 4 row-lanes: lane q
+// takes rows q, q+4, ... with two loads in flight, the four lanes are combined through LDS in a fixed order (deterministic).
+__device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int rows, int C, int c, bool valid, double& o1, double& o2)
 {
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
-    int r = 0;
-    for (; r + 3 < rows; r += 4) {
-        const float* p = partial + (size_t)r * 2 * C + c;
-        a0 += (double)p[0];             b0 += (double)p[C];
-        a1 += (double)p[2 * C];         b1 += (double)p[3 * C];
-        a2 += (double)p[4 * C];         b2 += (double)p[5 * C];
-        a3 += (double)p[6 * C];         b3 += (double)p[7 * C];
+    __shared__ double red[2][4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    if (valid) {
+        int r = q;
+        for (; r + 4 < rows; r += 8) {
+            const float* p = partial + (size_t)r * 2 * C + c;
+            a0 += (double)p[0];             b0 += (double)p[C];
+            a1 += (double)p[8 * C];         b1 += (double)p[9 * C];
+        }
+        for (; r < rows; r += 4) {
+            a0 += (double)partial[(size_t)r * 2 * C + c];
+            b0 += (double)partial[(size_t)r * 2 * C + C + c];
+        }
     }
-    for (; r < rows; ++r) {
-        a0 += (double)partial[(size_t)r * 2 * C + c];
-        b0 += (double)partial[(size_t)r * 2 * C + C + c];
-    }
-    o1 = (a0 + a1) + (a2 + a3);
-    o2 = (b0 + b1) + (b2 + b3);
+    red[0][q][cl] = a0 + a1;
+    red[1][q][cl] = b0 + b1;
+    __syncthreads();
+    o1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
+    o2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
 }
 
 // ---- forward finalize ----------------------------------------------------------
-__global__ __launch_bounds__(64) void bn_finalize_k(BnFinalizeArgs a)
+__global__ __launch_bounds__(256) void bn_finalize_k(BnFinalizeArgs a)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c == 0 && a.num_batches_tracked && a.train) *a.num_batches_tracked += 1;
-    if (c >= a.C) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const bool lead = threadIdx.x < 64;
+    if (c == 0 && lead && a.num_batches_tracked && a.train) *a.num_batches_tracked += 1;
+    double s1 = 0.0, s2 = 0.0;
+    if (a.train) sum_rows2(a.partial, a.rows, a.C, c, c < a.C, s1, s2);
+    if (c >= a.C || !lead) return;
     float mean, invstd;
     if (a.train) {
-        double s1, s2;
-        sum_rows2(a.partial, a.rows, a.C, c, s1, s2);
         const double n = (double)a.count;
         const double m = s1 / n;
         double var = s2 / n - m * m;
@@ -190,12 +197,12 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
 //   dx = A*(g - k1 - xhat*k2),  A = gamma*invstd, k1 = sum(g)/n, k2 = sum(g*xhat)/n,
 //   xhat recomputed per element as (x-mean)*invstd (factoring it into B*x + D would put a
 //   systematic per-channel rounding offset on dx that downstream channel sums amplify).
-__global__ __launch_bounds__(64) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
+__global__ __launch_bounds__(256) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
 {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= a.C) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     double s1, s2;
-    sum_rows2(a.partial, a.rows, a.C, c, s1, s2);
+    sum_rows2(a.partial, a.rows, a.C, c, c < a.C, s1, s2);
+    if (c >= a.C || threadIdx.x >= 64) return;
     if (a.dbeta) a.dbeta[c] = (float)s1;
     if (a.dgamma) a.dgamma[c] = (float)s2;
     if (a.coefA) {
@@ -287,7 +294,7 @@ int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C > 0 && a.scale && a.shift, "bn_finalize: bad args");
     LbcProfScope prof("bn_finalize", 0.0, 4.0 * (double)a.rows * 2 * a.C, s);
-    hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(256), 0, s, a);
     return lbc_check_launch("bn_finalize");
 }
 
@@ -302,9 +309,14 @@ int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)
 int lbc_chan_reduce_rows(long long pixels, int C)
 {
     const int rl = 256 / (C / 4);
-    // aim at >= 64 pixels per lane per block, at most 1024 blocks
+    // at most 1024 workgroups, at least 8 pixels per pixel-lane; small tensors still get >= ~512 workgroups when they can
     long long ppb = (long long)rl * 64;
     long long rows = (pixels + ppb - 1) / ppb;
+    if (rows < 512) {
+        ppb = (long long)rl * 8;
+        rows = (pixels + ppb - 1) / ppb;
+        if (rows > 512) rows = 512;
+    }
     if (rows > 1024) rows = 1024;
     if (rows < 1) rows = 1;
     return (int)rows;
@@ -325,7 +337,7 @@ int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
 int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s)
 {
     LbcProfScope prof("bn_bwd_finalize", 0.0, 4.0 * (double)a.rows * 2 * a.C, s);
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(64), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(256), 0, s, a);
     return lbc_check_launch("bn_bwd_finalize");
 }
 

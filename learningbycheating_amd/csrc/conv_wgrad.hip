@@ -387,7 +387,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict
     }
 }
 
-inline bool big_tile(const WgradArgs& a) { return a.CP % 128 == 0 && a.CQ % 128 == 0; }
+// 128x128 tiles when the channel counts allow and the reduction is long enough to amortise them; short reductions
+// (small batches, late layers) take 64x64 tiles: 4x the tiles, so far fewer split-K slabs to write and re-read.
+inline bool big_tile(const WgradArgs& a)
+{
+    return a.CP % 128 == 0 && a.CQ % 128 == 0 && (long long)a.N * a.OH * a.OW >= 16384;
+}
 
 }  // namespace
 
@@ -397,7 +402,7 @@ int lbc_wgrad_pick_split(const WgradArgs& a)
     const long long tiles = (long long)(a.CP / bp) * (a.CQ / bp) * a.KH * a.KW;
     const long long M = (long long)a.N * a.OH * a.OW;
     const long long chunks = (M + BR - 1) / BR;
-    long long ns = 1536 / tiles;
+    long long ns = (1024 + tiles - 1) / tiles;
     if (ns < 1) ns = 1;
     if (ns > 256) ns = 256;
     // keep at least 8 chunks (256 pixels) of reduction per split
