@@ -121,6 +121,11 @@ typedef struct lbc_camera { float w, h, fov, world_y, fixed_offset, pixels_per_m
 int lbc_loss(int kind, const lbc_camera* cam, const float* pred, const float* target, int N, int rows,
              float grad_scale, float* loss_per_sample, float* dpred, lbc_stream_t stream);
 
+/* Phase-2 (DAgger) resampling weight per sample: reference training/phase2_utils.py:50-59 (get_weight) on the selected
+ * branch, applied as in train_image_phase2.py:203-206.  pred_sel [N,5,2] camera space, teacher_sel [N,5,2] map space. */
+int lbc_phase2_weight(const lbc_camera* cam, const float* pred_sel, const float* teacher_sel, int N, float* weights,
+                      lbc_stream_t stream);
+
 /* Multi-tensor Adam (torch.optim.Adam semantics; reference training/train_image_phase1.py:252).
  * chunk table lives in device memory: see lbc_adam_chunk. */
 typedef struct lbc_adam_chunk { float* p; const float* g; float* m; float* v; int n; int pad; } lbc_adam_chunk;

@@ -53,6 +53,7 @@ _SIGNATURES = {
     "lbc_net_num_stages": (c_int, []),
     "lbc_net_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lbc_loss": (c_int, [c_int, ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "lbc_phase2_weight": (c_int, [ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "lbc_adam_step": (c_int, [c_void_p, c_int] + [ctypes.c_double] * 5 + [c_int, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)

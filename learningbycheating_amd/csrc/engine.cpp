@@ -700,6 +700,18 @@ int lbc_loss(int kind, const lbc_camera* cam, const float* pred, const float* ta
     return LBC_EINVAL;
 }
 
+int lbc_phase2_weight(const lbc_camera* cam, const float* pred_sel, const float* teacher_sel, int N, float* weights,
+                      lbc_stream_t stream)
+{
+    LBC_REQUIRE(cam && pred_sel && teacher_sel && weights, "phase2_weight: null argument");
+    LossArgs a;
+    memset(&a, 0, sizeof(a));
+    a.pred = pred_sel; a.target = teacher_sel; a.loss_per_sample = weights; a.N = N; a.R = 5;
+    a.w = cam->w; a.h = cam->h; a.fov = cam->fov; a.world_y = cam->world_y; a.fixed_offset = cam->fixed_offset;
+    a.pixels_per_meter = cam->pixels_per_meter; a.crop_size = cam->crop_size;
+    return lbc_phase2_weight_launch(a, (hipStream_t)stream);
+}
+
 int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int step, lbc_stream_t stream)
 {

@@ -167,6 +167,7 @@ struct LossArgs {
 int lbc_loss_phase1(const LossArgs& a, hipStream_t s);   // differentiable unprojection + L1 in map space
 int lbc_loss_phase0(const LossArgs& a, hipStream_t s);   // teacher map -> image projection (clip) + L1 in image space
 int lbc_loss_l1(const LossArgs& a, float target_scale, float target_shift, hipStream_t s);   // bird-view BC loss
+int lbc_phase2_weight_launch(const LossArgs& a, hipStream_t s);   // DAgger resampling weights (selected branch, map space)
 
 // ---- Adam (multi-tensor) ------------------------------------------------------------------
 struct AdamChunk { float* p; const float* g; float* m; float* v; int n; int pad; };

@@ -89,7 +89,48 @@ __global__ __launch_bounds__(64) void loss_k(LossArgs a, float t_scale, float t_
     }
 }
 
+// Phase-2 (DAgger) resampling weight of every sample, reference training/phase2_utils.py:50-59 (get_weight) applied as in
+// train_image_phase2.py:203-206: the student's SELECTED-branch camera-space prediction is unprojected to the map frame and
+// normalised (train_image_phase1-style CoordConverter + /(0.5*CROP_SIZE) - 1), then
+//   w[n] = mean_t( (0.7*|dx| + 0.3*|dy|) * 0.7^t )   over the 5 waypoints.
+__global__ __launch_bounds__(64) void phase2_weight_k(LossArgs a)
+{
+    __shared__ float red[8];
+    const int n = blockIdx.x, r = threadIdx.x;
+    float part = 0.f;
+    if (r < 5) {
+        const size_t o = ((size_t)n * 5 + r) * 2;
+        const float x = a.pred[o], y = a.pred[o + 1];
+        const float f = (float)((double)a.w / (2.0 * tan((double)a.fov * 3.14159265358979323846 / 360.0)));
+        const float cx = (x + 1.f) * a.w / 2.f, cy = (y + 1.f) * a.h / 2.f;
+        const float xt = (cx - a.w / 2.f) / f;
+        const float yt = (cy - a.h / 2.f) / f;
+        const float wz = a.world_y / yt;
+        const float wx = wz * xt;
+        float mx = wx * a.pixels_per_meter;
+        float my = wz * a.pixels_per_meter;
+        my = a.crop_size - my;
+        mx += a.crop_size / 2.f;
+        my += a.fixed_offset * a.pixels_per_meter;
+        const float half = 0.5f * a.crop_size;
+        const float px = mx / half - 1.f, py = my / half - 1.f;
+        float decay = 1.f;
+        for (int i = 0; i < r; ++i) decay *= 0.7f;
+        part = (fabsf(px - a.target[o]) * 0.7f + fabsf(py - a.target[o + 1]) * 0.3f) * decay;
+    }
+    if (r < 8) red[r] = part;
+    __syncthreads();
+    if (r == 0) a.loss_per_sample[n] = (red[0] + red[1] + red[2] + red[3] + red[4]) / 5.f;
+}
+
 }  // namespace
+
+int lbc_phase2_weight_launch(const LossArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.N > 0, "phase2_weight: bad shape");
+    hipLaunchKernelGGL(phase2_weight_k, dim3((unsigned)a.N), dim3(64), 0, s, a);
+    return lbc_check_launch("phase2_weight");
+}
 
 int lbc_loss_phase1(const LossArgs& a, hipStream_t s)
 {

@@ -53,6 +53,7 @@ class NativeTrainer:
         n = x.shape[0]
         if self.phase in (0, 1):
             t_sel, t_all = self.teng.forward(birdview, speed, command, False)
+            self.last_teacher = (t_sel, t_all)
         p_sel, p_all = self.eng.forward(x, speed, command, True)
         d_sel = d_all = None
         if self.phase == 1:

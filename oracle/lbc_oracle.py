@@ -310,6 +310,20 @@ def phase0_loss(pred_locations, image_locations, w=384, h=160):
     return torch.mean(torch.abs(pred_locations - loc), dim=(1, 2))
 
 
+def phase2_weight(pred_location_cam, teacher_location):
+    """resampling weight of train_image_phase2.py:203-206: get_weight (phase2_utils.py:50-59) on the selected-branch
+    prediction, unprojected to the map frame and normalised"""
+    learner = phase1_unproject(pred_location_cam) / (0.5 * CROP_SIZE) - 1.0
+    decay = torch.tensor([0.7 ** i for i in range(5)])
+    xy_bias = torch.tensor([0.7, 0.3])
+    return torch.mean((torch.abs(learner - teacher_location) * xy_bias).sum(dim=-1) * decay, dim=-1)
+
+
+def repeat(a, repeats, dim=0):
+    """np.repeat-style interleave used for --batch_aug (train_image_phase1.py:131-154): [1,2,3] -> [1,1,2,2,3,3]"""
+    return torch.repeat_interleave(a, repeats, dim=dim)
+
+
 def birdview_loss(pred_location, gt_location, size=192):
     """LocationLoss(choice='l1') of training/train_birdview.py:33-54 -> per-sample loss (N,)"""
     gt = gt_location / (0.5 * size) - 1.0

@@ -147,6 +147,20 @@ def main():
     assert torch.allclose(ref_l, o_l, rtol=1e-5, atol=1e-6) and torch.allclose(cam_r.grad, cam_o.grad, rtol=1e-4, atol=1e-6)
     out["phase1_loss"] = {"cam": cam, "teacher": teac, "map": ref_map.detach().clone(), "loss": ref_l.detach().clone(),
                           "dcam": cam_r.grad.clone()}
+    # ---- phase-2 resampling weight + batch_aug repeat vs the reference functions (training/phase2_utils.py) ----
+    import ast
+    src = open(ref_shim.REFERENCE_ROOT + "/training/phase2_utils.py").read()
+    ns = {"torch": torch}
+    for node in ast.parse(src).body:
+        if isinstance(node, ast.FunctionDef) and node.name in ("get_weight", "repeat"):
+            exec(compile(ast.Module([node], []), "phase2_utils.py", "exec"), ns)
+    pred_cam = cam[:, 0].clone()                       # (6,5,2) well-conditioned camera-space predictions
+    teac_sel = teac[:, 0].clone()
+    ref_w = ns["get_weight"](conv1(pred_cam) / (0.5 * 192) - 1.0, teac_sel)
+    assert torch.allclose(ref_w, O.phase2_weight(pred_cam, teac_sel), rtol=1e-5, atol=1e-7)
+    t = torch.arange(24.0).view(4, 3, 2)
+    assert torch.equal(ns["repeat"](t, 3), O.repeat(t, 3)) and torch.equal(ns["repeat"](t, 2, 1), O.repeat(t, 2, 1))
+    out["phase2_weight"] = {"pred_cam": pred_cam, "teacher": teac_sel, "weight": ref_w.clone()}
     torch.save(out, os.path.join(GOLD, "reference_outputs.pt"))
     with open(os.path.join(GOLD, "state_dict_layout.json"), "w") as f:
         json.dump(layouts, f)

@@ -247,6 +247,43 @@ def test_loss_kernels(env, size):
 
 
 @pytest.mark.parametrize("size", ["small", pytest.param("full", marks=gpu)])
+def test_phase2_weight_kernel(env, size):
+    """DAgger resampling weight (reference phase2_utils.py:50-59 as applied at train_image_phase2.py:203-206)"""
+    dev, _ = env
+    from learningbycheating_amd.training.native import camera_struct
+    gold = torch.load(os.path.join(GOLD, "reference_outputs.pt"))["phase2_weight"]
+    n = 6 if size == "small" else 128
+    g = torch.Generator().manual_seed(3)
+    cam = torch.rand((n, 5, 2), generator=g) * 1.6 - 0.8
+    cam[..., 1] = cam[..., 1].abs() * 0.8 + 0.15
+    teac = torch.rand((n, 5, 2), generator=g) * 2 - 1
+    cam[:6], teac[:6] = gold["pred_cam"], gold["teacher"]
+    cs = camera_struct()
+    w = torch.zeros(n, device=dev)
+    pc, tc = cam.to(dev), teac.to(dev)
+    _lib.check(_lib.get().lbc_phase2_weight(ctypes.byref(cs), _lib.ptr(pc), _lib.ptr(tc), n, _lib.ptr(w), _lib.stream_for(pc)))
+    assert torch.allclose(w.cpu(), O.phase2_weight(cam, teac), rtol=1e-5, atol=1e-7)
+    assert torch.allclose(w.cpu()[:6], gold["weight"], rtol=1e-5, atol=1e-7)       # the real reference's get_weight
+
+
+def test_replay_buffer_semantics():
+    from learningbycheating_amd.training.phase2_utils import ReplayBuffer, repeat
+    buf = ReplayBuffer(torch.device("cpu"), buffer_limit=6, seed=1)
+    g = torch.Generator().manual_seed(0)
+    buf.add_batch(torch.randint(0, 256, (8, 160, 384, 3), generator=g, dtype=torch.uint8), torch.zeros((8, 192, 192, 7), dtype=torch.uint8),
+                  torch.tensor([1, 2, 3, 4, 1, 2, 3, 4]), torch.arange(8.0), [5, 1, 7, 3, 0.5, 9, 2, 8])
+    assert len(buf) == 6 and sorted(buf._weights.tolist()) == [2, 3, 5, 7, 8, 9]         # lowest-loss samples evicted
+    buf.init_new_weights()
+    buf.update_weights([0, 5], torch.tensor([100.0, 200.0]))
+    buf.normalize_weights()
+    idx = buf.sample_indices(2000)
+    assert set(idx.tolist()) <= set(range(6)) and (idx == 5).mean() > 0.5 and (idx == 0).mean() > 0.2   # loss-weighted resampling
+    top, rgb, bv, cmd, speed = buf.get_highest_k(2)
+    assert set(top.tolist()) == {0, 5} and rgb.shape == (2, 3, 160, 384) and rgb.max() <= 1.0
+    assert torch.equal(repeat(torch.tensor([1, 2, 3]), 2), torch.tensor([1, 1, 2, 2, 3, 3]))
+
+
+@pytest.mark.parametrize("size", ["small", pytest.param("full", marks=gpu)])
 def test_fused_adam_matches_torch(env, size):
     dev, _ = env
     from learningbycheating_amd.optim import FusedAdam
@@ -316,6 +353,18 @@ def test_native_trainer_runs_and_is_deterministic(env):
         _, teac = teacher.eval()(bv.to(dev), speed.to(dev), onehot)
     want = O.phase1_loss(O.phase1_unproject(tr.last_pred[1].cpu()), teac.cpu())
     assert torch.allclose(loss, want, rtol=1e-4, atol=1e-5), (loss, want)
+    # phase-2 epoch on a tiny synthetic replay buffer: weights are written back, parameters move, nothing is NaN
+    from learningbycheating_amd.bird_view.utils import bz_utils as bzu
+    from learningbycheating_amd.training.train_image_phase2 import _train, synthetic_buffer
+    import tempfile
+    buf = synthetic_buffer(16, dev, seed=4)
+    before = student.deconv[1].weight.detach().clone()
+    with tempfile.TemporaryDirectory() as td:
+        bzu.log.init(td)
+        _train(buf, tr, {"device": dev, "batch_size": 4, "epoch_per_episode": 1, "speed_noise": 0.0, "log_iterations": 1,
+                         "log_dir": td, "rank": 0}, episode=99)
+    assert buf.normalized and (buf._weights != 1.0).any() and torch.isfinite(torch.as_tensor(buf._weights)).all()
+    assert not torch.equal(before, student.deconv[1].weight.detach())
 
 
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),

@@ -95,3 +95,10 @@ def test_known_answers():
     t[..., 1] = 1 - 2 * ((10 - 4.0) * 5) / 192.0
     uv = O.phase0_project(t)
     assert torch.allclose(uv[..., 0], torch.full((1, 5), 192.0)) and torch.allclose(uv[..., 1], torch.full((1, 5), 80 + 192 * 1.4 / 10))
+
+
+def test_phase2_weight_and_repeat_match_reference_fixture():
+    g = load_gold()["phase2_weight"]
+    assert torch.allclose(O.phase2_weight(g["pred_cam"], g["teacher"]), g["weight"], rtol=1e-5, atol=1e-7)
+    t = torch.arange(6.0).view(3, 2)
+    assert torch.equal(O.repeat(t, 2), torch.tensor([[0., 1.], [0., 1.], [2., 3.], [2., 3.], [4., 5.], [4., 5.]]))
