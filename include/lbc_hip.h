@@ -32,7 +32,9 @@ typedef struct lbc_conv_desc {
     int K;              /* output channels */
     int KH, KW, S, P;   /* filter size, stride, padding */
     int relu;           /* fuse ReLU into the epilogue */
-    int bf16;           /* 0: exact f32 MFMA.  1: MFMA operands rounded to bf16 (RNE), f32 accumulate; tensors stay f32 */
+    int bf16;           /* 0: exact f32 MFMA.  1: MFMA operands rounded to bf16 (RNE), f32 accumulate; tensors stay f32.
+                           2: as 1, and the activation tensors (x, y, resid, dy, dx: the `void*` arguments) are bf16 in
+                           HBM; weights, bias, statistics and weight gradients stay f32 */
     int w_transposed;   /* lbc_conv2d_dgrad / lbc_deconv3x3s2_fwd only: `w` is the lbc_weight_transpose()d copy (depth-
                            contiguous for these GEMMs).  Required when bf16 = 1. */
 } lbc_conv_desc;
@@ -42,9 +44,9 @@ typedef struct lbc_conv_desc {
  * pre_scale != NULL (the producing BatchNorm applied on load; zero padding stays zero).
  * stats (nullable): per-workgroup partial (sum, sum^2) of y per channel, [rows][2][K];
  * *stats_rows receives the number of rows written (query with stats == NULL allowed). */
-int lbc_conv2d_fwd(const lbc_conv_desc* d, const float* x, const float* w, const float* bias,
-                   const float* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
-                   float* y, float* stats, int* stats_rows, lbc_stream_t stream);
+int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
+                   const void* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
+                   void* y, float* stats, int* stats_rows, lbc_stream_t stream);
 
 /* w[A][T][B] -> wt[B][T][A] (fp32).  Conv2d weights [K][T][C] -> [C][T][K] for lbc_conv2d_dgrad, ConvTranspose2d weights
  * [C][T][K] -> [K][T][C] for lbc_deconv3x3s2_fwd, when lbc_conv_desc.w_transposed = 1. */
@@ -52,24 +54,24 @@ int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc
 
 /* Input gradient of nn.Conv2d (autograd of the call sites above; loss.backward() at
  * training/train_image_phase1.py:204).  dx[N,H,W,C] = dgrad(dy[N,OH,OW,K], w) (+resid). */
-int lbc_conv2d_dgrad(const lbc_conv_desc* d, const float* dy, const float* w, const float* resid,
-                     float* dx, lbc_stream_t stream);
+int lbc_conv2d_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, const void* resid,
+                     void* dx, lbc_stream_t stream);
 
 /* Weight gradient of nn.Conv2d.  dw[K][KH][KW][C] = beta*dw + sum_m dy[m][k] * x'[gather(m)][c].
  * workspace must hold lbc_conv2d_wgrad_workspace(d) bytes. */
 size_t lbc_conv2d_wgrad_workspace(const lbc_conv_desc* d);
-int lbc_conv2d_wgrad(const lbc_conv_desc* d, const float* x, const float* dy,
+int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                      const float* pre_scale, const float* pre_shift, int pre_relu,
                      float* dw, float beta, void* workspace, lbc_stream_t stream);
 
 /* nn.ConvTranspose2d(C,K,3,2,1,1) forward (reference bird_view/models/image.py:39,42,45;
  * birdview.py:37,40,43).  x[N,H,W,C] -> y[N,2H,2W,K]; d->KH=KW=3, S=2, P=1 required. */
-int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const float* x, const float* w, const float* bias,
+int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
                         const float* pre_scale, const float* pre_shift, int pre_relu,
-                        float* y, float* stats, int* stats_rows, lbc_stream_t stream);
-int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const float* dy, const float* w, float* dx, lbc_stream_t stream);
+                        void* y, float* stats, int* stats_rows, lbc_stream_t stream);
+int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, void* dx, lbc_stream_t stream);
 size_t lbc_deconv3x3s2_wgrad_workspace(const lbc_conv_desc* d);
-int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const float* x, const float* dy,
+int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                           const float* pre_scale, const float* pre_shift, int pre_relu,
                           float* dw, float beta, void* workspace, lbc_stream_t stream);
 
@@ -87,7 +89,9 @@ typedef struct lbc_net_desc {
     int normalize;     /* 1: (x-mean)/std with the ImageNet constants of image.py:32-35 */
     int max_batch;
     int precision;     /* 0: f32 everywhere (exact-f32 MFMA; the parity path).  1: convolution MFMA operands rounded to
-                          bf16 with f32 accumulation; tensors, BatchNorm, softmax, loss, Adam and the stem stay f32 */
+                          bf16 with f32 accumulation; tensors, BatchNorm, softmax, loss, Adam and the stem stay f32.
+                          2: as 1, and activations / activation gradients are stored as bf16 in the workspace (all
+                          arithmetic on them stays f32; parameters, gradients, statistics, outputs stay f32) */
 } lbc_net_desc;
 typedef struct lbc_net lbc_net;
 

@@ -12,6 +12,7 @@
 // producing convolution's epilogue (or by channel_stats below); they are reduced
 // here in double precision in a fixed order, so results are run-to-run identical.
 #include "lbc_common.hpp"
+#include "lbc_act.hpp"
 #include "lbc_kernels.hpp"
 
 namespace {
@@ -96,28 +97,35 @@ __global__ __launch_bounds__(256) void bn_finalize_k(BnFinalizeArgs a)
 }
 
 // ---- elementwise apply: y = relu?(x*s + t (+ r [* rs + rt])) ------------------
+template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
 {
+    const T* x = static_cast<const T*>(a.x);
+    const T* resid = static_cast<const T*>(a.resid);
+    T* y = static_cast<T*>(a.y);
     const int c4n = a.C / 4;
     const long long total4 = a.pixels * c4n;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
         const int c = (int)(i % c4n) * 4;
-        float4 v = reinterpret_cast<const float4*>(a.x)[i];
-        const float4 s = *reinterpret_cast<const float4*>(a.scale + c);
-        const float4 t = *reinterpret_cast<const float4*>(a.shift + c);
-        v.x = v.x * s.x + t.x; v.y = v.y * s.y + t.y; v.z = v.z * s.z + t.z; v.w = v.w * s.w + t.w;
-        if (a.resid) {
-            float4 r = reinterpret_cast<const float4*>(a.resid)[i];
+        f32x4 v = Act<T>::ld4(x + i * 4);
+        const f32x4 s = *reinterpret_cast<const f32x4*>(a.scale + c);
+        const f32x4 t = *reinterpret_cast<const f32x4*>(a.shift + c);
+        v = v * s + t;
+        if (resid) {
+            f32x4 r = Act<T>::ld4(resid + i * 4);
             if (a.rscale) {
-                const float4 rs = *reinterpret_cast<const float4*>(a.rscale + c);
-                const float4 rt = *reinterpret_cast<const float4*>(a.rshift + c);
-                r.x = r.x * rs.x + rt.x; r.y = r.y * rs.y + rt.y; r.z = r.z * rs.z + rt.z; r.w = r.w * rs.w + rt.w;
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(a.rscale + c);
+                const f32x4 rt = *reinterpret_cast<const f32x4*>(a.rshift + c);
+                r = r * rs + rt;
             }
-            v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            v += r;
         }
-        if (a.relu) { v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f); }
-        reinterpret_cast<float4*>(a.y)[i] = v;
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        Act<T>::st4(y + i * 4, v);
     }
 }
 
@@ -125,71 +133,69 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
 // Block layout: 256 threads = (C/4 channel groups) x RL pixel lanes (RL = 256/(C/4),
 // C/4 <= 256).  Each block owns a contiguous pixel range and writes one partial row
 // [2][C]:  row0 = sum g, row1 = sum g*q  where the meaning of g, q depends on the op.
-template <int OP>
+template <int OP, typename T>
 __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
 {
     __shared__ __attribute__((aligned(16))) float red[2 * 256 * 4];
+    const T* xx = static_cast<const T*>(a.x);
+    const T* dz = static_cast<const T*>(a.dz);
+    const T* mask = static_cast<const T*>(a.mask);
+    T* g_out = static_cast<T*>(a.g_out);
     const int c4n = a.C / 4;
     const int rl = 256 / c4n;
     const int cg = threadIdx.x % c4n;
     const int pl = threadIdx.x / c4n;
     const int c = cg * 4;
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (pl < rl) {
-        float4 mean = make_float4(0.f, 0.f, 0.f, 0.f), inv = make_float4(1.f, 1.f, 1.f, 1.f);
-        float4 msc = make_float4(1.f, 1.f, 1.f, 1.f), msh = make_float4(0.f, 0.f, 0.f, 0.f);
+        f32x4 mean = {0.f, 0.f, 0.f, 0.f}, inv = {1.f, 1.f, 1.f, 1.f};
+        f32x4 msc = {1.f, 1.f, 1.f, 1.f}, msh = {0.f, 0.f, 0.f, 0.f};
         if (OP == 1 && a.mean) {
-            mean = *reinterpret_cast<const float4*>(a.mean + c);
-            inv = *reinterpret_cast<const float4*>(a.invstd + c);
+            mean = *reinterpret_cast<const f32x4*>(a.mean + c);
+            inv = *reinterpret_cast<const f32x4*>(a.invstd + c);
         }
         if (OP == 1 && a.mask_scale) {
-            msc = *reinterpret_cast<const float4*>(a.mask_scale + c);
-            msh = *reinterpret_cast<const float4*>(a.mask_shift + c);
+            msc = *reinterpret_cast<const f32x4*>(a.mask_scale + c);
+            msh = *reinterpret_cast<const f32x4*>(a.mask_shift + c);
         }
         const long long p0 = (long long)blockIdx.x * a.pix_per_block;
         long long p1 = p0 + a.pix_per_block;
         if (p1 > a.pixels) p1 = a.pixels;
         for (long long p = p0 + pl; p < p1; p += rl) {
-            const long long i = p * c4n + cg;
+            const long long i = (p * c4n + cg) * 4;
             if (OP == 0) {            // plain statistics of x: sum x, sum x^2
-                const float4 v = reinterpret_cast<const float4*>(a.x)[i];
-                s1.x += v.x; s1.y += v.y; s1.z += v.z; s1.w += v.w;
-                s2.x += v.x * v.x; s2.y += v.y * v.y; s2.z += v.z * v.z; s2.w += v.w * v.w;
+                const f32x4 v = Act<T>::ld4(xx + i);
+                s1 += v;
+                s2 += v * v;
             } else {                  // backward: g = dz * (mask > 0); sum g, sum g * xhat
-                float4 g = reinterpret_cast<const float4*>(a.dz)[i];
-                if (a.mask) {
-                    float4 m = reinterpret_cast<const float4*>(a.mask)[i];
-                    if (a.mask_scale) {
-                        m.x = m.x * msc.x + msh.x; m.y = m.y * msc.y + msh.y;
-                        m.z = m.z * msc.z + msh.z; m.w = m.w * msc.w + msh.w;
-                    }
-                    g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
-                    g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+                f32x4 g = Act<T>::ld4(dz + i);
+                if (mask) {
+                    f32x4 m = Act<T>::ld4(mask + i);
+                    if (a.mask_scale) m = m * msc + msh;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
                 }
-                if (a.g_out) reinterpret_cast<float4*>(a.g_out)[i] = g;
-                s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-                if (a.x) {
-                    const float4 v = reinterpret_cast<const float4*>(a.x)[i];
-                    s2.x += g.x * (v.x - mean.x) * inv.x; s2.y += g.y * (v.y - mean.y) * inv.y;
-                    s2.z += g.z * (v.z - mean.z) * inv.z; s2.w += g.w * (v.w - mean.w) * inv.w;
+                if (g_out) Act<T>::st4(g_out + i, g);
+                s1 += g;
+                if (xx) {
+                    const f32x4 v = Act<T>::ld4(xx + i);
+                    s2 += g * (v - mean) * inv;
                 }
             }
         }
     }
-    reinterpret_cast<float4*>(red)[threadIdx.x] = s1;
-    reinterpret_cast<float4*>(red)[256 + threadIdx.x] = s2;
+    reinterpret_cast<f32x4*>(red)[threadIdx.x] = s1;
+    reinterpret_cast<f32x4*>(red)[256 + threadIdx.x] = s2;
     __syncthreads();
     if (threadIdx.x < c4n) {
-        float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
         for (int k = 0; k < rl; ++k) {
-            const float4 u = reinterpret_cast<const float4*>(red)[k * c4n + threadIdx.x];
-            const float4 w = reinterpret_cast<const float4*>(red)[256 + k * c4n + threadIdx.x];
-            t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
-            t2.x += w.x; t2.y += w.y; t2.z += w.z; t2.w += w.w;
+            t1 += reinterpret_cast<const f32x4*>(red)[k * c4n + threadIdx.x];
+            t2 += reinterpret_cast<const f32x4*>(red)[256 + k * c4n + threadIdx.x];
         }
         float* dst = a.partial + (size_t)blockIdx.x * 2 * a.C;
-        *reinterpret_cast<float4*>(dst + c) = t1;
-        *reinterpret_cast<float4*>(dst + a.C + c) = t2;
+        *reinterpret_cast<f32x4*>(dst + c) = t1;
+        *reinterpret_cast<f32x4*>(dst + a.C + c) = t2;
     }
 }
 
@@ -219,8 +225,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
 }
 
 // ---- backward apply: dx = A*(g - k1 - xhat*k2) over the first Cout channels --------
+template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdApplyArgs a)
 {
+    const T* gp = static_cast<const T*>(a.g);
+    const T* mask = static_cast<const T*>(a.mask);
+    const T* xx = static_cast<const T*>(a.x);
+    T* dx = static_cast<T*>(a.dx);
     const int c4n = a.C / 4;
     const int o4n = a.Cout / 4;
     const long long total4 = a.pixels * o4n;
@@ -229,35 +240,33 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdApplyArgs a)
         const long long p = i / o4n;
         const int cg = (int)(i - p * o4n);
         const int c = cg * 4;
-        const long long j = p * c4n + cg;
-        float4 g = reinterpret_cast<const float4*>(a.g)[j];
-        if (a.mask) {
-            const float4 m = reinterpret_cast<const float4*>(a.mask)[j];
-            g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
-            g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+        const long long j = (p * c4n + cg) * 4;
+        f32x4 g = Act<T>::ld4(gp + j);
+        if (mask) {
+            const f32x4 m = Act<T>::ld4(mask + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
         }
-        const float4 v = reinterpret_cast<const float4*>(a.x)[j];
-        const float4 A = *reinterpret_cast<const float4*>(a.coefA + c);
-        const float4 K1 = *reinterpret_cast<const float4*>(a.coefB + c);
-        const float4 K2 = *reinterpret_cast<const float4*>(a.coefD + c);
-        const float4 mu = *reinterpret_cast<const float4*>(a.mean + c);
-        const float4 iv = *reinterpret_cast<const float4*>(a.invstd + c);
-        float4 o;
-        o.x = A.x * (g.x - K1.x - (v.x - mu.x) * iv.x * K2.x); o.y = A.y * (g.y - K1.y - (v.y - mu.y) * iv.y * K2.y);
-        o.z = A.z * (g.z - K1.z - (v.z - mu.z) * iv.z * K2.z); o.w = A.w * (g.w - K1.w - (v.w - mu.w) * iv.w * K2.w);
-        if (a.accum) {
-            const float4 q = reinterpret_cast<const float4*>(a.dx)[i];
-            o.x += q.x; o.y += q.y; o.z += q.z; o.w += q.w;
-        }
-        reinterpret_cast<float4*>(a.dx)[i] = o;
+        const f32x4 v = Act<T>::ld4(xx + j);
+        const f32x4 A = *reinterpret_cast<const f32x4*>(a.coefA + c);
+        const f32x4 K1 = *reinterpret_cast<const f32x4*>(a.coefB + c);
+        const f32x4 K2 = *reinterpret_cast<const f32x4*>(a.coefD + c);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c);
+        const f32x4 iv = *reinterpret_cast<const f32x4*>(a.invstd + c);
+        f32x4 o = A * (g - K1 - (v - mu) * iv * K2);
+        if (a.accum) o += Act<T>::ld4(dx + i * 4);
+        Act<T>::st4(dx + i * 4, o);
     }
 }
 
 // ---- velocity late fusion: h = cat(trunk, speed broadcast to 128 channels) --------
 // reference bird_view/models/image.py:77-79 / birdview.py:67-69
-__global__ __launch_bounds__(256) void concat_velocity_k(const float* __restrict__ t, const float* __restrict__ vel,
-                                                         float* __restrict__ h, long long pixels, int hw, int Ct, int Cv)
+template <typename T>
+__global__ __launch_bounds__(256) void concat_velocity_k(const void* tv, const float* __restrict__ vel, void* hv, long long pixels,
+                                                         int hw, int Ct, int Cv)
 {
+    const T* t = static_cast<const T*>(tv);
+    T* h = static_cast<T*>(hv);
     const int C = Ct + Cv;
     const int c4n = C / 4;
     const long long total4 = pixels * c4n;
@@ -265,10 +274,10 @@ __global__ __launch_bounds__(256) void concat_velocity_k(const float* __restrict
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
         const long long p = i / c4n;
         const int c = (int)(i - p * c4n) * 4;
-        float4 v;
-        if (c < Ct) v = *reinterpret_cast<const float4*>(t + p * Ct + c);
-        else { const float s = vel[p / hw]; v = make_float4(s, s, s, s); }
-        reinterpret_cast<float4*>(h)[i] = v;
+        f32x4 v;
+        if (c < Ct) v = Act<T>::ld4(t + p * Ct + c);
+        else { const float s = vel[p / hw]; v = f32x4{s, s, s, s}; }
+        Act<T>::st4(h + i * 4, v);
     }
 }
 
@@ -301,8 +310,10 @@ int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s)
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 4 == 0 && a.pixels > 0, "bn_apply: bad shape");
-    LbcProfScope prof("bn_apply", 0.0, 4.0 * (double)a.pixels * a.C * (a.resid ? 3 : 2), s);
-    hipLaunchKernelGGL(bn_apply_k, dim3((unsigned)grid_for(a.pixels * (a.C / 4))), dim3(256), 0, s, a);
+    LbcProfScope prof("bn_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * a.C * (a.resid ? 3 : 2), s);
+#define LBC_K(T, g) hipLaunchKernelGGL((bn_apply_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.C / 4)));
+#undef LBC_K
     return lbc_check_launch("bn_apply");
 }
 
@@ -328,9 +339,11 @@ int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
     const int rows = lbc_chan_reduce_rows(a.pixels, a.C);
     a.pix_per_block = (a.pixels + rows - 1) / rows;
     LbcProfScope prof(op == 0 ? "channel_stats" : "bn_bwd_reduce", 0.0,
-                      4.0 * (double)a.pixels * a.C * (op == 0 ? 1 : (1 + (a.mask ? 1 : 0) + (a.x ? 1 : 0) + (a.g_out ? 1 : 0))), s);
-    if (op == 0) hipLaunchKernelGGL((channel_reduce_k<0>), dim3((unsigned)rows), dim3(256), 0, s, a);
-    else         hipLaunchKernelGGL((channel_reduce_k<1>), dim3((unsigned)rows), dim3(256), 0, s, a);
+                      (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * a.C * (op == 0 ? 1 : (1 + (a.mask ? 1 : 0) + (a.x ? 1 : 0) + (a.g_out ? 1 : 0))), s);
+#define LBC_K(T, OPV) hipLaunchKernelGGL((channel_reduce_k<OPV, T>), dim3((unsigned)rows), dim3(256), 0, s, a)
+    if (op == 0) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 0);
+    else         LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 1);
+#undef LBC_K
     return lbc_check_launch("channel_reduce");
 }
 
@@ -344,17 +357,20 @@ int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s)
 int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 4 == 0 && a.Cout % 4 == 0 && a.Cout <= a.C, "bn_bwd_apply: bad channels");
-    LbcProfScope prof("bn_bwd_apply", 0.0, 4.0 * (double)a.pixels * (a.C * (a.mask ? 3.0 : 2.0) + a.Cout * (a.accum ? 2.0 : 1.0)), s);
-    hipLaunchKernelGGL(bn_bwd_apply_k, dim3((unsigned)grid_for(a.pixels * (a.Cout / 4))), dim3(256), 0, s, a);
+    LbcProfScope prof("bn_bwd_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * (a.C * (a.mask ? 3.0 : 2.0) + a.Cout * (a.accum ? 2.0 : 1.0)), s);
+#define LBC_K(T, g) hipLaunchKernelGGL((bn_bwd_apply_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.Cout / 4)));
+#undef LBC_K
     return lbc_check_launch("bn_bwd_apply");
 }
 
-int lbc_concat_velocity(const float* t, const float* vel, float* h, int N, int hw, int Ct, int Cv, hipStream_t s)
+int lbc_concat_velocity(const void* t, const float* vel, void* h, int N, int hw, int Ct, int Cv, int act_bf16, hipStream_t s)
 {
     LBC_REQUIRE(Ct % 4 == 0 && Cv % 4 == 0, "concat_velocity: channels must be multiples of 4");
     const long long pixels = (long long)N * hw;
-    LbcProfScope prof("concat_velocity", 0.0, 4.0 * (double)pixels * (Ct + Ct + Cv), s);
-    hipLaunchKernelGGL(concat_velocity_k, dim3((unsigned)grid_for(pixels * ((Ct + Cv) / 4))), dim3(256), 0, s, t, vel, h,
-                       pixels, hw, Ct, Cv);
+    LbcProfScope prof("concat_velocity", 0.0, (act_bf16 ? 2.0 : 4.0) * (double)pixels * (Ct + Ct + Cv), s);
+#define LBC_K(T, g) hipLaunchKernelGGL((concat_velocity_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, t, vel, h, pixels, hw, Ct, Cv)
+    LBC_DISPATCH_ACT(act_bf16, LBC_K, grid_for(pixels * ((Ct + Cv) / 4)));
+#undef LBC_K
     return lbc_check_launch("concat_velocity");
 }

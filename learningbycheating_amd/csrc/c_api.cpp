@@ -22,13 +22,13 @@ static IgemmArgs conv_args(const lbc_conv_desc* d)
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K;
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
     a.relu = d->relu;
-    a.bf16 = d->bf16;
+    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
     return a;
 }
 
-int lbc_conv2d_fwd(const lbc_conv_desc* d, const float* x, const float* w, const float* bias,
-                   const float* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
-                   float* y, float* stats, int* stats_rows, lbc_stream_t stream)
+int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
+                   const void* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
+                   void* y, float* stats, int* stats_rows, lbc_stream_t stream)
 {
     LBC_REQUIRE(d, "conv2d_fwd: null desc");
     IgemmArgs a = conv_args(d);
@@ -45,15 +45,15 @@ int lbc_conv2d_fwd(const lbc_conv_desc* d, const float* x, const float* w, const
 }
 
 // dgrad of a Conv2d with geometry d: gathered tensor = dy [N,OH,OW,K], output = dx [N,H,W,C]
-static int conv_dgrad_impl(const lbc_conv_desc* d, const float* dy, const float* w, int wmajor, const float* resid,
+static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const float* w, int wmajor, const void* resid,
                            const float* bias, const float* pre_scale, const float* pre_shift, int pre_relu,
-                           int relu, float* dx, float* stats, int* stats_rows, hipStream_t s)
+                           int relu, void* dx, float* stats, int* stats_rows, hipStream_t s)
 {
     const int OH = (d->H + 2 * d->P - d->KH) / d->S + 1;
     const int OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu; a.bf16 = d->bf16;
+    a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu; a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
     a.N = d->N; a.H = OH; a.W = OW; a.C = d->K;
     a.OH = d->H; a.OW = d->W; a.K = d->C;
@@ -92,8 +92,8 @@ int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc
     return lbc_weight_transpose(w, wt, A, T, B, (hipStream_t)stream);
 }
 
-int lbc_conv2d_dgrad(const lbc_conv_desc* d, const float* dy, const float* w, const float* resid,
-                     float* dx, lbc_stream_t stream)
+int lbc_conv2d_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, const void* resid,
+                     void* dx, lbc_stream_t stream)
 {
     LBC_REQUIRE(d, "conv2d_dgrad: null desc");
     LBC_REQUIRE(!d->bf16 || d->w_transposed, "conv2d_dgrad: bf16 needs w_transposed = 1 (see lbc_weight_transpose_f32)");
@@ -113,9 +113,9 @@ static lbc_conv_desc deconv_as_conv(const lbc_conv_desc* d)
     return c;
 }
 
-int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const float* x, const float* w, const float* bias,
+int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
                         const float* pre_scale, const float* pre_shift, int pre_relu,
-                        float* y, float* stats, int* stats_rows, lbc_stream_t stream)
+                        void* y, float* stats, int* stats_rows, lbc_stream_t stream)
 {
     LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_fwd: geometry must be k3 s2 p1 op1");
     LBC_REQUIRE(!d->bf16 || d->w_transposed, "deconv3x3s2_fwd: bf16 needs w_transposed = 1 (see lbc_weight_transpose_f32)");
@@ -124,7 +124,7 @@ int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const float* x, const float* w, 
                            stats_rows, (hipStream_t)stream);
 }
 
-int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const float* dy, const float* w, float* dx, lbc_stream_t stream)
+int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, void* dx, lbc_stream_t stream)
 {
     LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_dgrad: geometry must be k3 s2 p1 op1");
     lbc_conv_desc c = deconv_as_conv(d);
@@ -144,7 +144,7 @@ static WgradArgs conv_wgrad_args(const lbc_conv_desc* d)
     a.CP = d->K;
     a.H = d->H; a.W = d->W; a.CQ = d->C;
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
-    a.bf16 = d->bf16;
+    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
     a.nsplit = lbc_wgrad_pick_split(a);
     return a;
 }
@@ -156,7 +156,7 @@ size_t lbc_conv2d_wgrad_workspace(const lbc_conv_desc* d)
     return (size_t)a.nsplit * (size_t)a.CP * (size_t)(a.KH * a.KW) * (size_t)a.CQ * sizeof(float);
 }
 
-int lbc_conv2d_wgrad(const lbc_conv_desc* d, const float* x, const float* dy,
+int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                      const float* pre_scale, const float* pre_shift, int pre_relu,
                      float* dw, float beta, void* workspace, lbc_stream_t stream)
 {
@@ -178,7 +178,7 @@ static WgradArgs deconv_wgrad_args(const lbc_conv_desc* d)
     a.N = d->N; a.OH = d->H; a.OW = d->W; a.CP = d->C;
     a.H = 2 * d->H; a.W = 2 * d->W; a.CQ = d->K;
     a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
-    a.bf16 = d->bf16;
+    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
     a.nsplit = lbc_wgrad_pick_split(a);
     return a;
 }
@@ -190,7 +190,7 @@ size_t lbc_deconv3x3s2_wgrad_workspace(const lbc_conv_desc* d)
     return (size_t)a.nsplit * (size_t)a.CP * 9 * (size_t)a.CQ * sizeof(float);
 }
 
-int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const float* x, const float* dy,
+int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                           const float* pre_scale, const float* pre_shift, int pre_relu,
                           float* dw, float beta, void* workspace, lbc_stream_t stream)
 {

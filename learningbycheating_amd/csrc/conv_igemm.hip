@@ -17,21 +17,24 @@
 // contracts the channel pair {i, 4+i} of each 8-channel group -- A and B use the
 // same pairing, so the sum over depth is complete.
 #include "lbc_common.hpp"
+#include "lbc_act.hpp"
 #include <type_traits>
 
 namespace {
-
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 // BF16 = false: exact-f32 MFMA (32x32x2), 32-channel chunks, float LDS tiles.
 // BF16 = true : operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) when the tile is written to LDS and multiplied on
 //               v_mfma_f32_32x32x16_bf16 with f32 accumulation; activations, weights, statistics and everything outside the
 //               MFMA stay f32 in HBM.  64-channel chunks, bf16 LDS tiles ([row][k] only: weights must be depth-contiguous).
-template <int BM, int BN, bool WMAJOR, int MODE, bool BF16>
+// AT = element type of the activation tensors x / y / resid in HBM (float, or __bf16 with BF16 = true): bf16 activations
+// are loaded 8 channels per 16-byte load and go to LDS without conversion unless a BatchNorm-on-load prologue is set.
+template <int BM, int BN, bool WMAJOR, int MODE, bool BF16, typename AT>
 __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
 {
     static_assert(!BF16 || WMAJOR, "the bf16 path needs depth-contiguous weights");
+    static_assert(!Act<AT>::kBf16 || BF16, "bf16 activations need the bf16 MFMA path");
+    constexpr bool ABF = Act<AT>::kBf16;
+    using areg_t = typename std::conditional<ABF, bf16x8, f32x4>::type;   // one 16-byte activation load
     using lds_t = typename std::conditional<BF16, __bf16, float>::type;
     constexpr int BK = BF16 ? 64 : 32;      // channels per depth chunk
     constexpr int LDK = BK + (BF16 ? 8 : 4);   // padded LDS row (elements): 144-byte rows either way -> conflict-free b128 reads
@@ -40,7 +43,10 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
     constexpr int WM = 2, WN = 2;
     constexpr int MT = BM / WM / 32;
     constexpr int NT = BN / WN / 32;
-    constexpr int RA = BM / RPP;            // A float4 loads per thread per chunk
+    constexpr int ASEGS = ABF ? BK / 8 : BK / 4;   // 16-byte segments per A tile row
+    constexpr int ARPP = 256 / ASEGS;
+    constexpr int AEL = ABF ? 8 : 4;        // elements per A load
+    constexpr int RA = BM / ARPP;           // A 16-byte loads per thread per chunk
     constexpr int RB = WMAJOR ? BN / RPP : BK * BN / 4 / 256;
     constexpr int LDN = BN + 4;             // padded LDS row for [k][n] tiles (f32 only)
     constexpr int SB = WMAJOR ? BN * LDK : BK * LDN;
@@ -83,13 +89,16 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
     }
 
     // ---- per-thread A row descriptors -------------------------------------
-    const int seg = tid % SEGS;
+    const int seg = tid % SEGS;        // weight-tile staging role
     const int arow = tid / SEGS;
+    const int aseg = tid % ASEGS;      // activation-tile staging role
+    const int aarow = tid / ASEGS;
+    const AT* xin = static_cast<const AT*>(a.x);
     int pixbase[RA];
     int ay[RA], ax[RA];
 #pragma unroll
     for (int j = 0; j < RA; ++j) {
-        const int m = m0 + arow + RPP * j;
+        const int m = m0 + aarow + ARPP * j;
         if (m < a.M) {
             const int lhw = a.LH * a.LW;
             const int n = m / lhw;
@@ -118,9 +127,12 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[RA], rb[RB];   // native vector values (HIP's float4 struct would be copied through a scratch alloca)
+    areg_t ra[RA];          // native vector values (HIP's float4 struct would be copied through a scratch alloca)
+    f32x4 rb[RB];
     bool aok[RA];
-    f32x4 lps = {1.f, 1.f, 1.f, 1.f}, lpt = {0.f, 0.f, 0.f, 0.f};
+    f32x4 lps[AEL / 4], lpt[AEL / 4];
+#pragma unroll
+    for (int q = 0; q < AEL / 4; ++q) { lps[q] = f32x4{1.f, 1.f, 1.f, 1.f}; lpt[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float relu_floor = (a.pre_scale && a.pre_relu) ? 0.f : -INFINITY;
 
     // Software pipeline, written out once (no lambdas: the staging arrays must stay in registers):
@@ -143,8 +155,11 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             const int tap = sTap[ti];
             const int r = tap / a.KW, s = tap - r * a.KW;
             if (a.pre_scale) {
-                lps = *reinterpret_cast<const f32x4*>(a.pre_scale + c0 + seg * 4);
-                lpt = *reinterpret_cast<const f32x4*>(a.pre_shift + c0 + seg * 4);
+#pragma unroll
+                for (int q = 0; q < AEL / 4; ++q) {
+                    lps[q] = *reinterpret_cast<const f32x4*>(a.pre_scale + c0 + aseg * AEL + q * 4);
+                    lpt[q] = *reinterpret_cast<const f32x4*>(a.pre_shift + c0 + aseg * AEL + q * 4);
+                }
             }
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
@@ -155,7 +170,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
                 const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int pix = ok ? (pixbase[j] + iy * a.W + ix) : 0;
                 aok[j] = ok;
-                ra[j] = *reinterpret_cast<const f32x4*>(a.x + ((size_t)pix * (size_t)a.C + (size_t)(c0 + seg * 4)));
+                ra[j] = *reinterpret_cast<const areg_t*>(xin + ((size_t)pix * (size_t)a.C + (size_t)(c0 + aseg * AEL)));
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
@@ -220,13 +235,24 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             const int buf = (it + 1) & 1;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
-                f32x4 v = ra[j] * lps + lpt;
+                lds_t* dst = &sA[buf][(aarow + ARPP * j) * LDK + aseg * AEL];
+                if constexpr (ABF) {
+                    bf16x8 h = ra[j];
+                    if (a.pre_scale) {      // BatchNorm(+ReLU) on load: unpack, f32 affine, repack
+                        f32x8 v = __builtin_convertvector(h, f32x8);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = aok[j] ? fmaxf(v[e], relu_floor) : 0.f;
-                if constexpr (BF16)
-                    *reinterpret_cast<bf16x4*>(&sA[buf][(arow + RPP * j) * LDK + seg * 4]) = __builtin_convertvector(v, bf16x4);
-                else
-                    *reinterpret_cast<f32x4*>(&sA[buf][(arow + RPP * j) * LDK + seg * 4]) = v;
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * lps[e >> 2][e & 3] + lpt[e >> 2][e & 3], relu_floor);
+                        h = __builtin_convertvector(v, bf16x8);
+                    }
+                    if (!aok[j]) h = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    *reinterpret_cast<bf16x8*>(dst) = h;
+                } else {
+                    f32x4 v = ra[j] * lps[0] + lpt[0];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = aok[j] ? fmaxf(v[e], relu_floor) : 0.f;
+                    if constexpr (BF16) *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(v, bf16x4);
+                    else                *reinterpret_cast<f32x4*>(dst) = v;
+                }
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
@@ -275,9 +301,9 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
                     const int col = n0 + (wn * NT + nj) * 32 + l31;
                     float v = acc[mi][nj][r];
                     if (a.bias) v += a.bias[col];
-                    if (a.resid) v += a.resid[obase + col];
+                    if (a.resid) v += Act<AT>::ld1(static_cast<const AT*>(a.resid) + obase + col);
                     if (a.relu) v = fmaxf(v, 0.f);
-                    a.y[obase + col] = v;
+                    Act<AT>::st1(static_cast<AT*>(a.y) + obase + col, v);
                     s1[nj] += v;
                     s2[nj] += v * v;
                 }
@@ -336,13 +362,16 @@ template <int BM, int BN>
 int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
     dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN)));
-    if (a.bf16) {
-        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true>), grid, dim3(256), 0, s, a);
-        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true>), grid, dim3(256), 0, s, a);
-    } else if (wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, false>), grid, dim3(256), 0, s, a);
-    else if (wmajor && mode == 1)   hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, false>), grid, dim3(256), 0, s, a);
-    else if (!wmajor && mode == 0)  hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 0, false>), grid, dim3(256), 0, s, a);
-    else                            hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 1, false>), grid, dim3(256), 0, s, a);
+    if (a.act_bf16) {
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16>), grid, dim3(256), 0, s, a);
+    } else if (a.bf16) {
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, float>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, float>), grid, dim3(256), 0, s, a);
+    } else if (wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, false, float>), grid, dim3(256), 0, s, a);
+    else if (wmajor && mode == 1)   hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, false, float>), grid, dim3(256), 0, s, a);
+    else if (!wmajor && mode == 0)  hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 0, false, float>), grid, dim3(256), 0, s, a);
+    else                            hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 1, false, float>), grid, dim3(256), 0, s, a);
     return lbc_check_launch("conv_igemm");
 }
 
@@ -374,6 +403,7 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     LBC_REQUIRE(cfg >= 0 && cfg < 3, "igemm: bad cfg %d", cfg);
     LBC_REQUIRE(a.C % (a.bf16 ? 64 : 32) == 0, "igemm: gathered channels %d not a multiple of %d", a.C, a.bf16 ? 64 : 32);
     LBC_REQUIRE(!a.bf16 || wmajor, "igemm: the bf16 path needs depth-contiguous weights (transpose first)");
+    LBC_REQUIRE(!a.act_bf16 || a.bf16, "igemm: bf16 activations need bf16 = 1");
     LBC_REQUIRE(a.K % kCfgBN[cfg] == 0, "igemm: output channels %d not a multiple of tile %d", a.K, kCfgBN[cfg]);
     LBC_REQUIRE(a.KH * a.KW <= 16, "igemm: too many taps");
     LBC_REQUIRE(a.S == 1 || a.S == 2, "igemm: stride %d unsupported", a.S);
@@ -389,8 +419,8 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     }
     const double in_frac = (mode == 1 && a.S == 2) ? 1.0 : 1.0;
     LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * a.K * (double)a.C * taps,
-                      4.0 * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) + (double)a.M * a.K * (a.resid ? 2 : 1) +
-                             (double)taps * a.C * a.K), s);
+                      (a.act_bf16 ? 2.0 : 4.0) * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) +
+                                                  (double)a.M * a.K * (a.resid ? 2 : 1)) + 4.0 * (double)taps * a.C * a.K, s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);
         case 1: return launch_cfg<128, 128>(a, wmajor, mode, s);

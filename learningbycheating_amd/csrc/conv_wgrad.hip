@@ -12,6 +12,8 @@
 // so LDS tiles are [pixel][channel] and MFMA fragments are ds_read_b32 reads of
 // 32 consecutive channels (conflict free); one MFMA consumes two pixels.
 #include "lbc_common.hpp"
+#include "lbc_act.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -97,7 +99,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
                 const int m = mc + row;
                 pok[j] = m < mend;
                 const int ms = pok[j] ? m : 0;
-                rp[j] = *reinterpret_cast<const f32x4*>(a.p + (size_t)ms * (size_t)a.CP + (size_t)(p0 + sg * 4));
+                rp[j] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.p) + (size_t)ms * (size_t)a.CP + (size_t)(p0 + sg * 4));
             }
 #pragma unroll
             for (int j = 0; j < RQ; ++j) {
@@ -109,7 +111,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
                 const int ix = qx[j] * a.S + s - a.P;
                 qok[j] = (m < mend) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int pix = qok[j] ? ((qn[j] * a.H + iy) * a.W + ix) : 0;
-                rq[j] = *reinterpret_cast<const f32x4*>(a.q + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + sg * 4));
+                rq[j] = *reinterpret_cast<const f32x4*>(static_cast<const float*>(a.q) + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + sg * 4));
                 qx[j] += BR;
                 while (qx[j] >= a.OW) { qx[j] -= a.OW; ++qy[j]; }
                 while (qy[j] >= a.OH) { qy[j] -= a.OH; ++qn[j]; }
@@ -182,26 +184,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
         }
 }
 
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-
 // bf16-MFMA variant (v_mfma_f32_32x32x16_bf16, f32 accumulation; operands stay f32 in HBM and are rounded to bf16 when
 // the tile is written to LDS).  The contraction runs over pixels, which are the slow axis of both NHWC operands, while a
 // bf16 MFMA fragment wants 8 consecutive depth values per lane.  So every thread stages 4 consecutive pixels x 4 channels
 // micro-tiles, transposes them in registers (free) and writes four 8-byte rows [channel][4 pixels]: LDS tiles are
 // [channel][64 pixels] and fragments are plain conflict-free ds_read_b128, with no extra LDS traffic.
-template <int BP, int BQ>
+// AT = element type of P and Q in HBM: float (micro-tiles of 4 pixels x 4 channels) or __bf16 (4 pixels x 8 channels).
+template <int BP, int BQ, typename AT>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_per_split)
 {
+    constexpr bool ABF = Act<AT>::kBf16;
+    using areg_t = typename std::conditional<ABF, bf16x8, f32x4>::type;
+    constexpr int CH = ABF ? 8 : 4;         // channels per 16-byte load
     constexpr int BRH = 64;                 // pixels per chunk
     constexpr int LD = BRH + 8;             // padded LDS row (bf16 elements) = 144 bytes
     constexpr int WM = 2, WN = 2;
     constexpr int MT = BP / WM / 32, NT = BQ / WN / 32;
-    constexpr int CGP = BP / 4, CGQ = BQ / 4;           // channel groups
-    constexpr int NP = 16 * CGP / 256, NQ = 16 * CGQ / 256;   // micro-tiles per thread (1 or 2)
+    constexpr int CGP = BP / CH, CGQ = BQ / CH;          // channel groups
+    constexpr int TP_ = 16 * CGP, TQ_ = 16 * CGQ;        // micro-tiles per chunk
+    constexpr int NP = (TP_ + 255) / 256, NQ = (TQ_ + 255) / 256;   // micro-tiles per thread
     __shared__ __attribute__((aligned(16))) __bf16 sP[2][BP * LD];
     __shared__ __attribute__((aligned(16))) __bf16 sQ[2][BQ * LD];
 
+    const AT* pin = static_cast<const AT*>(a.p);
+    const AT* qin = static_cast<const AT*>(a.q);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -235,13 +241,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    f32x4 rp[NP][4], rq[NQ][4];
+    areg_t rp[NP][4], rq[NQ][4];
     bool pok[NP][4], qok[NQ][4];
     // coordinates of the first pixel of each Q micro-tile, advanced by BRH per chunk
     int qn[NQ], qy[NQ], qx[NQ];
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
-        const int pg = (tid + 256 * t) / CGQ;
+        const int pg = ((tid + 256 * t) / CGQ) & 15;
         const int m = mbeg + 4 * pg;
         const int ohw = a.OH * a.OW;
         qn[t] = m / ohw;
@@ -258,28 +264,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGP, pg = u / CGP;
+                const int cg = u % CGP, pg = (u / CGP) & 15;
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = mc + 4 * pg + i;
-                    pok[t][i] = m < mend;
+                    pok[t][i] = (m < mend) && (u < TP_);
                     const int ms = pok[t][i] ? m : 0;
-                    rp[t][i] = *reinterpret_cast<const f32x4*>(a.p + (size_t)ms * (size_t)a.CP + (size_t)(p0 + cg * 4));
+                    rp[t][i] = *reinterpret_cast<const areg_t*>(pin + (size_t)ms * (size_t)a.CP + (size_t)(p0 + cg * CH));
                 }
             }
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGQ, pg = u / CGQ;
+                const int cg = u % CGQ, pg = (u / CGQ) & 15;
                 int n = qn[t], y = qy[t], x = qx[t];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = mc + 4 * pg + i;
                     const int iy = y * a.S + r - a.P;
                     const int ix = x * a.S + s - a.P;
-                    qok[t][i] = (m < mend) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
+                    qok[t][i] = (m < mend) && (u < TQ_) && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                     const int pix = qok[t][i] ? ((n * a.H + iy) * a.W + ix) : 0;
-                    rq[t][i] = *reinterpret_cast<const f32x4*>(a.q + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + cg * 4));
+                    rq[t][i] = *reinterpret_cast<const areg_t*>(qin + (size_t)pix * (size_t)a.CQ + (size_t)(q0 + cg * CH));
                     if (++x >= a.OW) { x = 0; if (++y >= a.OH) { y = 0; ++n; } }
                 }
                 qx[t] += BRH;
@@ -310,44 +316,43 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGP, pg = u / CGP;
-                f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
-                if (a.p_scale) {
-                    ps = *reinterpret_cast<const f32x4*>(a.p_scale + p0 + cg * 4);
-                    pt = *reinterpret_cast<const f32x4*>(a.p_shift + p0 + cg * 4);
-                }
-                f32x4 v[4];
+                const int cg = u % CGP, pg = (u / CGP) & 15;
+                if (u < TP_) {
+                    float v[4][CH];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = rp[t][i] * ps + pt;
-                    if (!pok[t][i]) v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-                }
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 col = {v[0][c], v[1][c], v[2][c], v[3][c]};   // channel c of the 4 pixels
-                    *reinterpret_cast<bf16x4*>(&sP[buf][(cg * 4 + c) * LD + pg * 4]) = __builtin_convertvector(col, bf16x4);
+                        for (int c = 0; c < CH; ++c) {
+                            float f = (float)rp[t][i][c];
+                            if (a.p_scale) f = f * a.p_scale[p0 + cg * CH + c] + a.p_shift[p0 + cg * CH + c];
+                            v[i][c] = pok[t][i] ? f : 0.f;
+                        }
+#pragma unroll
+                    for (int c = 0; c < CH; ++c) {
+                        const f32x4 col = {v[0][c], v[1][c], v[2][c], v[3][c]};   // channel c of the 4 pixels
+                        *reinterpret_cast<bf16x4*>(&sP[buf][(cg * CH + c) * LD + pg * 4]) = __builtin_convertvector(col, bf16x4);
+                    }
                 }
             }
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGQ, pg = u / CGQ;
-                f32x4 ps = {1.f, 1.f, 1.f, 1.f}, pt = {0.f, 0.f, 0.f, 0.f};
-                if (a.q_scale) {
-                    ps = *reinterpret_cast<const f32x4*>(a.q_scale + q0 + cg * 4);
-                    pt = *reinterpret_cast<const f32x4*>(a.q_shift + q0 + cg * 4);
-                }
-                f32x4 v[4];
+                const int cg = u % CGQ, pg = (u / CGQ) & 15;
+                if (u < TQ_) {
+                    float v[4][CH];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = rq[t][i] * ps + pt;
+                    for (int i = 0; i < 4; ++i)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[i][e] = qok[t][i] ? fmaxf(v[i][e], relu_floor) : 0.f;
-                }
+                        for (int c = 0; c < CH; ++c) {
+                            float f = (float)rq[t][i][c];
+                            if (a.q_scale) f = fmaxf(f * a.q_scale[q0 + cg * CH + c] + a.q_shift[q0 + cg * CH + c], relu_floor);
+                            v[i][c] = qok[t][i] ? f : 0.f;
+                        }
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const f32x4 col = {v[0][c], v[1][c], v[2][c], v[3][c]};
-                    *reinterpret_cast<bf16x4*>(&sQ[buf][(cg * 4 + c) * LD + pg * 4]) = __builtin_convertvector(col, bf16x4);
+                    for (int c = 0; c < CH; ++c) {
+                        const f32x4 col = {v[0][c], v[1][c], v[2][c], v[3][c]};
+                        *reinterpret_cast<bf16x4*>(&sQ[buf][(cg * CH + c) * LD + pg * 4]) = __builtin_convertvector(col, bf16x4);
+                    }
                 }
             }
         }
@@ -415,19 +420,24 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.CP % 64 == 0 && a.CQ % 64 == 0, "wgrad: channels (%d,%d) must be multiples of 64", a.CP, a.CQ);
     LBC_REQUIRE(a.nsplit >= 1, "wgrad: nsplit %d", a.nsplit);
+    LBC_REQUIRE(!a.act_bf16 || a.bf16, "wgrad: bf16 operands need bf16 = 1");
     const long long M = (long long)a.N * a.OH * a.OW;
     LBC_REQUIRE(M > 0 && M * a.CP < (1ll << 31) && (long long)a.N * a.H * a.W * a.CQ < (1ll << 31), "wgrad: bad tensor size");
     const int br = a.bf16 ? 64 : BR;
     const long long chunks = (M + br - 1) / br;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * br;
     LbcProfScope prof("conv_wgrad", 2.0 * M * a.CP * (double)a.CQ * a.KH * a.KW,
-                      4.0 * ((double)M * a.CP + (double)a.N * a.H * a.W * a.CQ + (double)a.nsplit * a.CP * a.KH * a.KW * a.CQ), s);
+                      (a.act_bf16 ? 2.0 : 4.0) * ((double)M * a.CP + (double)a.N * a.H * a.W * a.CQ) +
+                          4.0 * (double)a.nsplit * a.CP * a.KH * a.KW * a.CQ, s);
     const int bt = big_tile(a) ? 128 : 64;
     const long long ngroups = (long long)a.nsplit * (a.CP / bt) * (a.CQ / bt);
     const dim3 grid((unsigned)(((ngroups + 7) / 8) * 8 * a.KH * a.KW));
-    if (a.bf16) {
-        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
-        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
+    if (a.act_bf16) {
+        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, __bf16>), grid, dim3(256), 0, s, a, rows_per_split);
+        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, __bf16>), grid, dim3(256), 0, s, a, rows_per_split);
+    } else if (a.bf16) {
+        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, float>), grid, dim3(256), 0, s, a, rows_per_split);
+        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, float>), grid, dim3(256), 0, s, a, rows_per_split);
     } else if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
     else                    hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("conv_wgrad_f32");

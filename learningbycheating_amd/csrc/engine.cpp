@@ -41,6 +41,9 @@ size_t Net::alloc(size_t nfloats)
     return off;
 }
 
+// activation / activation-gradient tensor of n elements: f32, or bf16 (half the space) in precision 2
+size_t Net::alloc_act(size_t n) { return alloc(act_bf16_ ? (n + 1) / 2 : n); }
+
 BN Net::make_bn(const std::string& p, int C)
 {
     BN bn;
@@ -62,7 +65,7 @@ Conv Net::make_conv(const std::string& name, int Cin, int Cout, int H, int W, in
     c.Cin = Cin; c.Cout = Cout; c.H = H; c.W = W; c.k = k; c.s = s; c.p = p;
     c.OH = (H + 2 * p - k) / s + 1;
     c.OW = (W + 2 * p - k) / s + 1;
-    c.y = alloc((size_t)d_.max_batch * c.OH * c.OW * Cout);
+    c.y = alloc_act((size_t)d_.max_batch * c.OH * c.OW * Cout);
     return c;
 }
 
@@ -72,16 +75,17 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
     if (const char* e = getenv("LBC_NO_FUSE_Z1")) fuse_z1_ = !(e[0] == '1');
     if (const char* e = getenv("LBC_DGRAD_WT")) dgrad_wt_ = (e[0] == '1');
-    bf16_ = d.precision == 1;
+    bf16_ = d.precision >= 1;
+    act_bf16_ = d.precision == 2;
     if (bf16_) dgrad_wt_ = true;   // the bf16 tiles are [row][depth] only: every weight operand must be depth-contiguous
 
     // ---- stem (resnet.py:102-106) ----
     stem_w_ = add_tensor("conv.conv1.weight", kParam, {64, Cin, 7, 7});
     stem_bn_ = make_bn("conv.bn1", 64);
     xp_ = alloc(NB * (H0 + 6) * (W0 + 6) * Cin);
-    y0_ = alloc(NB * (H0 / 2) * (W0 / 2) * 64);
+    y0_ = alloc_act(NB * (H0 / 2) * (W0 / 2) * 64);
     H1_ = H0 / 4; W1_ = W0 / 4;
-    p0_ = alloc(NB * H1_ * W1_ * 64);
+    p0_ = alloc_act(NB * H1_ * W1_ * 64);
     idx_ = alloc(NB * H1_ * W1_ * 64 / 4);
 
     // ---- residual layers (resnet.py:107-110,124-146,162-168) ----
@@ -106,15 +110,15 @@ Net::Net(const lbc_net_desc& d) : d_(d)
                 b.ds = make_conv(pre + ".downsample.0.weight", inpl, planes, h, w, 1, stride, 0);
                 b.bd = make_bn(pre + ".downsample.1", planes);
             }
-            b.z1 = fuse_z1_ ? 0 : alloc(NB * oh * ow * planes);
-            b.out = alloc(NB * oh * ow * planes);
+            b.z1 = fuse_z1_ ? 0 : alloc_act(NB * oh * ow * planes);
+            b.out = alloc_act(NB * oh * ow * planes);
             blocks_.push_back(b);
             inpl = planes; h = oh; w = ow;
         }
     }
 
     // ---- velocity fusion + decoder (image.py:37-47,77-80) ----
-    hcat_ = alloc(NB * h * w * 640);
+    hcat_ = alloc_act(NB * h * w * 640);
     const int dc[4] = {640, 256, 128, 64};
     const char* bn_name[3] = {"deconv.0", "deconv.3", "deconv.6"};
     const char* ct_name[3] = {"deconv.1", "deconv.4", "deconv.7"};
@@ -125,7 +129,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
         D.w = add_tensor(std::string(ct_name[i]) + ".weight", kParam, {dc[i], dc[i + 1], 3, 3});
         D.bias = add_tensor(std::string(ct_name[i]) + ".bias", kParam, {dc[i + 1]});
         D.Cin = dc[i]; D.Cout = dc[i + 1]; D.H = dh; D.W = dw;
-        D.u = alloc(NB * (2 * dh) * (2 * dw) * dc[i + 1]);
+        D.u = alloc_act(NB * (2 * dh) * (2 * dw) * dc[i + 1]);
         dh *= 2; dw *= 2;
         max_act = std::max(max_act, NB * dh * dw * (size_t)dc[i + 1]);
     }
@@ -177,8 +181,8 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     wg_partial_ = alloc(wg);
 
     wt_ = alloc((size_t)640 * 512 * 9);
-    gD_ = alloc(max_act); gE_ = alloc(max_act); gF_ = alloc(max_act); gG_ = alloc(max_act);
-    g0_ = alloc(NB * (H0 / 2) * (W0 / 2) * 64);
+    gD_ = alloc_act(max_act); gE_ = alloc_act(max_act); gF_ = alloc_act(max_act); gG_ = alloc_act(max_act);
+    g0_ = alloc_act(NB * (H0 / 2) * (W0 / 2) * 64);
 }
 
 int Net::check_bound(bool need_grads) const
@@ -205,7 +209,7 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     const int cfg = lbc_igemm_pick(a.M, a.K);
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? W(partial_) : nullptr;
-    a.bf16 = bf16_;
+    a.bf16 = bf16_; a.act_bf16 = act_bf16_;
     return lbc_igemm_launch(a, 1, 0, cfg, s);
 }
 
@@ -255,13 +259,13 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
     StemArgs st;
     st.xp = W(xp_); st.w = P(stem_w_); st.y = W(y0_); st.stats = tr ? W(partial_) : nullptr;
-    st.N = N; st.H = H0; st.W = W0; st.Cin = Cin;
+    st.N = N; st.H = H0; st.W = W0; st.Cin = Cin; st.act_bf16 = act_bf16_;
     LBC_TRY(lbc_stem_fwd(st, s));
     LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), train, s));
     PoolFwdArgs pf;
     pf.y = W(y0_); pf.scale = W(stem_bn_.scale); pf.shift = W(stem_bn_.shift); pf.p = W(p0_);
     pf.idx = reinterpret_cast<unsigned char*>(W(idx_));
-    pf.N = N; pf.H = H0 / 2; pf.W = W0 / 2; pf.C = 64;
+    pf.N = N; pf.H = H0 / 2; pf.W = W0 / 2; pf.C = 64; pf.act_bf16 = act_bf16_;
     LBC_TRY(lbc_bn_relu_maxpool_fwd(pf, s));
 
     // resnet.py:38-54 BasicBlock.forward x 8/16
@@ -276,14 +280,14 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
         } else {
             memset(&ap, 0, sizeof(ap));
             ap.x = W(b.c1.y); ap.y = W(b.z1); ap.pixels = pix; ap.C = b.c1.Cout;
-            ap.scale = W(b.b1.scale); ap.shift = W(b.b1.shift); ap.relu = 1;
+            ap.scale = W(b.b1.scale); ap.shift = W(b.b1.shift); ap.relu = 1; ap.act_bf16 = act_bf16_;
             LBC_TRY(lbc_bn_apply(ap, s));
             LBC_TRY(conv_fwd(b.c2, W(b.z1), N, tr, &rows, s));
         }
         LBC_TRY(bn_finalize(b.b2, rows, pix, train, s));
         memset(&ap, 0, sizeof(ap));
         ap.x = W(b.c2.y); ap.y = W(b.out); ap.pixels = pix; ap.C = b.c2.Cout;
-        ap.scale = W(b.b2.scale); ap.shift = W(b.b2.shift); ap.relu = 1;
+        ap.scale = W(b.b2.scale); ap.shift = W(b.b2.shift); ap.relu = 1; ap.act_bf16 = act_bf16_;
         if (b.has_ds) {
             LBC_TRY(conv_fwd(b.ds, x, N, tr, &rows, s));
             LBC_TRY(bn_finalize(b.bd, rows, pix, train, s));
@@ -298,11 +302,11 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     // image.py:77-79 velocity late fusion; image.py:37-47 decoder (BN -> ConvT -> ReLU) x 3
     const Block& last = blocks_.back();
     const int th = last.c2.OH, tw = last.c2.OW;
-    LBC_TRY(lbc_concat_velocity(x, velocity, W(hcat_), N, th * tw, 512, 128, s));
+    LBC_TRY(lbc_concat_velocity(x, velocity, W(hcat_), N, th * tw, 512, 128, act_bf16_, s));
     if (tr) {
         ChanReduceArgs cr;
         memset(&cr, 0, sizeof(cr));
-        cr.x = W(hcat_); cr.partial = W(partial_); cr.pixels = (long long)N * th * tw; cr.C = 640;
+        cr.x = W(hcat_); cr.partial = W(partial_); cr.pixels = (long long)N * th * tw; cr.C = 640; cr.act_bf16 = act_bf16_;
         LBC_TRY(lbc_chan_reduce(cr, 0, s));
         rows = lbc_chan_reduce_rows(cr.pixels, 640);
     }
@@ -320,6 +324,7 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
         a.LH = D.H; a.LW = D.W; a.ostep = 2;
         a.M = N * D.H * D.W;
         a.stats = tr ? W(partial_) : nullptr;
+        a.act_bf16 = act_bf16_;
         int wmajor = 0;
         if (bf16_) {
             // w[Cin][T][Cout] -> wt[Cout][T][Cin]: depth-contiguous for the bf16 tiles
@@ -355,7 +360,7 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     }
     ha.cmd = W(cmd_);
     ha.pred_all = W(pred_all_); ha.pred_sel = pred_sel; ha.rowstat = W(rowstat_);
-    ha.N = N; ha.OH = HH_; ha.OW = HW_;
+    ha.N = N; ha.OH = HH_; ha.OW = HW_; ha.act_bf16 = act_bf16_;
     LBC_TRY(lbc_head_fwd(ha, s));
     if (hipMemcpyAsync(pred_all, W(pred_all_), sizeof(float) * 40 * N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
         lbc_set_error("net.forward: output copy failed");
@@ -373,7 +378,7 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
     memset(&r, 0, sizeof(r));
     r.x = x; r.dz = dz; r.mask = mask; r.g_out = g_out; r.mean = W(bn.mean); r.invstd = W(bn.invstd);
     if (mask_bn) { r.mask_scale = W(mask_bn->scale); r.mask_shift = W(mask_bn->shift); }
-    r.partial = W(partial_); r.pixels = pixels; r.C = bn.C;
+    r.partial = W(partial_); r.pixels = pixels; r.C = bn.C; r.act_bf16 = act_bf16_;
     LBC_TRY(lbc_chan_reduce(r, 1, s));
     int rows = lbc_chan_reduce_rows(pixels, bn.C);
     const float* part = W(partial_);
@@ -393,7 +398,7 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
     ap.g = g_out ? g_out : dz; ap.mask = g_out ? nullptr : mask; ap.x = x;
     ap.coefA = W(bn.cA); ap.coefB = W(bn.cB); ap.coefD = W(bn.cD);
     ap.mean = W(bn.mean); ap.invstd = W(bn.invstd);
-    ap.dx = dx; ap.pixels = pixels; ap.C = bn.C; ap.Cout = Cout;
+    ap.dx = dx; ap.pixels = pixels; ap.C = bn.C; ap.Cout = Cout; ap.act_bf16 = act_bf16_;
     return lbc_bn_bwd_apply(ap, s);
 }
 
@@ -408,7 +413,7 @@ int Net::conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const floa
     memset(&a, 0, sizeof(a));
     a.p = dy; a.q = x; a.partial = W(wg_partial_);
     if (pre) { a.q_scale = W(pre->scale); a.q_shift = W(pre->shift); a.q_relu = 1; }
-    a.bf16 = bf16_;
+    a.bf16 = bf16_; a.act_bf16 = act_bf16_;
     a.N = N; a.OH = c.OH; a.OW = c.OW; a.CP = c.Cout;
     a.H = c.H; a.W = c.W; a.CQ = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
@@ -427,7 +432,7 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     a.OH = c.H; a.OW = c.W; a.K = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
     int wmajor = 0;
-    a.bf16 = bf16_;
+    a.bf16 = bf16_; a.act_bf16 = act_bf16_;
     if (dgrad_wt_ && (c.k == 3 || bf16_)) {
         // w[Cout][T][Cin] -> wt[Cin][T][Cout]: output channel (Cin) major, gathered channel (Cout) contiguous
         LBC_TRY(lbc_weight_transpose(P(c.w), W(wt_), c.Cout, c.k * c.k, c.Cin, s));
@@ -504,7 +509,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             ha.pos_x[b] = P(head_px_[b]); ha.pos_y[b] = P(head_py_[b]);
         }
         ha.cmd = W(cmd_); ha.pred_all = W(pred_all_); ha.rowstat = W(rowstat_);
-        ha.N = N; ha.OH = HH_; ha.OW = HW_;
+        ha.N = N; ha.OH = HH_; ha.OW = HW_; ha.act_bf16 = act_bf16_;
         hb.d_all = d_all; hb.d_sel = d_sel; hb.s_partial = W(head_partial_); hb.dh = E; hb.chan_coef = W(head_coef_);
         LBC_TRY(lbc_head_bwd_reduce(hb, s));
         HeadBwdFinalizeArgs hf;
@@ -528,7 +533,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             // ReLU backward in place + bias gradient
             ChanReduceArgs r;
             memset(&r, 0, sizeof(r));
-            r.dz = E; r.mask = W(D.u); r.g_out = E; r.partial = W(partial_); r.pixels = opix; r.C = D.Cout;
+            r.dz = E; r.mask = W(D.u); r.g_out = E; r.partial = W(partial_); r.pixels = opix; r.C = D.Cout; r.act_bf16 = act_bf16_;
             LBC_TRY(lbc_chan_reduce(r, 1, s));
             int rows = lbc_chan_reduce_rows(opix, D.Cout);
             const float* part = W(partial_);
@@ -547,7 +552,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             wa.p_scale = W(D.bn.scale); wa.p_shift = W(D.bn.shift);
             wa.N = N; wa.OH = D.H; wa.OW = D.W; wa.CP = D.Cin;
             wa.H = 2 * D.H; wa.W = 2 * D.W; wa.CQ = D.Cout; wa.KH = 3; wa.KW = 3; wa.S = 2; wa.P = 1;
-            wa.bf16 = bf16_;
+            wa.bf16 = bf16_; wa.act_bf16 = act_bf16_;
             wa.nsplit = lbc_wgrad_pick_split(wa);
             LBC_TRY(lbc_wgrad_launch(wa, s));
             LBC_TRY(lbc_splitk_reduce(wa.partial, wa.nsplit, (long long)D.Cin * 9 * D.Cout, G(D.w), 0.f, s));
@@ -558,7 +563,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             a.N = N; a.H = 2 * D.H; a.W = 2 * D.W; a.C = D.Cout;
             a.OH = D.H; a.OW = D.W; a.K = D.Cin; a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
             a.M = N * D.H * D.W; a.LH = D.H; a.LW = D.W; a.ostep = 1;
-            a.bf16 = bf16_;
+            a.bf16 = bf16_; a.act_bf16 = act_bf16_;
             LBC_TRY(lbc_igemm_launch(a, 1, 0, lbc_igemm_pick(a.M, a.K), s));   // F = d bn(x)
             // BatchNorm backward; for the first decoder stage only the 512 trunk channels carry on
             float* dst = i == 0 ? bwd_D_ : E;
@@ -583,7 +588,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
         pb.scale = W(stem_bn_.scale); pb.shift = W(stem_bn_.shift);
         pb.mean = W(stem_bn_.mean); pb.invstd = W(stem_bn_.invstd);
         pb.g = W(g0_); pb.partial = W(partial_);
-        pb.N = N; pb.H = H0 / 2; pb.W = W0 / 2; pb.C = 64;
+        pb.N = N; pb.H = H0 / 2; pb.W = W0 / 2; pb.C = 64; pb.act_bf16 = act_bf16_;
         LBC_TRY(lbc_maxpool_relu_bwd_reduce(pb, s));
         int rows = lbc_pool_bwd_rows(N, H0 / 2, W0 / 2, 64);
         const long long pix = (long long)N * (H0 / 2) * (W0 / 2);
@@ -603,11 +608,11 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
         memset(&ap, 0, sizeof(ap));
         ap.g = W(g0_); ap.x = W(y0_); ap.coefA = W(stem_bn_.cA); ap.coefB = W(stem_bn_.cB); ap.coefD = W(stem_bn_.cD);
         ap.mean = W(stem_bn_.mean); ap.invstd = W(stem_bn_.invstd);
-        ap.dx = W(g0_); ap.pixels = pix; ap.C = 64; ap.Cout = 64;
+        ap.dx = W(g0_); ap.pixels = pix; ap.C = 64; ap.Cout = 64; ap.act_bf16 = act_bf16_;
         LBC_TRY(lbc_bn_bwd_apply(ap, s));
         StemWgradArgs sw;
         sw.xp = W(xp_); sw.dy = W(g0_); sw.partial = W(wg_partial_);
-        sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels;
+        sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels; sw.act_bf16 = act_bf16_;
         sw.nsplit = lbc_stem_wgrad_split(N, H0, W0);
         LBC_TRY(lbc_stem_wgrad(sw, s));
         LBC_TRY(lbc_splitk_reduce(sw.partial, sw.nsplit, (long long)64 * 49 * d_.in_channels, G(stem_w_), 0.f, s));
@@ -632,7 +637,8 @@ int lbc_net_create(const lbc_net_desc* d, lbc_net** out)
     LBC_REQUIRE(d->H > 0 && d->W > 0 && d->H % 32 == 0 && d->W % 32 == 0, "net_create: image %dx%d must be a multiple of 32", d->H, d->W);
     LBC_REQUIRE(d->max_batch >= 1, "net_create: max_batch %d", d->max_batch);
     LBC_REQUIRE(!d->normalize || d->in_channels == 3, "net_create: ImageNet normalisation needs 3 channels");
-    LBC_REQUIRE(d->precision == 0 || d->precision == 1, "net_create: precision %d unknown (0 = f32, 1 = bf16 MFMA operands)", d->precision);
+    LBC_REQUIRE(d->precision >= 0 && d->precision <= 2,
+                "net_create: precision %d unknown (0 = f32, 1 = bf16 MFMA operands, 2 = bf16 operands + bf16 activation storage)", d->precision);
     LBC_REQUIRE((long long)d->max_batch * (d->H / 2) * (d->W / 2) * 64 < (1ll << 31), "net_create: batch too large for 32-bit indexing");
     *out = new lbc_net(*d);
     return LBC_OK;

@@ -74,6 +74,7 @@ public:
 private:
     int add_tensor(const std::string& name, int kind, std::initializer_list<int> shape);
     size_t alloc(size_t nfloats);
+    size_t alloc_act(size_t nelems);
     BN make_bn(const std::string& prefix, int C);
     Conv make_conv(const std::string& name, int Cin, int Cout, int H, int W, int k, int s, int p);
     float* W(size_t off) const { return ws_ + off; }
@@ -84,7 +85,8 @@ private:
     int conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s);
     bool dgrad_wt_ = false;  // optional: input-gradient GEMMs read a per-step transposed copy of the weights (measured: no gain)
     size_t wt_ = 0;
-    bool bf16_ = false;      // precision 1: bf16 MFMA operands in the convolution family
+    bool bf16_ = false;      // precision >= 1: bf16 MFMA operands in the convolution family
+    bool act_bf16_ = false;  // precision 2: activations and activation gradients are stored as bf16 in HBM
     bool fuse_z1_ = true;    // conv2 / wgrad2 / bn1-backward read y1 with bn1(+ReLU) applied on load; z1 is never written
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,

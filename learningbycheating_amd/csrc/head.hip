@@ -18,6 +18,7 @@
 //   dh[pix,c] = sum_{b,s} dlogit * (W*gamma*invstd) - invstd*(k1 + k2*xh[pix,c])
 //   k1 = sum_b gamma_b*dbeta_b / n, k2 = sum_b gamma_b*dgamma_b / n.
 #include "lbc_common.hpp"
+#include "lbc_act.hpp"
 #include "lbc_kernels.hpp"
 
 namespace {
@@ -38,16 +39,18 @@ __device__ __forceinline__ void soft_merge(SoftAcc& a, const SoftAcc& b)
     a.m = M;
 }
 
-__device__ __forceinline__ void load_tile(const float* __restrict__ h, float* sH, int n, int HW, int tile, int tid)
+template <typename T>
+__device__ __forceinline__ void load_tile(const void* hv, float* sH, int n, int HW, int tile, int tid)
 {
+    const T* h = static_cast<const T*>(hv);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
         const int idx = tid + 256 * j;
         const int row = idx >> 4, sg = idx & 15;
         const int p = tile * TP + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p < HW) v = *reinterpret_cast<const float4*>(h + ((size_t)n * HW + (size_t)p) * 64 + (size_t)(sg * 4));
-        *reinterpret_cast<float4*>(&sH[row * LDH + sg * 4]) = v;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p < HW) v = Act<T>::ld4(h + ((size_t)n * HW + (size_t)p) * 64 + (size_t)(sg * 4));
+        *reinterpret_cast<f32x4*>(&sH[row * LDH + sg * 4]) = v;
     }
 }
 
@@ -68,6 +71,7 @@ __device__ __forceinline__ void fold_branch(const HeadArgs& a, int b, float* sW 
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void head_fwd_k(HeadArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sH[TP * LDH];
@@ -86,7 +90,7 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadArgs a)
 
     const int ntile = (HW + TP - 1) / TP;
     for (int tile = 0; tile < ntile; ++tile) {
-        load_tile(a.h, sH, n, HW, tile, tid);
+        load_tile<T>(a.h, sH, n, HW, tile, tid);
         __syncthreads();
         const int p = tile * TP + tid;
         if (p < HW) {
@@ -162,6 +166,7 @@ __device__ __forceinline__ void row_grad(const HeadBwdArgs& a, int n, int b, int
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_reduce_k(HeadBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sH[TP * LDH];
@@ -193,7 +198,7 @@ __global__ __launch_bounds__(256) void head_bwd_reduce_k(HeadBwdArgs a)
 
     const int ntile = (HW + TP - 1) / TP;
     for (int tile = 0; tile < ntile; ++tile) {
-        load_tile(a.f.h, sH, n, HW, tile, tid);
+        load_tile<T>(a.f.h, sH, n, HW, tile, tid);
         __syncthreads();
         const int p = tile * TP + tid;
         float dl[5];
@@ -296,6 +301,7 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_k(HeadBwdFinalizeArgs a
     }
 }
 
+template <typename T>
 __global__ __launch_bounds__(256) void head_bwd_apply_k(HeadBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float sH[TP * LDH];
@@ -317,7 +323,7 @@ __global__ __launch_bounds__(256) void head_bwd_apply_k(HeadBwdArgs a)
         sRow[tid * 5 + 3] = a.f.rowstat[o2];
         sRow[tid * 5 + 4] = 1.f / a.f.rowstat[o2 + 1];
     }
-    load_tile(a.f.h, sH, n, HW, tile, tid);
+    load_tile<T>(a.f.h, sH, n, HW, tile, tid);
     __syncthreads();
     const int p = tile * TP + tid;
     {
@@ -360,7 +366,7 @@ __global__ __launch_bounds__(256) void head_bwd_apply_k(HeadBwdArgs a)
         float o = -c1 - c2 * ((sH[pp * LDH + c] - mu) * iv);
 #pragma unroll
         for (int bs = 0; bs < 20; ++bs) o += sD[bs * TP + pp] * wf[bs];
-        a.dh[((size_t)n * HW + (size_t)pg) * 64 + c] = o;
+        Act<T>::st1(static_cast<T*>(a.dh) + ((size_t)n * HW + (size_t)pg) * 64 + c, o);
     }
 }
 
@@ -370,7 +376,9 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
     LbcProfScope prof("head_fwd", 2.0 * a.N * a.OH * a.OW * 64.0 * 20, 4.0 * a.N * (double)a.OH * a.OW * 64, s);
-    hipLaunchKernelGGL(head_fwd_k, dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
+#define LBC_K(T, d) hipLaunchKernelGGL((head_fwd_k<T>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a)
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 0);
+#undef LBC_K
     int rc = lbc_check_launch("head_fwd");
     if (rc) return rc;
     if (a.pred_sel) {
@@ -388,7 +396,9 @@ int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s)
     LBC_REQUIRE(a.f.mean[0] == a.f.mean[1] && a.f.mean[0] == a.f.mean[2] && a.f.mean[0] == a.f.mean[3],
                 "head backward requires training-mode (shared batch) statistics");
     LbcProfScope prof("head_bwd_reduce", 4.0 * a.f.N * a.f.OH * a.f.OW * 64.0 * 20, 4.0 * a.f.N * (double)a.f.OH * a.f.OW * 64, s);
-    hipLaunchKernelGGL(head_bwd_reduce_k, dim3((unsigned)a.f.N, 4), dim3(256), 0, s, a);
+#define LBC_K(T, d) hipLaunchKernelGGL((head_bwd_reduce_k<T>), dim3((unsigned)a.f.N, 4), dim3(256), 0, s, a)
+    LBC_DISPATCH_ACT(a.f.act_bf16, LBC_K, 0);
+#undef LBC_K
     return lbc_check_launch("head_bwd_reduce");
 }
 
@@ -402,6 +412,8 @@ int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s)
 {
     const int HW = a.f.OH * a.f.OW;
     LbcProfScope prof("head_bwd_apply", 4.0 * a.f.N * (double)HW * 64.0 * 20, 8.0 * a.f.N * (double)HW * 64, s);
-    hipLaunchKernelGGL(head_bwd_apply_k, dim3((unsigned)a.f.N, (unsigned)lbc_cdiv(HW, TP)), dim3(256), 0, s, a);
+#define LBC_K(T, d) hipLaunchKernelGGL((head_bwd_apply_k<T>), dim3((unsigned)a.f.N, (unsigned)lbc_cdiv(HW, TP)), dim3(256), 0, s, a)
+    LBC_DISPATCH_ACT(a.f.act_bf16, LBC_K, 0);
+#undef LBC_K
     return lbc_check_launch("head_bwd_apply");
 }

@@ -55,11 +55,11 @@ struct LbcProfScope {
 // wmajor 1: w[k][tap][c] (depth-contiguous), wmajor 0: w[c][tap][k].
 // ---------------------------------------------------------------------------
 struct IgemmArgs {
-    const float* x;       // gathered tensor, NHWC [N][H][W][C]
+    const void* x;        // gathered tensor, NHWC [N][H][W][C]; f32, or bf16 when act_bf16
     const float* w;
-    float* y;             // NHWC [N][OH][OW][K]
+    void* y;              // NHWC [N][OH][OW][K]; same element type as x
     const float* bias;    // [K] or nullptr
-    const float* resid;   // like y (may alias y) or nullptr; added before relu
+    const void* resid;    // like y (may alias y) or nullptr; added before relu
     float* stats;         // [rows][2][K] per-block (sum, sum of squares) of the stored value, or nullptr
     // fused BatchNorm-on-load of x (per gathered channel): x' = relu?(x*ps[c] + pt[c]); nullptr = identity
     const float* pre_scale;
@@ -73,7 +73,8 @@ struct IgemmArgs {
     int oy0, ox0, ostep;
     int relu;
     int stat_row0;
-    int bf16;             // 1: bf16 MFMA operands (f32 storage / accumulation), needs wmajor weights and C % 64 == 0
+    int bf16;             // 1: bf16 MFMA operands (f32 accumulation), needs wmajor weights and C % 64 == 0
+    int act_bf16;         // 1: x / y / resid are bf16 tensors (requires bf16 = 1)
 };
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg);   // number of M tiles (= stats rows) of a launch
@@ -87,8 +88,8 @@ int lbc_weight_transpose(const float* w, float* wt, int A, int T, int B, hipStre
 // (oy*S + r - P, ox*S + s - P).  Split over m into `nsplit` partial slabs which
 // lbc_splitk_reduce sums in a fixed order (deterministic).
 struct WgradArgs {
-    const float* p;
-    const float* q;
+    const void* p;        // f32, or bf16 when act_bf16
+    const void* q;
     float* partial;       // [nsplit][CP][T][CQ]
     // optional fused transforms on load (BatchNorm apply [+relu]) per channel
     const float* p_scale;
@@ -100,7 +101,8 @@ struct WgradArgs {
     int H, W, CQ;
     int KH, KW, S, P;
     int nsplit;
-    int bf16;             // 1: bf16 MFMA operands (f32 storage / accumulation)
+    int bf16;             // 1: bf16 MFMA operands (f32 accumulation)
+    int act_bf16;         // 1: p / q are bf16 tensors (requires bf16 = 1)
 };
 int lbc_wgrad_pick_split(const WgradArgs& a);
 int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s);

@@ -24,29 +24,31 @@ int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_
 int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 
 struct BnApplyArgs {
-    const float* x; float* y;
+    const void* x; void* y;      // activations: f32 or bf16 (act_bf16)
     long long pixels; int C;
     const float* scale; const float* shift;
-    const float* resid;          // nullable
+    const void* resid;           // nullable
     const float* rscale;         // nullable: residual is itself BatchNorm'ed (downsample path)
     const float* rshift;
     int relu;
+    int act_bf16;
 };
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s);
 
 // ---- per-channel reductions --------------------------------------------------------
 struct ChanReduceArgs {
-    const float* x;              // op0: tensor to take statistics of; op1: pre-BN activation (nullable)
-    const float* dz;             // op1: upstream gradient
-    const float* mask;           // op1: ReLU mask source (g = dz where mask > 0), nullable
+    const void* x;               // op0: tensor to take statistics of; op1: pre-BN activation (nullable)
+    const void* dz;              // op1: upstream gradient
+    const void* mask;            // op1: ReLU mask source (g = dz where mask > 0), nullable
     const float* mask_scale;     // op1: optional per-channel affine applied to the mask source first
     const float* mask_shift;     //      (mask = pre-BN activation, affine = that BN: relu(bn(y)) > 0)
-    float* g_out;                // op1: optional store of the masked gradient (may alias dz)
+    void* g_out;                 // op1: optional store of the masked gradient (may alias dz)
     const float* mean;           // op1: nullable
     const float* invstd;
     float* partial;              // [rows][2][C]
     long long pixels; int C;
     long long pix_per_block;     // filled by the launcher
+    int act_bf16;
 };
 int lbc_chan_reduce_rows(long long pixels, int C);
 int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s);
@@ -61,16 +63,17 @@ struct BnBwdFinalizeArgs {
 int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s);
 
 struct BnBwdApplyArgs {
-    const float* g; const float* mask; const float* x;
+    const void* g; const void* mask; const void* x;
     const float* coefA; const float* coefB; const float* coefD;   // A, k1, k2
     const float* mean; const float* invstd;
-    float* dx;                   // [pixels][Cout]
+    void* dx;                    // [pixels][Cout]
     long long pixels; int C, Cout;
     int accum;                   // dx += ...
+    int act_bf16;
 };
 int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
 
-int lbc_concat_velocity(const float* t, const float* vel, float* h, int N, int hw, int Ct, int Cv, hipStream_t s);
+int lbc_concat_velocity(const void* t, const float* vel, void* h, int N, int hw, int Ct, int Cv, int act_bf16, hipStream_t s);
 
 // ---- stem: input preparation, 7x7/2 convolution, BN+ReLU+maxpool -------------------
 // prep: NCHW fp32 image -> (optionally ImageNet-normalised) NHWC fp32 with a 3-pixel
@@ -80,44 +83,49 @@ int lbc_prep_input(const float* img_nchw, float* xp, int N, int C, int H, int W,
 struct StemArgs {
     const float* xp;             // [N][H+6][W+6][Cin]
     const float* w;              // [64][7][7][Cin]
-    float* y;                    // [N][H/2][W/2][64]
+    void* y;                     // [N][H/2][W/2][64] f32 or bf16 (act_bf16)
     float* stats;                // [rows][2][64] or nullptr
     int N, H, W, Cin;
+    int act_bf16;
 };
 int lbc_stem_rows(const StemArgs& a);
 int lbc_stem_fwd(const StemArgs& a, hipStream_t s);
 struct StemWgradArgs {
-    const float* xp; const float* dy; float* partial;   // partial [nsplit][64][7][7*Cin]
+    const float* xp; const void* dy; float* partial;   // partial [nsplit][64][7][7*Cin]; dy f32 or bf16
     int N, H, W, Cin, nsplit;
+    int act_bf16;
 };
 int lbc_stem_wgrad_split(int N, int H, int W);
 int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s);
 
 struct PoolFwdArgs {
-    const float* y;              // [N][H][W][C] pre-BN stem output
+    const void* y;               // [N][H][W][C] pre-BN stem output
     const float* scale; const float* shift;
-    float* p;                    // [N][H/2][W/2][C]
+    void* p;                     // [N][H/2][W/2][C]
     unsigned char* idx;          // [N][H/2][W/2][C] arg-max tap (0..8), nullable
     int N, H, W, C;
+    int act_bf16;
 };
 int lbc_bn_relu_maxpool_fwd(const PoolFwdArgs& a, hipStream_t s);
 struct PoolBwdArgs {
-    const float* dp;             // [N][H/2][W/2][C]
+    const void* dp;              // [N][H/2][W/2][C]
     const unsigned char* idx;
-    const float* y;              // [N][H][W][C]
+    const void* y;               // [N][H][W][C]
     const float* scale; const float* shift;   // forward BN affine (ReLU mask)
     const float* mean; const float* invstd;
-    float* g;                    // [N][H][W][C] masked gradient wrt the BN output
+    void* g;                     // [N][H][W][C] masked gradient wrt the BN output
     float* partial;              // [rows][2][C]
     int N, H, W, C;
     long long pix_per_block;
+    int act_bf16;
 };
 int lbc_pool_bwd_rows(int N, int H, int W, int C);
 int lbc_maxpool_relu_bwd_reduce(PoolBwdArgs a, hipStream_t s);
 
 // ---- waypoint head: 4 x (BN64 -> 1x1 conv 64->5 -> spatial softmax) + branch select --
 struct HeadArgs {
-    const float* h;              // [N][HW][64] decoder output
+    const void* h;               // [N][HW][64] decoder output, f32 or bf16 (act_bf16)
+    int act_bf16;
     const float* mean[4];        // per branch BatchNorm statistics [64] (train: all four point at the batch stats)
     const float* invstd[4];
     const float* gamma[4];       // [64]
@@ -138,7 +146,7 @@ struct HeadBwdArgs {
     const float* d_all;          // [N][4][5][2] nullable
     const float* d_sel;          // [N][5][2] nullable
     float* s_partial;            // [N][20*65] : per (branch,step): sum dlogit*h[c] (64) and sum dlogit
-    float* dh;                   // [N][HW][64]
+    void* dh;                    // [N][HW][64] (same element type as h)
     const float* chan_coef;      // pass 2: [2][64] per-channel coefficients (see head.hip)
 };
 int lbc_head_bwd_rows(int N);

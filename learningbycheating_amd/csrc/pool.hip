@@ -5,12 +5,16 @@
 // 149-152.  The forward stores the arg-max tap (0..8, first maximum in row-major
 // order, as torch does) per pooled element so the backward never re-scans windows.
 #include "lbc_common.hpp"
+#include "lbc_act.hpp"
 #include "lbc_kernels.hpp"
 
 namespace {
 
+template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
 {
+    const T* y = static_cast<const T*>(a.y);
+    T* pout = static_cast<T*>(a.p);
     const int OH = a.H / 2, OW = a.W / 2;
     const int c4n = a.C / 4;
     const long long total = (long long)a.N * OH * OW * c4n;
@@ -22,11 +26,11 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
         const int oy = (int)(t % OH);
         const int n = (int)(t / OH);
         const int c = cg * 4;
-        const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
-        const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
         const float ninf = -INFINITY;
-        float4 best = make_float4(ninf, ninf, ninf, ninf);
-        int bx = 0, by = 0, bz = 0, bw = 0;
+        f32x4 best = {ninf, ninf, ninf, ninf};
+        int bi[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = 2 * oy - 1 + r;
@@ -35,20 +39,20 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
             for (int s = 0; s < 3; ++s) {
                 const int ix = 2 * ox - 1 + s;
                 if ((unsigned)ix >= (unsigned)a.W) continue;
-                float4 v = *reinterpret_cast<const float4*>(a.y + ((size_t)(n * a.H + iy) * a.W + (size_t)ix) * a.C + c);
-                v.x = fmaxf(v.x * sc.x + sh.x, 0.f); v.y = fmaxf(v.y * sc.y + sh.y, 0.f);
-                v.z = fmaxf(v.z * sc.z + sh.z, 0.f); v.w = fmaxf(v.w * sc.w + sh.w, 0.f);
+                f32x4 v = Act<T>::ld4(y + ((size_t)(n * a.H + iy) * a.W + (size_t)ix) * a.C + c);
+                v = v * sc + sh;
                 const int tap = r * 3 + s;
-                if (v.x > best.x) { best.x = v.x; bx = tap; }
-                if (v.y > best.y) { best.y = v.y; by = tap; }
-                if (v.z > best.z) { best.z = v.z; bz = tap; }
-                if (v.w > best.w) { best.w = v.w; bw = tap; }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float z = fmaxf(v[e], 0.f);
+                    if (z > best[e]) { best[e] = z; bi[e] = tap; }
+                }
             }
         }
-        reinterpret_cast<float4*>(a.p)[i] = best;
+        Act<T>::st4(pout + i * 4, best);
         if (a.idx) {
             uchar4 u;
-            u.x = (unsigned char)bx; u.y = (unsigned char)by; u.z = (unsigned char)bz; u.w = (unsigned char)bw;
+            u.x = (unsigned char)bi[0]; u.y = (unsigned char)bi[1]; u.z = (unsigned char)bi[2]; u.w = (unsigned char)bi[3];
             reinterpret_cast<uchar4*>(a.idx)[i] = u;
         }
     }
@@ -56,21 +60,25 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
 
 // Backward: for every stem-output element gather the pooled gradients whose arg-max
 // is this element, apply the ReLU mask, store g and reduce (sum g, sum g*xhat).
+template <typename T>
 __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
 {
     __shared__ __attribute__((aligned(16))) float red[2 * 256 * 4];
+    const T* dp = static_cast<const T*>(a.dp);
+    const T* y = static_cast<const T*>(a.y);
+    T* gout = static_cast<T*>(a.g);
     const int OH = a.H / 2, OW = a.W / 2;
     const int c4n = a.C / 4;
     const int rl = 256 / c4n;
     const int cg = threadIdx.x % c4n;
     const int pl = threadIdx.x / c4n;
     const int c = cg * 4;
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
     if (pl < rl) {
-        const float4 sc = *reinterpret_cast<const float4*>(a.scale + c);
-        const float4 sh = *reinterpret_cast<const float4*>(a.shift + c);
-        const float4 mean = *reinterpret_cast<const float4*>(a.mean + c);
-        const float4 inv = *reinterpret_cast<const float4*>(a.invstd + c);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
+        const f32x4 mean = *reinterpret_cast<const f32x4*>(a.mean + c);
+        const f32x4 inv = *reinterpret_cast<const f32x4*>(a.invstd + c);
         const long long pixels = (long long)a.N * a.H * a.W;
         const long long p0 = (long long)blockIdx.x * a.pix_per_block;
         long long p1 = p0 + a.pix_per_block;
@@ -78,50 +86,48 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
         for (long long p = p0 + pl; p < p1; p += rl) {
             const int x = (int)(p % a.W);
             const long long t = p / a.W;
-            const int y = (int)(t % a.H);
+            const int yy = (int)(t % a.H);
             const int n = (int)(t / a.H);
-            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-            const int oy0 = y >> 1, oy1 = (y + 1) >> 1;   // windows covering row y (equal when y is even)
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            const int oy0 = yy >> 1, oy1 = (yy + 1) >> 1;   // windows covering row y (equal when y is even)
             const int ox0 = x >> 1, ox1 = (x + 1) >> 1;
             for (int oy = oy0; oy <= oy1; ++oy) {
                 if (oy >= OH) continue;
-                const int r = y - (2 * oy - 1);
+                const int r = yy - (2 * oy - 1);
                 for (int ox = ox0; ox <= ox1; ++ox) {
                     if (ox >= OW) continue;
                     const int s = x - (2 * ox - 1);
                     const int tap = r * 3 + s;
                     const size_t o = ((size_t)(n * OH + oy) * OW + (size_t)ox) * c4n + cg;
                     const uchar4 u = reinterpret_cast<const uchar4*>(a.idx)[o];
-                    const float4 d = reinterpret_cast<const float4*>(a.dp)[o];
-                    if (u.x == tap) g.x += d.x;
-                    if (u.y == tap) g.y += d.y;
-                    if (u.z == tap) g.z += d.z;
-                    if (u.w == tap) g.w += d.w;
+                    const f32x4 d = Act<T>::ld4(dp + o * 4);
+                    if (u.x == tap) g[0] += d[0];
+                    if (u.y == tap) g[1] += d[1];
+                    if (u.z == tap) g[2] += d[2];
+                    if (u.w == tap) g[3] += d[3];
                 }
             }
-            const float4 v = reinterpret_cast<const float4*>(a.y)[p * c4n + cg];
-            g.x = (v.x * sc.x + sh.x) > 0.f ? g.x : 0.f; g.y = (v.y * sc.y + sh.y) > 0.f ? g.y : 0.f;
-            g.z = (v.z * sc.z + sh.z) > 0.f ? g.z : 0.f; g.w = (v.w * sc.w + sh.w) > 0.f ? g.w : 0.f;
-            reinterpret_cast<float4*>(a.g)[p * c4n + cg] = g;
-            s1.x += g.x; s1.y += g.y; s1.z += g.z; s1.w += g.w;
-            s2.x += g.x * (v.x - mean.x) * inv.x; s2.y += g.y * (v.y - mean.y) * inv.y;
-            s2.z += g.z * (v.z - mean.z) * inv.z; s2.w += g.w * (v.w - mean.w) * inv.w;
+            const f32x4 v = Act<T>::ld4(y + (p * c4n + cg) * 4);
+            const f32x4 z = v * sc + sh;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+            Act<T>::st4(gout + (p * c4n + cg) * 4, g);
+            s1 += g;
+            s2 += g * (v - mean) * inv;
         }
     }
-    reinterpret_cast<float4*>(red)[threadIdx.x] = s1;
-    reinterpret_cast<float4*>(red)[256 + threadIdx.x] = s2;
+    reinterpret_cast<f32x4*>(red)[threadIdx.x] = s1;
+    reinterpret_cast<f32x4*>(red)[256 + threadIdx.x] = s2;
     __syncthreads();
     if (threadIdx.x < c4n) {
-        float4 t1 = make_float4(0.f, 0.f, 0.f, 0.f), t2 = t1;
+        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
         for (int k = 0; k < rl; ++k) {
-            const float4 u = reinterpret_cast<const float4*>(red)[k * c4n + threadIdx.x];
-            const float4 w = reinterpret_cast<const float4*>(red)[256 + k * c4n + threadIdx.x];
-            t1.x += u.x; t1.y += u.y; t1.z += u.z; t1.w += u.w;
-            t2.x += w.x; t2.y += w.y; t2.z += w.z; t2.w += w.w;
+            t1 += reinterpret_cast<const f32x4*>(red)[k * c4n + threadIdx.x];
+            t2 += reinterpret_cast<const f32x4*>(red)[256 + k * c4n + threadIdx.x];
         }
         float* dst = a.partial + (size_t)blockIdx.x * 2 * a.C;
-        *reinterpret_cast<float4*>(dst + c) = t1;
-        *reinterpret_cast<float4*>(dst + a.C + c) = t2;
+        *reinterpret_cast<f32x4*>(dst + c) = t1;
+        *reinterpret_cast<f32x4*>(dst + a.C + c) = t2;
     }
 }
 
@@ -133,8 +139,10 @@ int lbc_bn_relu_maxpool_fwd(const PoolFwdArgs& a, hipStream_t s)
     const long long total = (long long)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
     long long blocks = (total + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    LbcProfScope prof("bn_relu_maxpool_fwd", 0.0, 4.0 * total * 4 * (4.0 + 1.0 + 0.25), s);
-    hipLaunchKernelGGL(bn_relu_maxpool_fwd_k, dim3((unsigned)blocks), dim3(256), 0, s, a);
+    LbcProfScope prof("bn_relu_maxpool_fwd", 0.0, (a.act_bf16 ? 2.0 : 4.0) * total * 4 * (4.0 + 1.0) + total * 4.0, s);
+#define LBC_K(T, g) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, blocks);
+#undef LBC_K
     return lbc_check_launch("bn_relu_maxpool_fwd");
 }
 
@@ -146,7 +154,9 @@ int lbc_maxpool_relu_bwd_reduce(PoolBwdArgs a, hipStream_t s)
     const long long pixels = (long long)a.N * a.H * a.W;
     const int rows = lbc_pool_bwd_rows(a.N, a.H, a.W, a.C);
     a.pix_per_block = (pixels + rows - 1) / rows;
-    LbcProfScope prof("maxpool_relu_bwd_reduce", 0.0, 4.0 * (double)pixels * a.C * (2.0 + 0.25 + 0.0625), s);
-    hipLaunchKernelGGL(maxpool_relu_bwd_reduce_k, dim3((unsigned)rows), dim3(256), 0, s, a);
+    LbcProfScope prof("maxpool_relu_bwd_reduce", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)pixels * a.C * (2.0 + 0.25) + (double)pixels * a.C * 0.25, s);
+#define LBC_K(T, g) hipLaunchKernelGGL((maxpool_relu_bwd_reduce_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, rows);
+#undef LBC_K
     return lbc_check_launch("maxpool_relu_bwd_reduce");
 }

@@ -11,6 +11,7 @@
 // channels_last order [64][7][7][Cin] has exactly the same [r][L] structure.
 // There is no input gradient (the image is a leaf).
 #include "lbc_common.hpp"
+#include "lbc_act.hpp"
 #include "lbc_kernels.hpp"
 
 namespace {
@@ -35,7 +36,7 @@ __global__ __launch_bounds__(256) void prep_input_k(const float* __restrict__ im
     }
 }
 
-template <int CIN>
+template <int CIN, typename T>
 __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
 {
     constexpr int L = 7 * CIN;
@@ -139,7 +140,7 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
             const int m = m0 + row;
             if (m < M) {
                 const float v = acc[mi][e];
-                a.y[(size_t)m * BN + col] = v;
+                Act<T>::st1(static_cast<T*>(a.y) + (size_t)m * BN + col, v);
                 s1 += v; s2 += v * v;
             }
         }
@@ -158,7 +159,7 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
 }
 
 // dW[co][r][j] = sum_m dy[m][co] * xp_row(m, r)[j]; grid (split, r)
-template <int CIN>
+template <int CIN, typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_per_split)
 {
     constexpr int L = 7 * CIN;
@@ -200,15 +201,15 @@ __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_pe
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 
-    float4 rp[2];
+    f32x4 rp[2];
     float rq[QPT];
     auto load_chunk = [&](int ch) {
         const int mc = mbeg + ch * BR;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int m = mc + prow0 + 16 * j;
-            rp[j] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m < mend) rp[j] = *reinterpret_cast<const float4*>(a.dy + (size_t)m * 64 + (size_t)(pseg * 4));
+            rp[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (m < mend) rp[j] = Act<T>::ld4(static_cast<const T*>(a.dy) + (size_t)m * 64 + (size_t)(pseg * 4));
         }
         const bool ok = (mc + qrow) < mend;
         const long long base = (long long)((qn * Hp + 2 * qy + r) * Wp + 2 * qx) * CIN + qseg * QPT;
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_pe
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) *reinterpret_cast<float4*>(&sP[buf][(prow0 + 16 * j) * LDP + pseg * 4]) = rp[j];
+        for (int j = 0; j < 2; ++j) *reinterpret_cast<f32x4*>(&sP[buf][(prow0 + 16 * j) * LDP + pseg * 4]) = rp[j];
 #pragma unroll
         for (int q = 0; q < QPT; q += 2)
             *reinterpret_cast<float2*>(&sQ[buf][qrow * LDQ + qseg * QPT + q]) = make_float2(rq[q], rq[q + 1]);
@@ -299,8 +300,10 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
     const dim3 grid((unsigned)lbc_stem_rows(a));
     const double Ms = (double)a.N * (a.H / 2) * (a.W / 2);
     LbcProfScope prof("stem_fwd", 2.0 * Ms * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + Ms * 64), s);
-    if (a.Cin == 3) hipLaunchKernelGGL((stem_fwd_k<3>), grid, dim3(256), 0, s, a);
-    else            hipLaunchKernelGGL((stem_fwd_k<7>), grid, dim3(256), 0, s, a);
+#define LBC_K(T, CI) hipLaunchKernelGGL((stem_fwd_k<CI, T>), grid, dim3(256), 0, s, a)
+    if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
+    else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
+#undef LBC_K
     return lbc_check_launch("stem_fwd");
 }
 
@@ -321,7 +324,9 @@ int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s)
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 32;
     const dim3 grid((unsigned)a.nsplit, 7);
     LbcProfScope prof("stem_wgrad", 2.0 * M * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (double)M * 64), s);
-    if (a.Cin == 3) hipLaunchKernelGGL((stem_wgrad_k<3>), grid, dim3(256), 0, s, a, rows_per_split);
-    else            hipLaunchKernelGGL((stem_wgrad_k<7>), grid, dim3(256), 0, s, a, rows_per_split);
+#define LBC_K(T, CI) hipLaunchKernelGGL((stem_wgrad_k<CI, T>), grid, dim3(256), 0, s, a, rows_per_split)
+    if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
+    else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
+#undef LBC_K
     return lbc_check_launch("stem_wgrad");
 }

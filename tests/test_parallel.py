@@ -141,3 +141,32 @@ def test_data_parallel_gradients_emulated_gloo_world2():
         p.join(120)
         assert p.exitcode == 0
     assert err <= 1e-6 * scale + 1e-12, (err, scale)
+
+
+@pytest.mark.gpu
+def test_staged_allreduce_on_rccl_single_rank():
+    """the RCCL code path itself (side stream, events, async all_reduce, wait) on the one GPU available: a 1-rank nccl
+    group must leave the gradients bit-identical and must not deadlock; multi-rank correctness is covered by the gloo tests"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        from learningbycheating_amd.parallel import StageAllReducer, broadcast_module
+        offs, total = _offsets_for_image_model()
+        dev = torch.device("cuda", 0)
+        flat = torch.randn(total, device=dev)
+        ref = flat.clone()
+        red = StageAllReducer(flat, offs, force=True)
+        assert red.active and red.comm is not None
+        for rep in range(2):
+            for st in range(6):
+                flat[red.ranges[st][0]:red.ranges[st][1]].mul_(1.0)      # "backward stage" work on the compute stream
+                red.launch(st)
+            red.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, ref)
+        broadcast_module(torch.nn.Linear(4, 4).to(dev))
+    finally:
+        dist.destroy_process_group()
