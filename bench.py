@@ -87,7 +87,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--dtype", choices=["f32", "bf16"], default="bf16",
+    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16_act"], default="bf16",
                     help="f32: exact-f32 MFMA everywhere (the parity path). bf16: convolution MFMA operands rounded to bf16, f32 "
                          "accumulation, f32 master weights/activations/BatchNorm/soft-argmax/loss/Adam (BASELINE.json config 3)")
     ap.add_argument("--init-steps", type=int, default=40, help="below-horizon warm start (stands in for the phase-0 checkpoint)")
@@ -131,7 +131,7 @@ def main():
 
     def timed_run(dtype, steps, warmup):
         student, teacher = build_models(device)
-        student.precision = teacher.precision = {"f32": "fp32", "bf16": "bf16"}[dtype]
+        student.precision = teacher.precision = {"f32": "fp32", "bf16": "bf16", "bf16_act": "bf16_act"}[dtype]
         broadcast_module(student); broadcast_module(teacher)
         warm = NativeTrainer(student, None, per_gpu, (3, 160, 384), device, phase="l1_all", lr=1e-3, world_size=world)
         for _ in range(args.init_steps):
@@ -180,8 +180,8 @@ def main():
         ms = sum(v["ms"] for v in conv); gf = sum(v["gflop"] for v in conv); n = sum(v["launches"] for v in conv)
         total_ms = sum(v["ms"] for v in breakdown.values())
         ach = gf / ms if ms > 0 else 0.0     # GFLOP / ms = TFLOP/s
-        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype == "bf16" else PEAK_FP32_MFMA_TFLOPS
-        kname = "conv_igemm_k / conv_wgrad_bf16_k (v_mfma_f32_32x32x16_bf16)" if args.dtype == "bf16" else "conv_igemm_k / conv_wgrad_f32 (v_mfma_f32_32x32x2_f32)"
+        peak = PEAK_BF16_MFMA_TFLOPS if args.dtype != "f32" else PEAK_FP32_MFMA_TFLOPS
+        kname = "conv_igemm_k / conv_wgrad_bf16_k (v_mfma_f32_32x32x16_bf16)" if args.dtype != "f32" else "conv_igemm_k / conv_wgrad_f32 (v_mfma_f32_32x32x2_f32)"
         roof = {"bound": "mfma", "kernel": kname, "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "gflop_per_launch": round(gf / max(n, 1), 3),
@@ -198,14 +198,14 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "ImagePolicyModelSS(resnet34) phase-1 step vs BirdViewPolicyModelSS(resnet18) teacher, "
                                       "160x384 RGB + 7x192x192 bird-view, global batch %d (%d/GPU), %s, local BatchNorm, "
-                                      "Adam lr 1e-4" % (args.global_batch, per_gpu, "bf16 MFMA operands + f32 accumulate/master/BN/loss/Adam" if args.dtype == "bf16" else "exact-f32 MFMA"),
+                                      "Adam lr 1e-4" % (args.global_batch, per_gpu, {"bf16": "bf16 MFMA operands + f32 accumulate/master/BN/loss/Adam", "bf16_act": "bf16 MFMA operands and bf16 activation storage + f32 accumulate/master/BN/loss/Adam", "f32": "exact-f32 MFMA"}[args.dtype]),
                           "global_batch": args.global_batch, "parallelism": "dp%d" % world},
                "loss": loss_mean, "loss_finite": bool(loss_mean == loss_mean and abs(loss_mean) != float("inf")),
                "algorithmic_tflops": round(value * FLOP_PER_IMAGE_STEP / 1e12, 2),
                "roofline": roof}
         out["_alt"] = None
     also = None
-    if args.dtype == "bf16" and not args.no_alt:
+    if args.dtype != "f32" and not args.no_alt:
         # the exact-f32 parity path on the same workload, a short run reported next to the headline number
         del tr
         torch.cuda.empty_cache()

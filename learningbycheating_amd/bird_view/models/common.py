@@ -94,7 +94,8 @@ class PolicyBase(ResnetBase):
     """Executor plumbing shared by the two policy models."""
     _normalize = False
     #: "fp32" (default, the parity path: exact-f32 MFMA) or "bf16" (convolution MFMA operands rounded to bf16, f32
-    #: accumulation; weights, activations, BatchNorm, soft-argmax, loss and Adam stay f32).  Set before the first forward.
+    #: accumulation; weights, activations, BatchNorm, soft-argmax, loss and Adam stay f32) or "bf16_act" (as "bf16", and
+    #: activations / activation gradients are stored as bf16 in HBM; f32 master weights).  Set before the first forward.
     precision = "fp32"
 
     def _finish_init(self):
@@ -118,7 +119,7 @@ class PolicyBase(ResnetBase):
 
     def _engine_for(self, image, with_grads):
         n, c, h, w = image.shape
-        prec = {"fp32": 0, "bf16": 1}[self.precision]
+        prec = {"fp32": 0, "bf16": 1, "bf16_act": 2}[self.precision]
         key = (h, w, str(image.device), prec)
         eng = self._engines.get(key)
         if eng is None or eng.max_batch < n:

@@ -147,6 +147,29 @@ class _RoundGradBF16(torch.autograd.Function):
         return _rbf(g)
 
 
+# Emulation of precision = 2 on top of MFMA_BF16: every activation tensor the executor keeps in HBM (raw convolution
+# outputs, block outputs, the pooled stem output, the velocity-concatenated map, decoder outputs) is rounded to bf16 where
+# it is stored, and so is the gradient that flows back into it (activation gradients are stored as bf16 too).  The
+# executor's BatchNorm statistics come from the f32 accumulators; here they see the rounded tensor (a 2^-9-relative,
+# zero-mean difference).
+ACT_BF16 = False
+
+
+class _RoundBothBF16(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _rbf(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _rbf(g)
+
+
+def _st(x):
+    """a tensor the executor stores in HBM"""
+    return _RoundBothBF16.apply(x) if ACT_BF16 else x
+
+
 def _conv(x, w, bias, stride, pad):
     if MFMA_BF16:
         return _RoundGradBF16.apply(F.conv2d(_rbf(x), _rbf(w), None, stride, pad)) + (0 if bias is None else bias.view(1, -1, 1, 1))
@@ -188,9 +211,9 @@ def calibrate_running_stats(sd, kind, backbone, x, velocity, command):
 
 def trunk(sd, backbone, x, train, taps=None):
     """ResNet.forward (resnet.py:148-159) with BasicBlock.forward (resnet.py:38-54)."""
-    x = F.conv2d(x, sd["conv.conv1.weight"], None, 2, 3)
+    x = _st(F.conv2d(x, sd["conv.conv1.weight"], None, 2, 3))
     x = F.relu(_bn(sd, "conv.bn1", x, train))
-    x = F.max_pool2d(x, 3, 2, 1)
+    x = _st(F.max_pool2d(x, 3, 2, 1))
     if taps is not None:
         taps["pool"] = x
     inpl = 64
@@ -200,13 +223,13 @@ def trunk(sd, backbone, x, train, taps=None):
             p = "conv.layer%d.%d" % (li + 1, bi)
             stride = 2 if (li > 0 and bi == 0) else 1
             identity = x
-            out = _conv(x, sd[p + ".conv1.weight"], None, stride, 1)
+            out = _st(_conv(x, sd[p + ".conv1.weight"], None, stride, 1))
             out = F.relu(_bn(sd, p + ".bn1", out, train))
-            out = _conv(out, sd[p + ".conv2.weight"], None, 1, 1)
+            out = _st(_conv(out, sd[p + ".conv2.weight"], None, 1, 1))
             out = _bn(sd, p + ".bn2", out, train)
             if stride != 1 or inpl != planes:
-                identity = _bn(sd, p + ".downsample.1", _conv(x, sd[p + ".downsample.0.weight"], None, stride, 0), train)
-            x = F.relu(out + identity)
+                identity = _bn(sd, p + ".downsample.1", _st(_conv(x, sd[p + ".downsample.0.weight"], None, stride, 0)), train)
+            x = _st(F.relu(out + identity))
             inpl = planes
         if taps is not None:
             taps["layer%d" % (li + 1)] = x
@@ -237,11 +260,11 @@ def policy_forward(sd, kind, backbone, x, velocity, command, train, taps=None):
     h = trunk(sd, backbone, x, train, taps)
     b, c, kh, kw = h.shape
     vel = velocity[..., None, None, None].repeat((1, 128, kh, kw))              # image.py:77
-    h = torch.cat((h, vel), dim=1)
+    h = _st(torch.cat((h, vel), dim=1))
     for i in range(3):                                                          # image.py:37-47
         h = _bn(sd, "deconv.%d" % (3 * i), h, train)
         h = _deconv(h, sd["deconv.%d.weight" % (3 * i + 1)], sd["deconv.%d.bias" % (3 * i + 1)])
-        h = F.relu(h)
+        h = _st(F.relu(h))
     if taps is not None:
         taps["decoder"] = h
     preds = []

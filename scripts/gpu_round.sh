@@ -34,6 +34,14 @@ if [[ "$PHASES" == *bf16* ]]; then
   echo "bench bf16 exit $?" >> gpurun_out/summary.txt
   tail -1 gpurun_out/bench_bf16.log | cut -c1-900 >> gpurun_out/summary.txt
 fi
+if [[ "$PHASES" == *act* ]]; then
+  # precision 2: bf16 MFMA operands + bf16 activation storage
+  timeout 900 python bench.py --dtype bf16_act --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_bf16_act.json > gpurun_out/bench_bf16_act.log 2>&1
+  echo "bench bf16_act exit $?" >> gpurun_out/summary.txt
+  tail -1 gpurun_out/bench_bf16_act.log | cut -c1-900 >> gpurun_out/summary.txt
+  timeout 600 python bench.py --dtype bf16_act --global-batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_b32_bf16_act.json > gpurun_out/bench_b32_bf16_act.log 2>&1
+  echo "bench b32 bf16_act: $(tail -1 gpurun_out/bench_b32_bf16_act.log | cut -c1-260)" >> gpurun_out/summary.txt
+fi
 if [[ "$PHASES" == *diag* ]]; then
   for v in NONE LBC_NO_FUSE_Z1 LBC_NO_DGRAD_WT; do
     env $v=1 timeout 600 python scripts/diag_grads.py ${DIAG_ARGS:-birdview resnet18 192 192 4} > gpurun_out/diag_$v.log 2>&1

@@ -14,14 +14,19 @@ def nchw(t):
     return t.permute(0, 3, 1, 2).contiguous()
 
 
-def guarded(shape, device, fill=float("nan")):
+def guarded(shape, device, fill=float("nan"), dtype=torch.float32):
     """tensor placed in the middle of a NaN-filled buffer: out-of-range writes/reads show up"""
     n = 1
     for s in shape:
         n *= s
     pad = 256
-    buf = torch.full((n + 2 * pad,), fill, dtype=torch.float32, device=device)
+    buf = torch.full((n + 2 * pad,), fill, dtype=dtype, device=device)
     return buf, buf[pad:pad + n].view(shape)
+
+
+def act_dtype(bf16):
+    """element type of the activation tensors for lbc_conv_desc.bf16 (2 = bf16 tensors in HBM)"""
+    return torch.bfloat16 if bf16 == 2 else torch.float32
 
 
 def check_guard(buf, n):
@@ -48,38 +53,41 @@ class Conv:
         K, _, k, _ = w.shape
         d = self.desc(N, H, W, C, K, k, stride, pad, relu, bf16)
         OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-        xh, wh = nhwc(x).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
-        buf, y = guarded((N, OH, OW, K), self.dev)
+        at = act_dtype(bf16)
+        xh, wh = nhwc(x).to(self.dev).to(at), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        buf, y = guarded((N, OH, OW, K), self.dev, dtype=at)
         rows = ctypes.c_int(0)
         _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
         st = torch.zeros((rows.value, 2, K), device=self.dev) if stats else None
-        keep = [t.to(self.dev) if t is not None else None for t in (bias, nhwc(resid) if resid is not None else None,
+        keep = [t.to(self.dev) if t is not None else None for t in (bias, nhwc(resid).to(at) if resid is not None else None,
                                                                       pre[0] if pre else None, pre[1] if pre else None)]
         _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(wh), _lib.ptr(keep[0]), _lib.ptr(keep[1]),
                                            _lib.ptr(keep[2]), _lib.ptr(keep[3]), 1 if (pre and pre[2]) else 0, _lib.ptr(y),
                                            _lib.ptr(st), ctypes.byref(rows), _lib.stream_for(xh)))
         check_guard(buf, y.numel())
-        return nchw(y).cpu(), (st.cpu() if stats else None)
+        return nchw(y).float().cpu(), (st.cpu() if stats else None)
 
     def dgrad(self, dy, w, H, W, stride, pad, resid=None, bf16=0, transposed=False):
         N, K = dy.shape[:2]
         _, C, k, _ = w.shape
         d = self.desc(N, H, W, C, K, k, stride, pad, 0, bf16, 1 if transposed else 0)
-        dyh, wh = nhwc(dy).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        at = act_dtype(bf16)
+        dyh, wh = nhwc(dy).to(self.dev).to(at), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
         if transposed:
             wh = self.transpose(wh.view(K, k * k, C), K, k * k, C)
-        r = nhwc(resid).to(self.dev) if resid is not None else None
-        buf, dx = guarded((N, H, W, C), self.dev)
+        r = nhwc(resid).to(self.dev).to(at) if resid is not None else None
+        buf, dx = guarded((N, H, W, C), self.dev, dtype=at)
         _lib.check(self.lib.lbc_conv2d_dgrad(ctypes.byref(d), _lib.ptr(dyh), _lib.ptr(wh), _lib.ptr(r), _lib.ptr(dx), _lib.stream_for(dyh)))
         check_guard(buf, dx.numel())
-        return nchw(dx).cpu()
+        return nchw(dx).float().cpu()
 
     def wgrad(self, x, dy, k, stride, pad, pre=None, beta=0.0, dw0=None, bf16=0):
         N, C, H, W = x.shape
         K = dy.shape[1]
         d = self.desc(N, H, W, C, K, k, stride, pad, 0, bf16)
         ws = torch.empty(self.lib.lbc_conv2d_wgrad_workspace(ctypes.byref(d)) // 4 + 1, device=self.dev)
-        xh, dyh = nhwc(x).to(self.dev), nhwc(dy).to(self.dev)
+        at = act_dtype(bf16)
+        xh, dyh = nhwc(x).to(self.dev).to(at), nhwc(dy).to(self.dev).to(at)
         buf, dw = guarded((K, k, k, C), self.dev)
         if dw0 is not None:
             dw.copy_(dw0.permute(0, 2, 3, 1))
@@ -95,20 +103,21 @@ class Conv:
         K = w.shape[1]
         d = self.desc(N, H, W, C, K, 3, 2, 1, relu, bf16)
         dfwd = self.desc(N, H, W, C, K, 3, 2, 1, relu, bf16, 1 if bf16 else 0)
-        xh, wh = nhwc(x).to(self.dev), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        at = act_dtype(bf16)
+        xh, wh = nhwc(x).to(self.dev).to(at), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
         wfwd = self.transpose(wh.view(C, 9, K), C, 9, K) if bf16 else wh
         ps, pt, b = pre[0].to(self.dev), pre[1].to(self.dev), bias.to(self.dev)
         rows = ctypes.c_int(0)
         _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(dfwd), None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
         st = torch.zeros((rows.value, 2, K), device=self.dev)
-        buf, y = guarded((N, 2 * H, 2 * W, K), self.dev)
+        buf, y = guarded((N, 2 * H, 2 * W, K), self.dev, dtype=at)
         _lib.check(self.lib.lbc_deconv3x3s2_fwd(ctypes.byref(dfwd), _lib.ptr(xh), _lib.ptr(wfwd), _lib.ptr(b), _lib.ptr(ps), _lib.ptr(pt), 0,
                                                 _lib.ptr(y), _lib.ptr(st), ctypes.byref(rows), _lib.stream_for(xh)))
         check_guard(buf, y.numel())
 
         def bwd(dy):
-            dyh = nhwc(dy).to(self.dev)
-            bufx, dx = guarded((N, H, W, C), self.dev)
+            dyh = nhwc(dy).to(self.dev).to(at)
+            bufx, dx = guarded((N, H, W, C), self.dev, dtype=at)
             _lib.check(self.lib.lbc_deconv3x3s2_dgrad(ctypes.byref(d), _lib.ptr(dyh), _lib.ptr(wh), _lib.ptr(dx), _lib.stream_for(dyh)))
             check_guard(bufx, dx.numel())
             ws = torch.empty(self.lib.lbc_deconv3x3s2_wgrad_workspace(ctypes.byref(d)) // 4 + 1, device=self.dev)
@@ -116,8 +125,8 @@ class Conv:
             _lib.check(self.lib.lbc_deconv3x3s2_wgrad(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(dyh), _lib.ptr(ps), _lib.ptr(pt), 0,
                                                       _lib.ptr(dw), 0.0, _lib.ptr(ws), _lib.stream_for(xh)))
             check_guard(bufw, dw.numel())
-            return nchw(dx).cpu(), dw.permute(0, 3, 1, 2).contiguous().cpu()
-        return nchw(y).cpu(), st.cpu(), bwd
+            return nchw(dx).float().cpu(), dw.permute(0, 3, 1, 2).contiguous().cpu()
+        return nchw(y).float().cpu(), st.cpu(), bwd
 
 
 def relerr(a, b):

@@ -150,26 +150,50 @@ BF_REAL = [pytest.param(c, marks=gpu) for c in [(8, 40, 96, 64, 64, 3, 1, 1), (8
                                                  (16, 5, 12, 512, 512, 3, 1, 1), (2, 10, 24, 256, 512, 1, 2, 0)]]
 
 
+# mode 1: f32 tensors, operands rounded inside the kernel.  mode 2: the activation tensors themselves are bf16 in HBM
+# (inputs pre-rounded, outputs rounded once on store -> half a bf16 ulp = 2^-9 relative on top of mode 1's error)
+MODES = [1, 2]
+OUT_TOL = {1: 0.0, 2: 2.0 ** -8}
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cfg", BF_SMALL + BF_REAL)
-def test_conv_fwd_bf16_mode(env, cfg):
+def test_conv_fwd_bf16_mode(env, cfg, mode):
     """against an f32 convolution of the bf16-rounded operands (tight), and against the unrounded one (bf16-level)"""
     dev, _ = env
     N, H, W, C, K, k, s, p = cfg
     x, w = make(cfg, 20)
+    if mode == 2:
+        x = rbf(x)
     g = torch.Generator().manual_seed(21)
     ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
     xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))      # BN+ReLU on load happens in f32, before the rounding
     ref = F.conv2d(rbf(xin), rbf(w), None, s, p)
-    y, st = Conv(dev).fwd(x, w, s, p, pre=(ps, pt, True), stats=True, bf16=1)
+    y, st = Conv(dev).fwd(x, w, s, p, pre=(ps, pt, True), stats=True, bf16=mode)
     # not tighter: the on-load affine is an fma on the GPU and mul+add in torch, and a 1-ulp f32 difference that straddles
     # a bf16 rounding boundary moves that operand by 2^-8 relative (measured 2e-5 .. 1.3e-4 on the layer shapes)
-    assert relerr(y, ref) < 5e-4
+    assert relerr(y, ref) < 5e-4 + OUT_TOL[mode]
     assert relerr(y, F.conv2d(xin, w, None, s, p)) < 2e-2
-    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)   # statistics come from the f32 accumulators
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_conv_fwd_bf16_residual_relu(env, mode):
+    """epilogue with residual (+ReLU): the residual is read in the tensors' element type"""
+    dev, _ = env
+    cfg = (2, 6, 8, 64, 64, 3, 1, 1)
+    x, w = make(cfg, 40)
+    r = torch.randn((2, 64, 6, 8), generator=torch.Generator().manual_seed(41))
+    if mode == 2:
+        x, r = rbf(x), rbf(r)
+    ref = F.relu(F.conv2d(rbf(x), rbf(w), None, 1, 1) + r)
+    y, _ = Conv(dev).fwd(x, w, 1, 1, resid=r, relu=1, bf16=mode)
+    assert relerr(y, ref) < 1e-4 + OUT_TOL[mode]
+
+
+@pytest.mark.parametrize("mode", MODES)
 @pytest.mark.parametrize("cfg", BF_SMALL + [(40, 5, 6, 64, 64, 3, 1, 1)] + BF_REAL)
-def test_conv_wgrad_bf16_mode(env, cfg):
+def test_conv_wgrad_bf16_mode(env, cfg, mode):
     dev, _ = env
     N, H, W, C, K, k, s, p = cfg
     x, w = make(cfg, 22)
@@ -177,12 +201,32 @@ def test_conv_wgrad_bf16_mode(env, cfg):
     y = F.conv2d(rbf(x), w, None, s, p)
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(23))
     y.backward(rbf(dy))
-    dw = Conv(dev).wgrad(x, dy, k, s, p, bf16=1)
+    dw = Conv(dev).wgrad(rbf(x) if mode == 2 else x, rbf(dy) if mode == 2 else dy, k, s, p, bf16=mode)
     assert relerr(dw, w.grad) < 1e-4
 
 
+@pytest.mark.parametrize("mode", MODES)
+def test_conv_wgrad_bf16_bn_relu_on_load(env, mode):
+    """conv2's weight gradient reads y1 with bn1 + ReLU applied on load (f32), then rounds the operand"""
+    dev, _ = env
+    cfg = (3, 6, 8, 64, 128, 3, 1, 1)
+    x, w = make(cfg, 42)
+    g = torch.Generator().manual_seed(43)
+    ps, pt = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    if mode == 2:
+        x = rbf(x)
+    xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    w = w.requires_grad_(True)
+    y = F.conv2d(rbf(xin), w, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(rbf(dy))
+    dw = Conv(dev).wgrad(x, rbf(dy) if mode == 2 else dy, 3, 1, 1, pre=(ps, pt, True), bf16=mode)
+    assert relerr(dw, w.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
+
+
 @pytest.mark.parametrize("cfg", BF_SMALL[:3] + [pytest.param((4, 20, 48, 128, 128, 3, 1, 1), marks=gpu), pytest.param((2, 20, 48, 128, 256, 3, 2, 1), marks=gpu)])
-def test_conv_dgrad_bf16_mode_and_transposed_weights(env, cfg):
+@pytest.mark.parametrize("mode", MODES)
+def test_conv_dgrad_bf16_mode_and_transposed_weights(env, cfg, mode):
     dev, _ = env
     N, H, W, C, K, k, s, p = cfg
     x, w = make(cfg, 24)
@@ -190,8 +234,9 @@ def test_conv_dgrad_bf16_mode_and_transposed_weights(env, cfg):
     y = F.conv2d(x, rbf(w), None, s, p)
     dy = torch.randn(y.shape, generator=torch.Generator().manual_seed(25))
     y.backward(rbf(dy))
-    dx = Conv(dev).dgrad(dy, w, H, W, s, p, bf16=1, transposed=True)
-    assert relerr(dx, x.grad) < 1e-4
+    r = rbf(torch.randn(x.shape, generator=torch.Generator().manual_seed(27)))
+    dx = Conv(dev).dgrad(rbf(dy) if mode == 2 else dy, w, H, W, s, p, resid=r, bf16=mode, transposed=True)
+    assert relerr(dx, x.grad + r) < 1e-4 + OUT_TOL[mode]
     # the transposed-weight route in exact f32 as well
     x.grad = None
     F.conv2d(x, w, None, s, p).backward(dy)
@@ -199,11 +244,14 @@ def test_conv_dgrad_bf16_mode_and_transposed_weights(env, cfg):
 
 
 @pytest.mark.parametrize("cfg", [(2, 3, 4, 64, 64), (1, 5, 12, 128, 64)] + [pytest.param((4, 5, 12, 640, 256), marks=gpu), pytest.param((2, 20, 48, 128, 64), marks=gpu)])
-def test_deconv_bf16_mode(env, cfg):
+@pytest.mark.parametrize("mode", MODES)
+def test_deconv_bf16_mode(env, cfg, mode):
     dev, _ = env
     N, H, W, C, K = cfg
     g = torch.Generator().manual_seed(26)
     x = torch.randn((N, C, H, W), generator=g)
+    if mode == 2:
+        x = rbf(x)
     w = (torch.randn((C, K, 3, 3), generator=g) * (2.0 / (C * 2.25)) ** 0.5).requires_grad_(True)
     b = torch.randn(K, generator=g)
     ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
@@ -211,12 +259,12 @@ def test_deconv_bf16_mode(env, cfg):
     wr = rbf(w.detach()).requires_grad_(True)
     u = F.conv_transpose2d(rbf(xn), wr, b, 2, 1, 1)
     ref = F.relu(u)
-    y, st, bwd = Conv(dev).deconv_all(x, w.detach(), b, (ps, pt), relu=1, bf16=1)
-    assert relerr(y, ref) < 5e-4          # see test_conv_fwd_bf16_mode
-    dy = torch.randn(u.shape, generator=g)
+    y, st, bwd = Conv(dev).deconv_all(x, w.detach(), b, (ps, pt), relu=1, bf16=mode)
+    assert relerr(y, ref) < 5e-4 + OUT_TOL[mode]          # see test_conv_fwd_bf16_mode
+    dy = rbf(torch.randn(u.shape, generator=g))
     # reference backward with the executor's rounding points: dy rounded; dx = gather over rounded dy with rounded w;
     # dw = rounded bn(x) x rounded dy
     xr = rbf(xn.detach()).requires_grad_(True)
     F.conv_transpose2d(xr, wr, None, 2, 1, 1).backward(rbf(dy))
     dx, dw = bwd(dy)
-    assert relerr(dx, xr.grad) < 1e-4 and relerr(dw, wr.grad) < 5e-4
+    assert relerr(dx, xr.grad) < 1e-4 + OUT_TOL[mode] and relerr(dw, wr.grad) < 5e-4

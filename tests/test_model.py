@@ -367,9 +367,10 @@ def test_native_trainer_runs_and_is_deterministic(env):
     assert not torch.equal(before, student.deconv[1].weight.detach())
 
 
+@pytest.mark.parametrize("precision", [1, 2])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),
                                                  pytest.param("birdview", "resnet18", 192, 192, 8, marks=gpu)])
-def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n):
+def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision):
     """precision=1: convolution MFMA operands rounded to bf16, everything else f32.  Every kernel of this mode is checked
     tightly in tests/test_kernels.py against rounded-operand references; end to end the comparison can only be
     statistical, because a bf16 rounding boundary (relative step 2^-8) crossed by one element after a 1e-7 perturbation
@@ -378,9 +379,10 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n):
     dev, _ = env
     sd = O.make_state_dict(kind, backbone, 3, h, w)
     x, speed, cmd = _inputs(kind, n, h, w, 4)
-    eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=1)
+    eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
     ps, pa = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
     O.MFMA_BF16 = True
+    O.ACT_BF16 = precision == 2   # precision 2: activations and their gradients are also stored as bf16
     try:
         sp = O.as_params(sd)
         ops, opa = O.policy_forward(sp, kind, backbone, x, speed, cmd, True)
@@ -389,7 +391,7 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n):
         eng.backward(d_sel.to(dev), d_all.to(dev))
         ((opa * d_all).sum() + (ops * d_sel).sum()).backward()
     finally:
-        O.MFMA_BF16 = False
+        O.MFMA_BF16 = O.ACT_BF16 = False
     err = (pa.cpu() - opa).abs().max().item()
     assert err < 6e-2, err
     assert (pa.cpu() - opa).abs().mean().item() < 1e-2
@@ -402,4 +404,4 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n):
     # measured on MI355X (r34, 160x384, N=8): median 0.88, minimum 0.80 -- two bf16 evaluations of an untrained 34-layer
     # BatchNorm network decorrelate at this level; a wrong kernel gives ~0
     assert cos[len(cos) // 2] > 0.8 and cos[len(cos) // 10] > 0.6, (cos[:5], cos[len(cos) // 2])
-    print("bf16 mode: max |pred - oracle_bf16| = %.3e, median gradient cosine = %.4f, p10 = %.4f" % (err, cos[len(cos) // 2], cos[len(cos) // 10]))
+    print("bf16 mode %d: max |pred - oracle_bf16| = %.3e, median gradient cosine = %.4f, p10 = %.4f" % (precision, err, cos[len(cos) // 2], cos[len(cos) // 10]))
