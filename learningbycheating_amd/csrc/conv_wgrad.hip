@@ -14,6 +14,7 @@
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -190,12 +191,29 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
 // micro-tiles, transposes them in registers (free) and writes four 8-byte rows [channel][4 pixels]: LDS tiles are
 // [channel][64 pixels] and fragments are plain conflict-free ds_read_b128, with no extra LDS traffic.
 // AT = element type of P and Q in HBM: float (micro-tiles of 4 pixels x 4 channels) or __bf16 (4 pixels x 8 channels).
-template <int BP, int BQ, typename AT>
+//
+// Staging: a thread owns micro-tiles of 4 consecutive pixels x CH channels (one 16-byte load per pixel), transposes them
+// in registers and writes CH 8-byte columns into the [channel][64 pixels] LDS tiles (rows padded to 144 B, which keeps
+// the ds_read_b128 fragment reads conflict-free).  ds_write_b64 is serviced in groups of 16 consecutive lanes over 32
+// banks, and a row is 36 dwords, so lanes of a group that differ only in their channel group (8 rows = 288 dwords = 0
+// mod 32) collide: the micro-tile index therefore puts KB channel-group bits and 4-KB pixel-group bits into the low 4
+// lane bits (KB = 1: f32 input conflict-free, bf16 input 2-way; loads still cover whole 128-byte lines per wave).
+template <int CG, int KB>
+__device__ __forceinline__ void wgrad_tile_coord(int u, int& cg, int& pg)
+{
+    constexpr int LCG = CG == 32 ? 5 : CG == 16 ? 4 : CG == 8 ? 3 : 2;
+    static_assert(KB <= LCG && KB <= 4, "wgrad: lane mapping");
+    cg = (u & ((1 << KB) - 1)) | (((u >> 4) & ((1 << (LCG - KB)) - 1)) << KB);
+    pg = ((u >> KB) & ((1 << (4 - KB)) - 1)) | (((u >> (4 + LCG - KB)) & ((1 << KB) - 1)) << (4 - KB));
+}
+
+template <int BP, int BQ, typename AT, int KB>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_per_split)
 {
     constexpr bool ABF = Act<AT>::kBf16;
-    using areg_t = typename std::conditional<ABF, bf16x8, f32x4>::type;
-    constexpr int CH = ABF ? 8 : 4;         // channels per 16-byte load
+    // channels per load: 16-byte loads, except bf16 input on the 64-wide tiles (8-byte loads keep all 256 threads staging)
+    constexpr int CH = (ABF && BP >= 128) ? 8 : 4;
+    using areg_t = typename std::conditional<ABF, typename std::conditional<CH == 8, bf16x8, bf16x4>::type, f32x4>::type;
     constexpr int BRH = 64;                 // pixels per chunk
     constexpr int LD = BRH + 8;             // padded LDS row (bf16 elements) = 144 bytes
     constexpr int WM = 2, WN = 2;
@@ -245,9 +263,35 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
     bool pok[NP][4], qok[NQ][4];
     // coordinates of the first pixel of each Q micro-tile, advanced by BRH per chunk
     int qn[NQ], qy[NQ], qx[NQ];
+    // per-thread on-load affine of its channels (identity when absent: x*1+0 and max(x,-inf) are exact)
+    const float relu_floor = (a.q_scale && a.q_relu) ? 0.f : -INFINITY;
+    float psc[NP][CH], psh[NP][CH], qsc[NQ][CH], qsh[NQ][CH];
+#pragma unroll
+    for (int t = 0; t < NP; ++t) {
+        int cg, pg;
+        wgrad_tile_coord<CGP, KB>(tid + 256 * t, cg, pg);
+        cg = (tid + 256 * t < TP_) ? cg : 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            psc[t][c] = a.p_scale ? a.p_scale[p0 + cg * CH + c] : 1.f;
+            psh[t][c] = a.p_scale ? a.p_shift[p0 + cg * CH + c] : 0.f;
+        }
+    }
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
-        const int pg = ((tid + 256 * t) / CGQ) & 15;
+        int cg, pg;
+        wgrad_tile_coord<CGQ, KB>(tid + 256 * t, cg, pg);
+        cg = (tid + 256 * t < TQ_) ? cg : 0;
+#pragma unroll
+        for (int c = 0; c < CH; ++c) {
+            qsc[t][c] = a.q_scale ? a.q_scale[q0 + cg * CH + c] : 1.f;
+            qsh[t][c] = a.q_scale ? a.q_shift[q0 + cg * CH + c] : 0.f;
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+        int cg, pg;
+        wgrad_tile_coord<CGQ, KB>(tid + 256 * t, cg, pg);
         const int m = mbeg + 4 * pg;
         const int ohw = a.OH * a.OW;
         qn[t] = m / ohw;
@@ -255,7 +299,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
         qy[t] = rem / a.OW;
         qx[t] = rem - qy[t] * a.OW;
     }
-    const float relu_floor = (a.q_scale && a.q_relu) ? 0.f : -INFINITY;
 
     for (int ch = -1; ch < nchunk; ++ch) {
         const bool more = ch + 1 < nchunk;
@@ -264,7 +307,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGP, pg = (u / CGP) & 15;
+                int cg, pg;
+                wgrad_tile_coord<CGP, KB>(u, cg, pg);
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     const int m = mc + 4 * pg + i;
@@ -276,7 +320,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGQ, pg = (u / CGQ) & 15;
+                int cg, pg;
+                wgrad_tile_coord<CGQ, KB>(u, cg, pg);
                 int n = qn[t], y = qy[t], x = qx[t];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -316,15 +361,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 #pragma unroll
             for (int t = 0; t < NP; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGP, pg = (u / CGP) & 15;
+                int cg, pg;
+                wgrad_tile_coord<CGP, KB>(u, cg, pg);
                 if (u < TP_) {
                     float v[4][CH];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int c = 0; c < CH; ++c) {
-                            float f = (float)rp[t][i][c];
-                            if (a.p_scale) f = f * a.p_scale[p0 + cg * CH + c] + a.p_shift[p0 + cg * CH + c];
+                            const float f = (float)rp[t][i][c] * psc[t][c] + psh[t][c];
                             v[i][c] = pok[t][i] ? f : 0.f;
                         }
 #pragma unroll
@@ -337,15 +382,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 #pragma unroll
             for (int t = 0; t < NQ; ++t) {
                 const int u = tid + 256 * t;
-                const int cg = u % CGQ, pg = (u / CGQ) & 15;
+                int cg, pg;
+                wgrad_tile_coord<CGQ, KB>(u, cg, pg);
                 if (u < TQ_) {
                     float v[4][CH];
 #pragma unroll
                     for (int i = 0; i < 4; ++i)
 #pragma unroll
                         for (int c = 0; c < CH; ++c) {
-                            float f = (float)rq[t][i][c];
-                            if (a.q_scale) f = fmaxf(f * a.q_scale[q0 + cg * CH + c] + a.q_shift[q0 + cg * CH + c], relu_floor);
+                            const float f = fmaxf((float)rq[t][i][c] * qsc[t][c] + qsh[t][c], relu_floor);
                             v[i][c] = qok[t][i] ? f : 0.f;
                         }
 #pragma unroll
@@ -394,9 +439,12 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict
 
 // 128x128 tiles when the channel counts allow and the reduction is long enough to amortise them; short reductions
 // (small batches, late layers) take 64x64 tiles: 4x the tiles, so far fewer split-K slabs to write and re-read.
+// Threshold measured on MI355X (scripts/bench_ops.py): 4096 rows beats 16384 at batch 256 (layer4: 0.32 -> 0.23 ms)
+// and is neutral at batch 32.
 inline bool big_tile(const WgradArgs& a)
 {
-    return a.CP % 128 == 0 && a.CQ % 128 == 0 && (long long)a.N * a.OH * a.OW >= 16384;
+    static const long long min_m = getenv("LBC_WGRAD_BIGM") ? atoll(getenv("LBC_WGRAD_BIGM")) : 4096;   // tuning knob
+    return a.CP % 128 == 0 && a.CQ % 128 == 0 && (long long)a.N * a.OH * a.OW >= min_m;
 }
 
 }  // namespace
@@ -432,12 +480,18 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     const int bt = big_tile(a) ? 128 : 64;
     const long long ngroups = (long long)a.nsplit * (a.CP / bt) * (a.CQ / bt);
     const dim3 grid((unsigned)(((ngroups + 7) / 8) * 8 * a.KH * a.KW));
+    static const int kb = getenv("LBC_WGRAD_KB") ? atoi(getenv("LBC_WGRAD_KB")) : -1;   // tuning knob (lane mapping, see the kernel)
+#define LBC_WG(AT, KB)                                                                                                               \
+    do {                                                                                                                             \
+        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, AT, KB>), grid, dim3(256), 0, s, a, rows_per_split);        \
+        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, AT, KB>), grid, dim3(256), 0, s, a, rows_per_split);          \
+    } while (0)
     if (a.act_bf16) {
-        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, __bf16>), grid, dim3(256), 0, s, a, rows_per_split);
-        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, __bf16>), grid, dim3(256), 0, s, a, rows_per_split);
+        if (kb == 0) LBC_WG(__bf16, 0); else if (kb == 2) LBC_WG(__bf16, 2); else if (kb == 3) LBC_WG(__bf16, 3); else if (kb == 1) LBC_WG(__bf16, 1);
+        else if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, __bf16, 1>), grid, dim3(256), 0, s, a, rows_per_split);
+        else                  hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, __bf16, 2>), grid, dim3(256), 0, s, a, rows_per_split);
     } else if (a.bf16) {
-        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, float>), grid, dim3(256), 0, s, a, rows_per_split);
-        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, float>), grid, dim3(256), 0, s, a, rows_per_split);
+        if (kb == 0) LBC_WG(float, 0); else if (kb == 1) LBC_WG(float, 1); else if (kb == 3) LBC_WG(float, 3); else LBC_WG(float, 2);
     } else if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
     else                    hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("conv_wgrad_f32");

@@ -392,9 +392,17 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision):
         ((opa * d_all).sum() + (ops * d_sel).sum()).backward()
     finally:
         O.MFMA_BF16 = O.ACT_BF16 = False
+    with torch.no_grad():
+        _, exact = O.policy_forward({k: v.clone() for k, v in sd.items()}, kind, backbone, x, speed, cmd, True)   # unrounded f32
     err = (pa.cpu() - opa).abs().max().item()
-    assert err < 6e-2, err
-    assert (pa.cpu() - opa).abs().mean().item() < 1e-2
+    e_eng, e_emu = (pa.cpu() - exact).abs(), (opa.detach() - exact).abs()
+    print("precision %d: |engine - f32| mean %.3e max %.3e; |emulation - f32| mean %.3e max %.3e; |engine - emulation| max %.3e"
+          % (precision, e_eng.mean(), e_eng.max(), e_emu.mean(), e_emu.max(), err))
+    # the executor's reduced-precision result must sit as close to the exact-f32 result as the emulation of its rounding
+    # points does (two such evaluations differ from each other by as much as each differs from f32)
+    assert e_eng.mean().item() < 2.0 * e_emu.mean().item() + 1e-3 and e_eng.max().item() < 3.0 * e_emu.max().item() + 1e-2
+    assert err < (6e-2 if precision == 1 else 2.5e-1), err
+    assert (pa.cpu() - opa).abs().mean().item() < (1e-2 if precision == 1 else 3e-2)
     cos = []
     for k, v in eng.grad_views.items():
         a, b = v.cpu().reshape(-1).double(), sp[k].grad.reshape(-1).double()
