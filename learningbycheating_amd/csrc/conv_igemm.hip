@@ -28,17 +28,22 @@ namespace {
 //               MFMA stay f32 in HBM.  64-channel chunks, bf16 LDS tiles ([row][k] only: weights must be depth-contiguous).
 // AT = element type of the activation tensors x / y / resid in HBM (float, or __bf16 with BF16 = true): bf16 activations
 // are loaded 8 channels per 16-byte load and go to LDS without conversion unless a BatchNorm-on-load prologue is set.
-template <int BM, int BN, bool WMAJOR, int MODE, bool BF16, typename AT>
+// WT = element type of the weight operand in HBM (float, or __bf16 with BF16 = true: a per-step bf16 copy, lbc_weight_prep).
+template <int BM, int BN, bool WMAJOR, int MODE, bool BF16, typename AT, typename WT>
 __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
 {
     static_assert(!BF16 || WMAJOR, "the bf16 path needs depth-contiguous weights");
     static_assert(!Act<AT>::kBf16 || BF16, "bf16 activations need the bf16 MFMA path");
+    static_assert(!Act<WT>::kBf16 || BF16, "bf16 weights need the bf16 MFMA path");
     constexpr bool ABF = Act<AT>::kBf16;
+    constexpr bool WBF = Act<WT>::kBf16;
+    using breg_t = typename std::conditional<WBF, bf16x8, f32x4>::type;    // one 16-byte weight load
+    constexpr int BEL = WBF ? 8 : 4;
     using areg_t = typename std::conditional<ABF, bf16x8, f32x4>::type;   // one 16-byte activation load
     using lds_t = typename std::conditional<BF16, __bf16, float>::type;
     constexpr int BK = BF16 ? 64 : 32;      // channels per depth chunk
     constexpr int LDK = BK + (BF16 ? 8 : 4);   // padded LDS row (elements): 144-byte rows either way -> conflict-free b128 reads
-    constexpr int SEGS = BK / 4;            // float4 segments per tile row
+    constexpr int SEGS = BK / BEL;          // 16-byte segments per weight-tile row
     constexpr int RPP = 256 / SEGS;         // tile rows staged per pass of the 256 threads
     constexpr int WM = 2, WN = 2;
     constexpr int MT = BM / WM / 32;
@@ -55,6 +60,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
     __shared__ __attribute__((aligned(16))) lds_t sB[2][SB];
     __shared__ int sTap[16];
     __shared__ int sNTap;
+    __shared__ int sOpix[BM];   // output pixel of every tile row (strided / phase launches; dense launches use m itself)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -110,6 +116,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             pixbase[j] = n * a.H * a.W;
             if (MODE == 0) { ay[j] = oy * a.S - a.P; ax[j] = ox * a.S - a.P; }
             else           { ay[j] = oy + a.P;       ax[j] = ox + a.P; }
+            if (aseg == 0) sOpix[aarow + ARPP * j] = (n * a.OH + oy) * a.OW + ox;
         } else {
             pixbase[j] = 0; ay[j] = -(1 << 20); ax[j] = -(1 << 20);
         }
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     areg_t ra[RA];          // native vector values (HIP's float4 struct would be copied through a scratch alloca)
-    f32x4 rb[RB];
+    breg_t rb[RB];
     bool aok[RA];
     f32x4 lps[AEL / 4], lpt[AEL / 4];
 #pragma unroll
@@ -176,14 +183,14 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             for (int j = 0; j < RB; ++j) {
                 size_t off;
                 if (WMAJOR) {
-                    off = (size_t)(n0 + arow + RPP * j) * (size_t)(T * a.C) + (size_t)(tap * a.C + c0 + seg * 4);
+                    off = (size_t)(n0 + arow + RPP * j) * (size_t)(T * a.C) + (size_t)(tap * a.C + c0 + seg * BEL);
                 } else {
                     const int idx = tid + 256 * j;
                     const int krow = idx / (BN / 4);
                     const int s4 = idx - krow * (BN / 4);
                     off = (size_t)(c0 + krow) * (size_t)(T * a.K) + (size_t)(tap * a.K + n0 + s4 * 4);
                 }
-                rb[j] = *reinterpret_cast<const f32x4*>(a.w + off);
+                rb[j] = *reinterpret_cast<const breg_t*>(static_cast<const WT*>(a.w) + off);
             }
         }
         if (it >= 0) {
@@ -256,7 +263,9 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
-                if constexpr (BF16) {
+                if constexpr (WBF) {
+                    *reinterpret_cast<bf16x8*>(&sB[buf][(arow + RPP * j) * LDK + seg * 8]) = rb[j];
+                } else if constexpr (BF16) {
                     *reinterpret_cast<bf16x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = __builtin_convertvector(rb[j], bf16x4);
                 } else if (WMAJOR) {
                     *reinterpret_cast<f32x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = rb[j];
@@ -284,17 +293,10 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             const int m = m0 + row;
             if (m < a.M) {
                 size_t obase;
-                if (MODE == 0 && a.ostep == 1) {
+                if (a.ostep == 1) {   // dense output (stride-1 either way, or a strided gather): row m is pixel m
                     obase = (size_t)m * (size_t)a.K;
-                } else {
-                    const int lhw = a.LH * a.LW;
-                    const int n = m / lhw;
-                    const int rem = m - n * lhw;
-                    const int ly = rem / a.LW;
-                    const int lx = rem - ly * a.LW;
-                    const int oy = ly * a.ostep + a.oy0;
-                    const int ox = lx * a.ostep + a.ox0;
-                    obase = ((size_t)(n * a.OH + oy) * (size_t)a.OW + (size_t)ox) * (size_t)a.K;
+                } else {              // one output-parity phase of a stride-2 transposed launch
+                    obase = (size_t)sOpix[row] * (size_t)a.K;
                 }
 #pragma unroll
                 for (int nj = 0; nj < NT; ++nj) {
@@ -358,20 +360,59 @@ __global__ __launch_bounds__(256) void weight_transpose_k(const float* __restric
     }
 }
 
+// All convolution weights of a network in one launch: w[A][T][B] (f32) -> bf16 copy in the same layout and bf16
+// transposed copy [B][T][A]; a block handles one 32x32 (a, b) tile of one tap of one tensor.
+__global__ __launch_bounds__(256) void weight_prep_k(WeightPrepArgs a)
+{
+    __shared__ float tile[32][33];
+    int li = 0;
+    for (int i = 1; i < a.count; ++i)
+        if ((int)blockIdx.x >= a.item[i].tile_begin) li = i;
+    const WeightPrepItem& it = a.item[li];
+    const int A = it.A, T = it.T, B = it.B;
+    const int nb = (B + 31) / 32, na = (A + 31) / 32;
+    int rel = (int)blockIdx.x - it.tile_begin;
+    const int bb = rel % nb; rel /= nb;
+    const int ab = rel % na;
+    const int t = rel / na;
+    const int a0 = ab * 32, b0 = bb * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    __bf16* wn = static_cast<__bf16*>(it.wn);
+    __bf16* wt = static_cast<__bf16*>(it.wt);
+    for (int j = ty; j < 32; j += 8) {
+        const int ai = a0 + j, bi = b0 + tx;
+        float v = 0.f;
+        if (ai < A && bi < B) {
+            const size_t o = ((size_t)ai * T + t) * B + bi;
+            v = it.w[o];
+            wn[o] = (__bf16)v;
+        }
+        tile[j][tx] = v;
+    }
+    __syncthreads();
+    for (int j = ty; j < 32; j += 8) {
+        const int bi = b0 + j, ai = a0 + tx;
+        if (ai < A && bi < B) wt[((size_t)bi * T + t) * A + ai] = (__bf16)tile[tx][j];
+    }
+}
+
 template <int BM, int BN>
 int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
     dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN)));
-    if (a.act_bf16) {
-        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16>), grid, dim3(256), 0, s, a);
-        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16>), grid, dim3(256), 0, s, a);
+    if (a.w_bf16) {
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, __bf16>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, __bf16>), grid, dim3(256), 0, s, a);
+    } else if (a.act_bf16) {
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, float>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, float>), grid, dim3(256), 0, s, a);
     } else if (a.bf16) {
-        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, float>), grid, dim3(256), 0, s, a);
-        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, float>), grid, dim3(256), 0, s, a);
-    } else if (wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, false, float>), grid, dim3(256), 0, s, a);
-    else if (wmajor && mode == 1)   hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, false, float>), grid, dim3(256), 0, s, a);
-    else if (!wmajor && mode == 0)  hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 0, false, float>), grid, dim3(256), 0, s, a);
-    else                            hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 1, false, float>), grid, dim3(256), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, float, float>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, float, float>), grid, dim3(256), 0, s, a);
+    } else if (wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, false, float, float>), grid, dim3(256), 0, s, a);
+    else if (wmajor && mode == 1)   hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, false, float, float>), grid, dim3(256), 0, s, a);
+    else if (!wmajor && mode == 0)  hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 0, false, float, float>), grid, dim3(256), 0, s, a);
+    else                            hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 1, false, float, float>), grid, dim3(256), 0, s, a);
     return lbc_check_launch("conv_igemm");
 }
 
@@ -385,6 +426,16 @@ int lbc_weight_transpose(const float* w, float* wt, int A, int T, int B, hipStre
     LbcProfScope prof("weight_transpose", 0.0, 8.0 * A * T * B, s);
     hipLaunchKernelGGL(weight_transpose_k, dim3((unsigned)lbc_cdiv(B, 32), (unsigned)lbc_cdiv(A, 32), (unsigned)T), dim3(256), 0, s, w, wt, A, T, B);
     return lbc_check_launch("weight_transpose");
+}
+
+int lbc_weight_prep(const WeightPrepArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.count >= 1 && a.count <= WeightPrepArgs::kMax && a.tiles > 0, "weight_prep: bad table");
+    double elems = 0;
+    for (int i = 0; i < a.count; ++i) elems += (double)a.item[i].A * a.item[i].T * a.item[i].B;
+    LbcProfScope prof("weight_prep", 0.0, 8.0 * elems, s);
+    hipLaunchKernelGGL(weight_prep_k, dim3((unsigned)a.tiles), dim3(256), 0, s, a);
+    return lbc_check_launch("weight_prep");
 }
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kCfgBM[cfg]); }
@@ -404,6 +455,7 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     LBC_REQUIRE(a.C % (a.bf16 ? 64 : 32) == 0, "igemm: gathered channels %d not a multiple of %d", a.C, a.bf16 ? 64 : 32);
     LBC_REQUIRE(!a.bf16 || wmajor, "igemm: the bf16 path needs depth-contiguous weights (transpose first)");
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "igemm: bf16 activations need bf16 = 1");
+    LBC_REQUIRE(!a.w_bf16 || a.act_bf16, "igemm: bf16 weight copies are used with bf16 activations only");
     LBC_REQUIRE(a.K % kCfgBN[cfg] == 0, "igemm: output channels %d not a multiple of tile %d", a.K, kCfgBN[cfg]);
     LBC_REQUIRE(a.KH * a.KW <= 16, "igemm: too many taps");
     LBC_REQUIRE(a.S == 1 || a.S == 2, "igemm: stride %d unsupported", a.S);
@@ -420,7 +472,7 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     const double in_frac = (mode == 1 && a.S == 2) ? 1.0 : 1.0;
     LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * a.K * (double)a.C * taps,
                       (a.act_bf16 ? 2.0 : 4.0) * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) +
-                                                  (double)a.M * a.K * (a.resid ? 2 : 1)) + 4.0 * (double)taps * a.C * a.K, s);
+                                                  (double)a.M * a.K * (a.resid ? 2 : 1)) + (a.w_bf16 ? 2.0 : 4.0) * (double)taps * a.C * a.K, s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);
         case 1: return launch_cfg<128, 128>(a, wmajor, mode, s);

@@ -66,6 +66,7 @@ Conv Net::make_conv(const std::string& name, int Cin, int Cout, int H, int W, in
     c.OH = (H + 2 * p - k) / s + 1;
     c.OW = (W + 2 * p - k) / s + 1;
     c.y = alloc_act((size_t)d_.max_batch * c.OH * c.OW * Cout);
+    if (act_bf16_) { c.wn = alloc(((size_t)Cout * Cin * k * k + 1) / 2); c.wt = alloc(((size_t)Cout * Cin * k * k + 1) / 2); }
     return c;
 }
 
@@ -130,6 +131,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
         D.bias = add_tensor(std::string(ct_name[i]) + ".bias", kParam, {dc[i + 1]});
         D.Cin = dc[i]; D.Cout = dc[i + 1]; D.H = dh; D.W = dw;
         D.u = alloc_act(NB * (2 * dh) * (2 * dw) * dc[i + 1]);
+        if (act_bf16_) { D.wn = alloc(((size_t)dc[i] * dc[i + 1] * 9 + 1) / 2); D.wt = alloc(((size_t)dc[i] * dc[i + 1] * 9 + 1) / 2); }
         dh *= 2; dw *= 2;
         max_act = std::max(max_act, NB * dh * dw * (size_t)dc[i + 1]);
     }
@@ -210,7 +212,32 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? W(partial_) : nullptr;
     a.bf16 = bf16_; a.act_bf16 = act_bf16_;
+    if (act_bf16_) { a.w = W(c.wn); a.w_bf16 = 1; }
     return lbc_igemm_launch(a, 1, 0, cfg, s);
+}
+
+int Net::weight_prep(hipStream_t s)
+{
+    WeightPrepArgs a;
+    memset(&a, 0, sizeof(a));
+    int n = 0, tiles = 0;
+    auto add = [&](const float* w, size_t wn, size_t wt, int A, int T, int B) {
+        if (n >= WeightPrepArgs::kMax) return false;
+        WeightPrepItem& it = a.item[n++];
+        it.w = w; it.wn = W(wn); it.wt = W(wt); it.A = A; it.T = T; it.B = B; it.tile_begin = tiles;
+        tiles += lbc_cdiv(A, 32) * lbc_cdiv(B, 32) * T;
+        return true;
+    };
+    bool ok = true;
+    for (const Block& b : blocks_) {
+        ok = ok && add(P(b.c1.w), b.c1.wn, b.c1.wt, b.c1.Cout, 9, b.c1.Cin);
+        ok = ok && add(P(b.c2.w), b.c2.wn, b.c2.wt, b.c2.Cout, 9, b.c2.Cin);
+        if (b.has_ds) ok = ok && add(P(b.ds.w), b.ds.wn, b.ds.wt, b.ds.Cout, 1, b.ds.Cin);
+    }
+    for (int i = 0; i < 3; ++i) ok = ok && add(P(dec_[i].w), dec_[i].wn, dec_[i].wt, dec_[i].Cin, 9, dec_[i].Cout);
+    LBC_REQUIRE(ok, "net: more than %d convolution weights", WeightPrepArgs::kMax);
+    a.count = n; a.tiles = tiles;
+    return lbc_weight_prep(a, s);
 }
 
 int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running)
@@ -255,6 +282,7 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     const float m3[3] = {0.485f, 0.456f, 0.406f}, s3[3] = {0.229f, 0.224f, 0.225f};
     for (int i = 0; i < 3; ++i) { nc.mean[i] = m3[i]; nc.stdv[i] = s3[i]; }
     LBC_TRY(lbc_prep_input(image, W(xp_), N, Cin, H0, W0, nc, s));
+    if (act_bf16_) LBC_TRY(weight_prep(s));   // the caller's optimizer may have stepped: refresh the bf16 weight copies
 
     // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
     StemArgs st;
@@ -326,7 +354,9 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
         a.stats = tr ? W(partial_) : nullptr;
         a.act_bf16 = act_bf16_;
         int wmajor = 0;
-        if (bf16_) {
+        if (act_bf16_) {
+            a.w = W(D.wt); a.w_bf16 = 1; a.bf16 = 1; wmajor = 1;
+        } else if (bf16_) {
             // w[Cin][T][Cout] -> wt[Cout][T][Cin]: depth-contiguous for the bf16 tiles
             LBC_TRY(lbc_weight_transpose(P(D.w), W(wt_), D.Cin, 9, D.Cout, s));
             a.w = W(wt_); a.bf16 = 1; wmajor = 1;
@@ -433,7 +463,9 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
     int wmajor = 0;
     a.bf16 = bf16_; a.act_bf16 = act_bf16_;
-    if (dgrad_wt_ && (c.k == 3 || bf16_)) {
+    if (act_bf16_) {
+        a.w = W(c.wt); a.w_bf16 = 1; wmajor = 1;
+    } else if (dgrad_wt_ && (c.k == 3 || bf16_)) {
         // w[Cout][T][Cin] -> wt[Cin][T][Cout]: output channel (Cin) major, gathered channel (Cout) contiguous
         LBC_TRY(lbc_weight_transpose(P(c.w), W(wt_), c.Cout, c.k * c.k, c.Cin, s));
         a.w = W(wt_);
@@ -564,6 +596,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             a.OH = D.H; a.OW = D.W; a.K = D.Cin; a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
             a.M = N * D.H * D.W; a.LH = D.H; a.LW = D.W; a.ostep = 1;
             a.bf16 = bf16_; a.act_bf16 = act_bf16_;
+            if (act_bf16_) { a.w = W(D.wn); a.w_bf16 = 1; }
             LBC_TRY(lbc_igemm_launch(a, 1, 0, lbc_igemm_pick(a.M, a.K), s));   // F = d bn(x)
             // BatchNorm backward; for the first decoder stage only the 512 trunk channels carry on
             float* dst = i == 0 ? bwd_D_ : E;

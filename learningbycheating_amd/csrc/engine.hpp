@@ -40,6 +40,7 @@ struct Conv {   // nn.Conv2d without bias
     int w = -1;
     int Cin = 0, Cout = 0, H = 0, W = 0, k = 0, s = 1, p = 0, OH = 0, OW = 0;
     size_t y = 0;            // raw output (pre-BN)
+    size_t wn = 0, wt = 0;   // precision 2: per-step bf16 copies of the weight, [Cout][T][Cin] and transposed [Cin][T][Cout]
 };
 
 struct Block {
@@ -54,6 +55,7 @@ struct Deconv {   // BN -> ConvTranspose2d(k3,s2,p1,op1) -> ReLU
     int w = -1, bias = -1;
     int Cin = 0, Cout = 0, H = 0, W = 0;   // input spatial size
     size_t u = 0;                          // relu output [N,2H,2W,Cout]
+    size_t wn = 0, wt = 0;                 // precision 2: bf16 copies [Cin][T][Cout] and transposed [Cout][T][Cin]
 };
 
 class Net {
@@ -88,6 +90,7 @@ private:
     bool bf16_ = false;      // precision >= 1: bf16 MFMA operands in the convolution family
     bool act_bf16_ = false;  // precision 2: activations and activation gradients are stored as bf16 in HBM
     bool fuse_z1_ = true;    // conv2 / wgrad2 / bn1-backward read y1 with bn1(+ReLU) applied on load; z1 is never written
+    int weight_prep(hipStream_t s);
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
                     float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr);

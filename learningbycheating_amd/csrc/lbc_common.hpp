@@ -56,7 +56,7 @@ struct LbcProfScope {
 // ---------------------------------------------------------------------------
 struct IgemmArgs {
     const void* x;        // gathered tensor, NHWC [N][H][W][C]; f32, or bf16 when act_bf16
-    const float* w;
+    const void* w;        // weights: f32, or bf16 when w_bf16 (needs bf16 = 1; see lbc_weight_prep)
     void* y;              // NHWC [N][OH][OW][K]; same element type as x
     const float* bias;    // [K] or nullptr
     const void* resid;    // like y (may alias y) or nullptr; added before relu
@@ -75,7 +75,25 @@ struct IgemmArgs {
     int stat_row0;
     int bf16;             // 1: bf16 MFMA operands (f32 accumulation), needs wmajor weights and C % 64 == 0
     int act_bf16;         // 1: x / y / resid are bf16 tensors (requires bf16 = 1)
+    int w_bf16;           // 1: w is a bf16 copy of the weights (requires bf16 = 1, depth-contiguous)
 };
+
+// One launch converts every convolution weight of a network to bf16, in its own layout w[A][T][B] and transposed
+// wt[B][T][A] (the depth-contiguous operand of the input-gradient / transposed-convolution GEMMs).
+struct WeightPrepItem {
+    const float* w;
+    void* wn;             // bf16 [A][T][B]
+    void* wt;             // bf16 [B][T][A]
+    int A, T, B;
+    int tile_begin;       // first 32x32 tile of this tensor in the launch
+};
+struct WeightPrepArgs {
+    static const int kMax = 48;
+    WeightPrepItem item[kMax];
+    int count;
+    int tiles;
+};
+int lbc_weight_prep(const WeightPrepArgs& a, hipStream_t s);
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg);   // number of M tiles (= stats rows) of a launch
 int lbc_igemm_pick(long long M, int K);

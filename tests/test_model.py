@@ -392,8 +392,10 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision):
         ((opa * d_all).sum() + (ops * d_sel).sum()).backward()
     finally:
         O.MFMA_BF16 = O.ACT_BF16 = False
-    with torch.no_grad():
-        _, exact = O.policy_forward({k: v.clone() for k, v in sd.items()}, kind, backbone, x, speed, cmd, True)   # unrounded f32
+    xp = O.as_params(sd)                                                       # unrounded f32 forward / backward
+    exs, exact = O.policy_forward(xp, kind, backbone, x, speed, cmd, True)
+    ((exact * d_all).sum() + (exs * d_sel).sum()).backward()
+    exact = exact.detach()
     err = (pa.cpu() - opa).abs().max().item()
     e_eng, e_emu = (pa.cpu() - exact).abs(), (opa.detach() - exact).abs()
     print("precision %d: |engine - f32| mean %.3e max %.3e; |emulation - f32| mean %.3e max %.3e; |engine - emulation| max %.3e"
@@ -403,13 +405,21 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision):
     assert e_eng.mean().item() < 2.0 * e_emu.mean().item() + 1e-3 and e_eng.max().item() < 3.0 * e_emu.max().item() + 1e-2
     assert err < (6e-2 if precision == 1 else 2.5e-1), err
     assert (pa.cpu() - opa).abs().mean().item() < (1e-2 if precision == 1 else 3e-2)
-    cos = []
-    for k, v in eng.grad_views.items():
-        a, b = v.cpu().reshape(-1).double(), sp[k].grad.reshape(-1).double()
-        if b.norm() > 1e-6 and not (k.startswith("location_pred") and k.endswith("bias")):
-            cos.append((torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item())
-    cos.sort()
-    # measured on MI355X (r34, 160x384, N=8): median 0.88, minimum 0.80 -- two bf16 evaluations of an untrained 34-layer
-    # BatchNorm network decorrelate at this level; a wrong kernel gives ~0
-    assert cos[len(cos) // 2] > 0.8 and cos[len(cos) // 10] > 0.6, (cos[:5], cos[len(cos) // 2])
-    print("bf16 mode %d: max |pred - oracle_bf16| = %.3e, median gradient cosine = %.4f, p10 = %.4f" % (precision, err, cos[len(cos) // 2], cos[len(cos) // 10]))
+    def cosines(ga, gb):
+        out = []
+        for k in eng.grad_views:
+            a, b = ga(k).reshape(-1).double(), gb(k).reshape(-1).double()
+            if b.norm() > 1e-6 and not (k.startswith("location_pred") and k.endswith("bias")):
+                out.append((torch.dot(a, b) / (a.norm() * b.norm() + 1e-30)).item())
+        out.sort()
+        return out[len(out) // 2], out[len(out) // 10], out[0]
+
+    g_eng, g_emu, g_f32 = (lambda k: eng.grad_views[k].cpu()), (lambda k: sp[k].grad), (lambda k: xp[k].grad)
+    c_ee, c_ef, c_mf = cosines(g_eng, g_emu), cosines(g_eng, g_f32), cosines(g_emu, g_f32)
+    print("precision %d gradient cosines (median, p10, min): engine~emulation %.3f %.3f %.3f | engine~f32 %.3f %.3f %.3f | emulation~f32 %.3f %.3f %.3f"
+          % ((precision,) + c_ee + c_ef + c_mf))
+    # Two reduced-precision evaluations of an untrained 34-layer BatchNorm network decorrelate (measured on MI355X, r34
+    # 160x384 N=8: precision 1 median 0.88 / min 0.80; precision 2 median 0.74 / min 0.59); a wrong kernel gives ~0.  The
+    # yardstick is the emulation itself: the executor's gradients must be as close to exact f32 as the emulation's are.
+    assert c_ef[0] > c_mf[0] - 0.08 and c_ef[1] > c_mf[1] - 0.12, (c_ef, c_mf)
+    assert c_ee[0] > (0.8 if precision == 1 else 0.6) and c_ee[1] > (0.6 if precision == 1 else 0.45), c_ee
