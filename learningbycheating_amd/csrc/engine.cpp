@@ -287,7 +287,7 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
     StemArgs st;
     st.xp = W(xp_); st.w = P(stem_w_); st.y = W(y0_); st.stats = tr ? W(partial_) : nullptr;
-    st.N = N; st.H = H0; st.W = W0; st.Cin = Cin; st.act_bf16 = act_bf16_;
+    st.N = N; st.H = H0; st.W = W0; st.Cin = Cin; st.act_bf16 = act_bf16_; st.bf16 = bf16_;
     LBC_TRY(lbc_stem_fwd(st, s));
     LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), train, s));
     PoolFwdArgs pf;

@@ -87,6 +87,7 @@ struct StemArgs {
     float* stats;                // [rows][2][64] or nullptr
     int N, H, W, Cin;
     int act_bf16;
+    int bf16;                    // 1: bf16 MFMA operands (f32 accumulation)
 };
 int lbc_stem_rows(const StemArgs& a);
 int lbc_stem_fwd(const StemArgs& a, hipStream_t s);

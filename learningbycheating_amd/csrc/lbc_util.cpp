@@ -40,11 +40,11 @@ void lbc_prof_begin(const char* name, double flops, double bytes, hipStream_t s)
 {
     ProfRec r;
     r.name = name; r.flops = flops; r.bytes = bytes;
-    hipEventCreate(&r.e0); hipEventCreate(&r.e1);
-    hipEventRecord(r.e0, s);
+    (void)hipEventCreate(&r.e0); (void)hipEventCreate(&r.e1);
+    (void)hipEventRecord(r.e0, s);
     g_recs.push_back(r);
 }
-void lbc_prof_end(hipStream_t s) { if (!g_recs.empty()) hipEventRecord(g_recs.back().e1, s); }
+void lbc_prof_end(hipStream_t s) { if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s); }
 
 extern "C" int lbc_profile_enable(int on)
 {
@@ -58,13 +58,13 @@ extern "C" int lbc_profile_report(char* buf, int cap)
     std::map<std::string, Agg> agg;
     std::vector<std::string> order;
     for (ProfRec& r : g_recs) {
-        hipEventSynchronize(r.e1);
+        (void)hipEventSynchronize(r.e1);
         float ms = 0.f;
-        hipEventElapsedTime(&ms, r.e0, r.e1);
+        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
         if (!agg.count(r.name)) order.push_back(r.name);
         Agg& a = agg[r.name];
         a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
-        hipEventDestroy(r.e0); hipEventDestroy(r.e1);
+        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
     g_recs.clear();
     int off = 0;

@@ -128,8 +128,8 @@ def checksum(sd):
 # ----------------------------------------------------------------------------------------
 # Emulation of the executor's optional "bf16 MFMA operand" precision (lbc_net_desc.precision = 1): every operand of a
 # trunk/decoder convolution GEMM -- activations, weights and, in the backward pass, output gradients -- is rounded to
-# bf16 (RNE) right before the multiply; accumulation, tensors and everything else stay f32.  The stem and the head's 1x1
-# convolution are not rounded.  Off by default (the reference arithmetic is f32).
+# bf16 (RNE) right before the multiply; accumulation, tensors and everything else stay f32.  The stem convolution is
+# rounded the same way; the head's 1x1 convolution is not.  Off by default (the reference arithmetic is f32).
 MFMA_BF16 = False
 
 
@@ -211,7 +211,7 @@ def calibrate_running_stats(sd, kind, backbone, x, velocity, command):
 
 def trunk(sd, backbone, x, train, taps=None):
     """ResNet.forward (resnet.py:148-159) with BasicBlock.forward (resnet.py:38-54)."""
-    x = _st(F.conv2d(x, sd["conv.conv1.weight"], None, 2, 3))
+    x = _st(_conv(x, sd["conv.conv1.weight"], None, 2, 3))
     x = F.relu(_bn(sd, "conv.bn1", x, train))
     x = _st(F.max_pool2d(x, 3, 2, 1))
     if taps is not None:

@@ -62,6 +62,15 @@ if [[ "$PHASES" == *prof* ]]; then
   # keep the (large) raw trace out of the merge budget
   find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
 fi
+if [[ "$PHASES" == *p32* ]]; then
+  # kernel trace at the per-GPU load of the 8-GPU run (32 images): sum of kernel durations vs wall = launch-gap share
+  rm -rf gpurun_out/prof32
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof32" -o lbc -- python "$OLDPWD/bench.py" --dtype ${PROF_DTYPE:-bf16_act} --global-batch 32 --steps 20 --warmup 3 --init-steps 2 --no-cpu-baseline --no-alt) > gpurun_out/prof32.log 2>&1
+  echo "prof32 exit $?" >> gpurun_out/summary.txt
+  tail -1 gpurun_out/prof32.log | cut -c1-200 >> gpurun_out/summary.txt
+  python scripts/trace_gaps.py $(find gpurun_out/prof32 -name "*kernel_trace.csv" | head -1) >> gpurun_out/summary.txt 2>&1
+  find gpurun_out/prof32 -name "*kernel_trace*" -size +20M -delete
+fi
 if [[ "$PHASES" == *pmc* ]]; then
   # hardware counters: separate passes, kernel-trace only (no sys/runtime tracing together with --pmc)
   i=0
