@@ -164,6 +164,7 @@ int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
     WgradArgs a = conv_wgrad_args(d);
     a.p = dy; a.q = x; a.partial = (float*)workspace;
     a.q_scale = pre_scale; a.q_shift = pre_shift; a.q_relu = pre_relu;
+    if (a.nsplit == 1 && beta == 0.f) { a.partial = dw; return lbc_wgrad_launch(a, (hipStream_t)stream); }
     int rc = lbc_wgrad_launch(a, (hipStream_t)stream);
     if (rc) return rc;
     return lbc_splitk_reduce(a.partial, a.nsplit, (long long)a.CP * a.KH * a.KW * a.CQ, dw, beta, (hipStream_t)stream);
@@ -199,6 +200,7 @@ int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
     WgradArgs a = deconv_wgrad_args(d);
     a.p = x; a.q = dy; a.partial = (float*)workspace;
     a.p_scale = pre_scale; a.p_shift = pre_shift;
+    if (a.nsplit == 1 && beta == 0.f) { a.partial = dw; return lbc_wgrad_launch(a, (hipStream_t)stream); }
     int rc = lbc_wgrad_launch(a, (hipStream_t)stream);
     if (rc) return rc;
     return lbc_splitk_reduce(a.partial, a.nsplit, (long long)a.CP * 9 * a.CQ, dw, beta, (hipStream_t)stream);

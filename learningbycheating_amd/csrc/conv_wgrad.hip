@@ -418,21 +418,39 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
         }
 }
 
+// out = beta*out + sum_k partial[k]: G threads share one float4 of the result, thread g adds slabs g, g+G, ... and the G
+// partial sums are combined through LDS in a fixed order (deterministic).  G > 1 keeps the chip busy when the result
+// is small and the slab count large (layer1 at small batch: 147 KB result, > 100 slabs).
+template <int G>
 __global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict__ partial, int nsplit, long long count4,
                                                          float* __restrict__ out, float beta)
 {
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < count4; i += stride) {
-        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int k = 0; k < nsplit; ++k) {
-            const float4 v = reinterpret_cast<const float4*>(partial)[(long long)k * count4 + i];
-            s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+    constexpr int E = 256 / G;
+    __shared__ __attribute__((aligned(16))) f32x4 red[256];
+    const int e = threadIdx.x % E, g = threadIdx.x / E;
+    const long long i = (long long)blockIdx.x * E + e;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (i < count4) {
+        const f32x4* src = reinterpret_cast<const f32x4*>(partial) + i;
+        int k = g;
+        for (; k + 3 * G < nsplit; k += 4 * G) {     // 4 independent loads in flight
+            const f32x4 v0 = src[(long long)k * count4], v1 = src[(long long)(k + G) * count4];
+            const f32x4 v2 = src[(long long)(k + 2 * G) * count4], v3 = src[(long long)(k + 3 * G) * count4];
+            s += v0; s += v1; s += v2; s += v3;
         }
-        float4* o = reinterpret_cast<float4*>(out) + i;
-        if (beta != 0.f) {
-            const float4 p = *o;
-            s.x += beta * p.x; s.y += beta * p.y; s.z += beta * p.z; s.w += beta * p.w;
+        for (; k < nsplit; k += G) s += src[(long long)k * count4];
+    }
+    if (G > 1) {
+        red[g * E + e] = s;
+        __syncthreads();
+        if (g == 0) {
+#pragma unroll
+            for (int gg = 1; gg < G; ++gg) s += red[gg * E + e];
         }
+    }
+    if (g == 0 && i < count4) {
+        f32x4* o = reinterpret_cast<f32x4*>(out) + i;
+        if (beta != 0.f) s += beta * *o;
         *o = s;
     }
 }
@@ -455,7 +473,8 @@ int lbc_wgrad_pick_split(const WgradArgs& a)
     const long long tiles = (long long)(a.CP / bp) * (a.CQ / bp) * a.KH * a.KW;
     const long long M = (long long)a.N * a.OH * a.OW;
     const long long chunks = (M + BR - 1) / BR;
-    long long ns = (1024 + tiles - 1) / tiles;
+    static const long long target = getenv("LBC_WGRAD_BLOCKS") ? atoll(getenv("LBC_WGRAD_BLOCKS")) : 1024;   // tuning knob
+    long long ns = (target + tiles - 1) / tiles;
     if (ns < 1) ns = 1;
     if (ns > 256) ns = 256;
     // keep at least 8 chunks (256 pixels) of reduction per split
@@ -501,10 +520,17 @@ int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* 
 {
     LBC_REQUIRE(count % 4 == 0, "splitk_reduce: count %lld not a multiple of 4", count);
     const long long c4 = count / 4;
-    long long blocks = (c4 + 255) / 256;
-    if (blocks > 2048) blocks = 2048;
-    if (blocks < 1) blocks = 1;
+    // threads per result element: enough for >= 512 workgroups, at most a quarter of the slab count
+    int G = 1;
+    while (G < 16 && c4 * G < 512 * 256 && 4 * G <= nsplit) G *= 2;
+    const unsigned blocks = (unsigned)((c4 * G + 255) / 256);
     LbcProfScope prof("splitk_reduce", 0.0, 4.0 * (double)count * (nsplit + 1), s);
-    hipLaunchKernelGGL(splitk_reduce_f32, dim3((unsigned)blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta);
+    switch (G) {
+        case 1: hipLaunchKernelGGL(splitk_reduce_f32<1>, dim3(blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta); break;
+        case 2: hipLaunchKernelGGL(splitk_reduce_f32<2>, dim3(blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta); break;
+        case 4: hipLaunchKernelGGL(splitk_reduce_f32<4>, dim3(blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta); break;
+        case 8: hipLaunchKernelGGL(splitk_reduce_f32<8>, dim3(blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta); break;
+        default: hipLaunchKernelGGL(splitk_reduce_f32<16>, dim3(blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta); break;
+    }
     return lbc_check_launch("splitk_reduce_f32");
 }

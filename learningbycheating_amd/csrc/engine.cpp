@@ -448,6 +448,7 @@ int Net::conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const floa
     a.H = c.H; a.W = c.W; a.CQ = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
     a.nsplit = lbc_wgrad_pick_split(a);
+    if (a.nsplit == 1) { a.partial = G(c.w); return lbc_wgrad_launch(a, s); }   // a single slab is the gradient itself
     LBC_TRY(lbc_wgrad_launch(a, s));
     return lbc_splitk_reduce(a.partial, a.nsplit, (long long)c.Cout * c.k * c.k * c.Cin, G(c.w), 0.f, s);
 }
@@ -586,8 +587,9 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             wa.H = 2 * D.H; wa.W = 2 * D.W; wa.CQ = D.Cout; wa.KH = 3; wa.KW = 3; wa.S = 2; wa.P = 1;
             wa.bf16 = bf16_; wa.act_bf16 = act_bf16_;
             wa.nsplit = lbc_wgrad_pick_split(wa);
+            if (wa.nsplit == 1) wa.partial = G(D.w);
             LBC_TRY(lbc_wgrad_launch(wa, s));
-            LBC_TRY(lbc_splitk_reduce(wa.partial, wa.nsplit, (long long)D.Cin * 9 * D.Cout, G(D.w), 0.f, s));
+            if (wa.nsplit > 1) LBC_TRY(lbc_splitk_reduce(wa.partial, wa.nsplit, (long long)D.Cin * 9 * D.Cout, G(D.w), 0.f, s));
             // input gradient: a stride-2 gather convolution over g with the same weight tensor
             IgemmArgs a;
             memset(&a, 0, sizeof(a));

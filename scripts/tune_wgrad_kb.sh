@@ -1,1 +1,1 @@
-for bm in 16384 4096; do echo "== BIGM=$bm"; LBC_WGRAD_BIGM=$bm PYTHONPATH=. timeout 300 python scripts/bench_ops.py ${1:-256} 12 wgrad 2>&1 | grep -v amdgpu.ids; done
+for tb in 256 512 1024; do echo "== BLOCKS=$tb"; LBC_WGRAD_BLOCKS=$tb PYTHONPATH=. timeout 300 python scripts/bench_ops.py ${1:-256} 2 wgrad 2>&1 | grep -v amdgpu.ids; done
