@@ -87,9 +87,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--global-batch", type=int, default=256)
-    ap.add_argument("--dtype", choices=["f32", "bf16", "bf16_act"], default="bf16",
-                    help="f32: exact-f32 MFMA everywhere (the parity path). bf16: convolution MFMA operands rounded to bf16, f32 "
-                         "accumulation, f32 master weights/activations/BatchNorm/soft-argmax/loss/Adam (BASELINE.json config 3)")
+    ap.add_argument("--dtype", choices=["f32", "bf16_mfma", "bf16"], default="bf16",
+                    help="f32: exact-f32 MFMA everywhere (the parity path). bf16: mixed precision of BASELINE.json config 3 -- bf16 MFMA "
+                         "operands and bf16 activation storage, f32 accumulation / master weights / gradients / BatchNorm / soft-argmax / "
+                         "loss / Adam. bf16_mfma: bf16 MFMA operands only, every tensor f32")
     ap.add_argument("--init-steps", type=int, default=40, help="below-horizon warm start (stands in for the phase-0 checkpoint)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short exact-f32 run reported under 'also'")
@@ -131,7 +132,7 @@ def main():
 
     def timed_run(dtype, steps, warmup):
         student, teacher = build_models(device)
-        student.precision = teacher.precision = {"f32": "fp32", "bf16": "bf16", "bf16_act": "bf16_act"}[dtype]
+        student.precision = teacher.precision = {"f32": "fp32", "bf16_mfma": "bf16_mfma", "bf16": "bf16"}[dtype]
         broadcast_module(student); broadcast_module(teacher)
         warm = NativeTrainer(student, None, per_gpu, (3, 160, 384), device, phase="l1_all", lr=1e-3, world_size=world)
         for _ in range(args.init_steps):
@@ -198,7 +199,7 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "ImagePolicyModelSS(resnet34) phase-1 step vs BirdViewPolicyModelSS(resnet18) teacher, "
                                       "160x384 RGB + 7x192x192 bird-view, global batch %d (%d/GPU), %s, local BatchNorm, "
-                                      "Adam lr 1e-4" % (args.global_batch, per_gpu, {"bf16": "bf16 MFMA operands + f32 accumulate/master/BN/loss/Adam", "bf16_act": "bf16 MFMA operands and bf16 activation storage + f32 accumulate/master/BN/loss/Adam", "f32": "exact-f32 MFMA"}[args.dtype]),
+                                      "Adam lr 1e-4" % (args.global_batch, per_gpu, {"bf16_mfma": "bf16 MFMA operands + f32 tensors/accumulate/master/BN/loss/Adam", "bf16": "bf16 MFMA operands and bf16 activation storage + f32 accumulate/master weights/gradients/BN/loss/Adam", "f32": "exact-f32 MFMA"}[args.dtype]),
                           "global_batch": args.global_batch, "parallelism": "dp%d" % world},
                "loss": loss_mean, "loss_finite": bool(loss_mean == loss_mean and abs(loss_mean) != float("inf")),
                "algorithmic_tflops": round(value * FLOP_PER_IMAGE_STEP / 1e12, 2),

@@ -93,9 +93,10 @@ class _PolicyFunction(torch.autograd.Function):
 class PolicyBase(ResnetBase):
     """Executor plumbing shared by the two policy models."""
     _normalize = False
-    #: "fp32" (default, the parity path: exact-f32 MFMA) or "bf16" (convolution MFMA operands rounded to bf16, f32
-    #: accumulation; weights, activations, BatchNorm, soft-argmax, loss and Adam stay f32) or "bf16_act" (as "bf16", and
-    #: activations / activation gradients are stored as bf16 in HBM; f32 master weights).  Set before the first forward.
+    #: "fp32" (default, the parity path: exact-f32 MFMA everywhere); "bf16" = mixed precision as in BASELINE.json config 3
+    #: (convolution MFMA operands and the activations / activation gradients stored in HBM are bf16; f32 accumulation,
+    #: f32 master weights, gradients, BatchNorm statistics, soft-argmax, loss and Adam); "bf16_mfma" = only the MFMA
+    #: operands are rounded to bf16, every tensor stays f32.  Set before the first forward.
     precision = "fp32"
 
     def _finish_init(self):
@@ -119,7 +120,7 @@ class PolicyBase(ResnetBase):
 
     def _engine_for(self, image, with_grads):
         n, c, h, w = image.shape
-        prec = {"fp32": 0, "bf16": 1, "bf16_act": 2}[self.precision]
+        prec = {"fp32": 0, "bf16_mfma": 1, "bf16": 2}[self.precision]
         key = (h, w, str(image.device), prec)
         eng = self._engines.get(key)
         if eng is None or eng.max_batch < n:

@@ -42,6 +42,7 @@ def train(config):
     bzu.log.init(config["log_dir"], rank)
     bzu.log.save_config({k: v for k, v in config.items() if k not in ("rank", "world_size")})
     net = BirdViewPolicyModelSS(config["model_args"]["backbone"]).to(device)
+    net.precision = config.get("precision", "fp32")
     if config["resume"]:
         # the reference takes glob('model-*.th')[-1] unsorted (train_birdview.py:164-169); sort numerically instead
         ckpts = sorted(Path(config["log_dir"]).glob("model-*.th"), key=lambda p: int(p.stem.split("-")[1]))
@@ -79,6 +80,8 @@ def main(argv=None):
     parser.add_argument("--lr", type=float, default=1e-4)
     parser.add_argument("--synthetic", type=int, default=2048)
     parser.add_argument("--iters_per_epoch", type=int, default=1000)
+    parser.add_argument("--precision", choices=["fp32", "bf16", "bf16_mfma"], default="fp32",
+                        help="fp32 = the reference arithmetic; bf16 = bf16 MFMA operands + bf16 activation storage, f32 master weights")
     parsed = parser.parse_args(argv)
     if parsed.dataset_dir is not None:
         raise SystemExit("the LMDB reader needs the lmdb/cv2 packages (not in this image); use --synthetic N")
@@ -90,7 +93,7 @@ def main(argv=None):
         dist.init_process_group("nccl")
     config = {
         "log_dir": parsed.log_dir, "log_iterations": parsed.log_iterations, "max_epoch": parsed.max_epoch,
-        "device": torch.device("cuda", local), "optimizer_args": {"lr": parsed.lr}, "resume": parsed.resume,
+        "device": torch.device("cuda", local), "precision": parsed.precision, "optimizer_args": {"lr": parsed.lr}, "resume": parsed.resume,
         "data_args": {"dataset_dir": parsed.dataset_dir, "batch_size": parsed.batch_size, "n_step": N_STEP, "gap": parsed.gap,
                       "crop_x_jitter": parsed.x_jitter, "crop_y_jitter": parsed.y_jitter, "angle_jitter": parsed.angle_jitter,
                       "max_frames": parsed.max_frames, "cmd_biased": parsed.cmd_biased},

@@ -89,6 +89,7 @@ def train(config):
     if config["phase0_ckpt"]:
         net.load_state_dict(torch.load(config["phase0_ckpt"], map_location=device))
     teacher_net = BirdViewPolicyModelSS(teacher_config["model_args"]["backbone"], pretrained=True, all_branch=True).to(device)
+    net.precision = teacher_net.precision = config.get("precision", "fp32")
     if config["teacher_args"]["model_path"]:
         teacher_net.load_state_dict(torch.load(config["teacher_args"]["model_path"], map_location=device))
     teacher_net.eval()
@@ -128,6 +129,8 @@ def main(argv=None):
     parser.add_argument("--lr", type=float, default=1e-4)
     parser.add_argument("--synthetic", type=int, default=2048, help="number of device-resident synthetic frames")
     parser.add_argument("--iters_per_epoch", type=int, default=1000)
+    parser.add_argument("--precision", choices=["fp32", "bf16", "bf16_mfma"], default="fp32",
+                        help="fp32 = the reference arithmetic; bf16 = bf16 MFMA operands + bf16 activation storage, f32 master weights")
     parsed = parser.parse_args(argv)
     if parsed.dataset_dir is not None:
         raise SystemExit("the LMDB reader needs the lmdb/cv2/imgaug packages (not in this image); use --synthetic N")
@@ -143,7 +146,7 @@ def main(argv=None):
         dist.init_process_group("nccl")
     config = {
         "log_dir": parsed.log_dir, "log_iterations": parsed.log_iterations, "max_epoch": parsed.max_epoch,
-        "device": torch.device("cuda", local), "phase0_ckpt": parsed.ckpt, "optimizer_args": {"lr": parsed.lr},
+        "device": torch.device("cuda", local), "precision": parsed.precision, "phase0_ckpt": parsed.ckpt, "optimizer_args": {"lr": parsed.lr},
         "speed_noise": parsed.speed_noise,
         "data_args": {"dataset_dir": parsed.dataset_dir, "batch_size": parsed.batch_size, "n_step": N_STEP, "gap": GAP,
                       "augment": parsed.augment, "batch_aug": parsed.batch_aug, "num_workers": 8},

@@ -91,6 +91,8 @@ def main(argv=None):
     parser.add_argument("--speed_noise", type=float, default=0.0)
     parser.add_argument("--lr", type=float, default=1e-4)
     parser.add_argument("--synthetic", type=int, default=20000, help="frames in the synthetic replay buffer")
+    parser.add_argument("--precision", choices=["fp32", "bf16", "bf16_mfma"], default="fp32",
+                        help="fp32 = the reference arithmetic; bf16 = bf16 MFMA operands + bf16 activation storage, f32 master weights")
     parsed = parser.parse_args(argv)
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
@@ -101,6 +103,7 @@ def main(argv=None):
         dist.init_process_group("nccl")
     config = {"log_dir": parsed.log_dir, "log_iterations": parsed.log_iterations, "epoch_per_episode": int(parsed.epoch_per_episode),
               "batch_size": parsed.batch_size, "speed_noise": parsed.speed_noise, "device": device, "rank": rank,
+              "precision": parsed.precision,
               "model_args": {"model": "image_ss", "backbone": BACKBONE},
               "agent_args": {"camera_args": {"w": 384, "h": 160, "fov": 90, "world_y": 1.4, "fixed_offset": 4.0}}}
     bzu.log.init(parsed.log_dir, rank)
@@ -109,6 +112,7 @@ def main(argv=None):
     if parsed.ckpt:
         net.load_state_dict(torch.load(parsed.ckpt, map_location=device))
     teacher = BirdViewPolicyModelSS("resnet18", all_branch=True).to(device)
+    net.precision = teacher.precision = parsed.precision
     if parsed.teacher_path:
         teacher.load_state_dict(torch.load(parsed.teacher_path, map_location=device))
     broadcast_module(net)

@@ -24,23 +24,23 @@ if [[ "$PHASES" == *bench* ]]; then
 fi
 if [[ "$PHASES" == *small* ]]; then
   # per-GPU load of the 8-GPU run (32 images / GPU) on one GPU: predicts strong-scaling efficiency
-  for dt in bf16 f32; do
+  for dt in bf16 bf16_mfma f32; do
     timeout 600 python bench.py --dtype $dt --global-batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_b32_$dt.json > gpurun_out/bench_b32_$dt.log 2>&1
     echo "bench b32 $dt: $(tail -1 gpurun_out/bench_b32_$dt.log | cut -c1-260)" >> gpurun_out/summary.txt
   done
 fi
-if [[ "$PHASES" == *bf16* ]]; then
-  timeout 900 python bench.py --dtype bf16 --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --breakdown gpurun_out/breakdown_bf16.json > gpurun_out/bench_bf16.log 2>&1
-  echo "bench bf16 exit $?" >> gpurun_out/summary.txt
-  tail -1 gpurun_out/bench_bf16.log | cut -c1-900 >> gpurun_out/summary.txt
+if [[ "$PHASES" == *mfma* ]]; then
+  timeout 900 python bench.py --dtype bf16_mfma --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --breakdown gpurun_out/breakdown_bf16_mfma.json > gpurun_out/bench_bf16_mfma.log 2>&1
+  echo "bench bf16_mfma exit $?" >> gpurun_out/summary.txt
+  tail -1 gpurun_out/bench_bf16_mfma.log | cut -c1-900 >> gpurun_out/summary.txt
 fi
 if [[ "$PHASES" == *act* ]]; then
-  # precision 2: bf16 MFMA operands + bf16 activation storage
-  timeout 900 python bench.py --dtype bf16_act --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_bf16_act.json > gpurun_out/bench_bf16_act.log 2>&1
-  echo "bench bf16_act exit $?" >> gpurun_out/summary.txt
-  tail -1 gpurun_out/bench_bf16_act.log | cut -c1-900 >> gpurun_out/summary.txt
-  timeout 600 python bench.py --dtype bf16_act --global-batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_b32_bf16_act.json > gpurun_out/bench_b32_bf16_act.log 2>&1
-  echo "bench b32 bf16_act: $(tail -1 gpurun_out/bench_b32_bf16_act.log | cut -c1-260)" >> gpurun_out/summary.txt
+  # default mixed precision: bf16 MFMA operands + bf16 activation storage
+  timeout 900 python bench.py --dtype bf16 --steps ${BENCH_STEPS:-10} --warmup 3 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_bf16.json > gpurun_out/bench_bf16.log 2>&1
+  echo "bench bf16 exit $?" >> gpurun_out/summary.txt
+  tail -1 gpurun_out/bench_bf16.log | cut -c1-900 >> gpurun_out/summary.txt
+  timeout 600 python bench.py --dtype bf16 --global-batch 32 --steps 20 --warmup 5 --no-cpu-baseline --no-alt --breakdown gpurun_out/breakdown_b32_bf16.json > gpurun_out/bench_b32_bf16.log 2>&1
+  echo "bench b32 bf16: $(tail -1 gpurun_out/bench_b32_bf16.log | cut -c1-260)" >> gpurun_out/summary.txt
 fi
 if [[ "$PHASES" == *diag* ]]; then
   for v in NONE LBC_NO_FUSE_Z1 LBC_NO_DGRAD_WT; do
@@ -65,7 +65,7 @@ fi
 if [[ "$PHASES" == *p32* ]]; then
   # kernel trace at the per-GPU load of the 8-GPU run (32 images): sum of kernel durations vs wall = launch-gap share
   rm -rf gpurun_out/prof32
-  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof32" -o lbc -- python "$OLDPWD/bench.py" --dtype ${PROF_DTYPE:-bf16_act} --global-batch 32 --steps 20 --warmup 3 --init-steps 2 --no-cpu-baseline --no-alt) > gpurun_out/prof32.log 2>&1
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof32" -o lbc -- python "$OLDPWD/bench.py" --dtype ${PROF_DTYPE:-bf16} --global-batch 32 --steps 20 --warmup 3 --init-steps 2 --no-cpu-baseline --no-alt) > gpurun_out/prof32.log 2>&1
   echo "prof32 exit $?" >> gpurun_out/summary.txt
   tail -1 gpurun_out/prof32.log | cut -c1-200 >> gpurun_out/summary.txt
   python scripts/trace_gaps.py $(find gpurun_out/prof32 -name "*kernel_trace.csv" | head -1) >> gpurun_out/summary.txt 2>&1
