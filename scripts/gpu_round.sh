@@ -56,7 +56,7 @@ if [[ "$PHASES" == *ab* ]]; then
 fi
 if [[ "$PHASES" == *prof* ]]; then
   rm -rf gpurun_out/prof
-  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o lbc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --init-steps 2 --no-cpu-baseline) > gpurun_out/prof.log 2>&1
+  (cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/gpurun_out/prof" -o lbc -- python "$OLDPWD/bench.py" --steps 3 --warmup 1 --init-steps 2 --no-cpu-baseline --no-alt) > gpurun_out/prof.log 2>&1
   echo "prof exit $?" >> gpurun_out/summary.txt
   find gpurun_out/prof -name "*kernel_stats*" | head -3 >> gpurun_out/summary.txt
   # keep the (large) raw trace out of the merge budget
@@ -77,7 +77,7 @@ if [[ "$PHASES" == *pmc* ]]; then
   for ctrs in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_INSTS_VALU_MFMA_MOPS_F32" "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
     rm -rf gpurun_out/pmc$i
-    (cd /tmp && timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc$i" -o lbc -- python "$OLDPWD/bench.py" --steps 1 --warmup 1 --init-steps 1 --no-cpu-baseline) > gpurun_out/pmc$i.log 2>&1
+    (cd /tmp && timeout 600 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$OLDPWD/gpurun_out/pmc$i" -o lbc -- python "$OLDPWD/bench.py" --steps 1 --warmup 1 --init-steps 1 --no-cpu-baseline --no-alt) > gpurun_out/pmc$i.log 2>&1
     echo "pmc$i ($ctrs) exit $?" >> gpurun_out/summary.txt
     find gpurun_out/pmc$i -name "*kernel_trace*" -delete
     ls -la gpurun_out/pmc$i/* 2>/dev/null | head -5 >> gpurun_out/summary.txt
