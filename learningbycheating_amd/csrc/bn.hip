@@ -100,32 +100,29 @@ __global__ __launch_bounds__(256) void bn_finalize_k(BnFinalizeArgs a)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
 {
+    constexpr int V = Act<T>::kVec;          // 16-byte accesses: 4 f32 or 8 bf16 channels per thread
+    using vec = typename Act<T>::vec;
+    using PV = ParamVec<V>;
     const T* x = static_cast<const T*>(a.x);
     const T* resid = static_cast<const T*>(a.resid);
     T* y = static_cast<T*>(a.y);
-    const int c4n = a.C / 4;
-    const long long total4 = a.pixels * c4n;
+    const int cvn = a.C / V;
+    const long long total = a.pixels * cvn;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        const int c = (int)(i % c4n) * 4;
-        f32x4 v = Act<T>::ld4(x + i * 4);
-        const f32x4 s = *reinterpret_cast<const f32x4*>(a.scale + c);
-        const f32x4 t = *reinterpret_cast<const f32x4*>(a.shift + c);
-        v = v * s + t;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int c = (int)(i % cvn) * V;
+        vec v = Act<T>::ldv(x + i * V);
+        v = v * PV::ld(a.scale + c) + PV::ld(a.shift + c);
         if (resid) {
-            f32x4 r = Act<T>::ld4(resid + i * 4);
-            if (a.rscale) {
-                const f32x4 rs = *reinterpret_cast<const f32x4*>(a.rscale + c);
-                const f32x4 rt = *reinterpret_cast<const f32x4*>(a.rshift + c);
-                r = r * rs + rt;
-            }
+            vec r = Act<T>::ldv(resid + i * V);
+            if (a.rscale) r = r * PV::ld(a.rscale + c) + PV::ld(a.rshift + c);
             v += r;
         }
         if (a.relu) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            for (int e = 0; e < V; ++e) v[e] = fmaxf(v[e], 0.f);
         }
-        Act<T>::st4(y + i * 4, v);
+        Act<T>::stv(y + i * V, v);
     }
 }
 
@@ -136,66 +133,64 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
 template <int OP, typename T>
 __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float red[2 * 256 * 4];
+    constexpr int V = Act<T>::kVec;
+    using vec = typename Act<T>::vec;
+    using PV = ParamVec<V>;
+    __shared__ __attribute__((aligned(16))) float red[2 * 256 * V];
     const T* xx = static_cast<const T*>(a.x);
     const T* dz = static_cast<const T*>(a.dz);
     const T* mask = static_cast<const T*>(a.mask);
     T* g_out = static_cast<T*>(a.g_out);
-    const int c4n = a.C / 4;
-    const int rl = 256 / c4n;
-    const int cg = threadIdx.x % c4n;
-    const int pl = threadIdx.x / c4n;
-    const int c = cg * 4;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    const int cvn = a.C / V;
+    const int rl = 256 / cvn;
+    const int cg = threadIdx.x % cvn;
+    const int pl = threadIdx.x / cvn;
+    const int c = cg * V;
+    vec s1 = PV::splat(0.f), s2 = s1;
     if (pl < rl) {
-        f32x4 mean = {0.f, 0.f, 0.f, 0.f}, inv = {1.f, 1.f, 1.f, 1.f};
-        f32x4 msc = {1.f, 1.f, 1.f, 1.f}, msh = {0.f, 0.f, 0.f, 0.f};
-        if (OP == 1 && a.mean) {
-            mean = *reinterpret_cast<const f32x4*>(a.mean + c);
-            inv = *reinterpret_cast<const f32x4*>(a.invstd + c);
-        }
-        if (OP == 1 && a.mask_scale) {
-            msc = *reinterpret_cast<const f32x4*>(a.mask_scale + c);
-            msh = *reinterpret_cast<const f32x4*>(a.mask_shift + c);
-        }
+        vec mean = PV::splat(0.f), inv = PV::splat(1.f);
+        vec msc = PV::splat(1.f), msh = PV::splat(0.f);
+        if (OP == 1 && a.mean) { mean = PV::ld(a.mean + c); inv = PV::ld(a.invstd + c); }
+        if (OP == 1 && a.mask_scale) { msc = PV::ld(a.mask_scale + c); msh = PV::ld(a.mask_shift + c); }
         const long long p0 = (long long)blockIdx.x * a.pix_per_block;
         long long p1 = p0 + a.pix_per_block;
         if (p1 > a.pixels) p1 = a.pixels;
+#pragma unroll 2
         for (long long p = p0 + pl; p < p1; p += rl) {
-            const long long i = (p * c4n + cg) * 4;
+            const long long i = (p * cvn + cg) * V;
             if (OP == 0) {            // plain statistics of x: sum x, sum x^2
-                const f32x4 v = Act<T>::ld4(xx + i);
+                const vec v = Act<T>::ldv(xx + i);
                 s1 += v;
                 s2 += v * v;
             } else {                  // backward: g = dz * (mask > 0); sum g, sum g * xhat
-                f32x4 g = Act<T>::ld4(dz + i);
+                vec g = Act<T>::ldv(dz + i);
                 if (mask) {
-                    f32x4 m = Act<T>::ld4(mask + i);
+                    vec m = Act<T>::ldv(mask + i);
                     if (a.mask_scale) m = m * msc + msh;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+                    for (int e = 0; e < V; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
                 }
-                if (g_out) Act<T>::st4(g_out + i, g);
+                if (g_out) Act<T>::stv(g_out + i, g);
                 s1 += g;
                 if (xx) {
-                    const f32x4 v = Act<T>::ld4(xx + i);
+                    const vec v = Act<T>::ldv(xx + i);
                     s2 += g * (v - mean) * inv;
                 }
             }
         }
     }
-    reinterpret_cast<f32x4*>(red)[threadIdx.x] = s1;
-    reinterpret_cast<f32x4*>(red)[256 + threadIdx.x] = s2;
+    PV::st(red + threadIdx.x * V, s1);
+    PV::st(red + (256 + threadIdx.x) * V, s2);
     __syncthreads();
-    if (threadIdx.x < c4n) {
-        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+    if (threadIdx.x < cvn) {
+        vec t1 = PV::splat(0.f), t2 = t1;
         for (int k = 0; k < rl; ++k) {
-            t1 += reinterpret_cast<const f32x4*>(red)[k * c4n + threadIdx.x];
-            t2 += reinterpret_cast<const f32x4*>(red)[256 + k * c4n + threadIdx.x];
+            t1 += PV::ld(red + (k * cvn + threadIdx.x) * V);
+            t2 += PV::ld(red + (256 + k * cvn + threadIdx.x) * V);
         }
         float* dst = a.partial + (size_t)blockIdx.x * 2 * a.C;
-        *reinterpret_cast<f32x4*>(dst + c) = t1;
-        *reinterpret_cast<f32x4*>(dst + a.C + c) = t2;
+        PV::st(dst + c, t1);
+        PV::st(dst + a.C + c, t2);
     }
 }
 
@@ -228,34 +223,32 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdApplyArgs a)
 {
+    constexpr int V = Act<T>::kVec;
+    using vec = typename Act<T>::vec;
+    using PV = ParamVec<V>;
     const T* gp = static_cast<const T*>(a.g);
     const T* mask = static_cast<const T*>(a.mask);
     const T* xx = static_cast<const T*>(a.x);
     T* dx = static_cast<T*>(a.dx);
-    const int c4n = a.C / 4;
-    const int o4n = a.Cout / 4;
-    const long long total4 = a.pixels * o4n;
+    const int cvn = a.C / V;
+    const int ovn = a.Cout / V;
+    const long long total = a.pixels * ovn;
     const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += stride) {
-        const long long p = i / o4n;
-        const int cg = (int)(i - p * o4n);
-        const int c = cg * 4;
-        const long long j = (p * c4n + cg) * 4;
-        f32x4 g = Act<T>::ld4(gp + j);
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const long long p = i / ovn;
+        const int cg = (int)(i - p * ovn);
+        const int c = cg * V;
+        const long long j = (p * cvn + cg) * V;
+        vec g = Act<T>::ldv(gp + j);
         if (mask) {
-            const f32x4 m = Act<T>::ld4(mask + j);
+            const vec m = Act<T>::ldv(mask + j);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
+            for (int e = 0; e < V; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
         }
-        const f32x4 v = Act<T>::ld4(xx + j);
-        const f32x4 A = *reinterpret_cast<const f32x4*>(a.coefA + c);
-        const f32x4 K1 = *reinterpret_cast<const f32x4*>(a.coefB + c);
-        const f32x4 K2 = *reinterpret_cast<const f32x4*>(a.coefD + c);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(a.mean + c);
-        const f32x4 iv = *reinterpret_cast<const f32x4*>(a.invstd + c);
-        f32x4 o = A * (g - K1 - (v - mu) * iv * K2);
-        if (a.accum) o += Act<T>::ld4(dx + i * 4);
-        Act<T>::st4(dx + i * 4, o);
+        const vec v = Act<T>::ldv(xx + j);
+        vec o = PV::ld(a.coefA + c) * (g - PV::ld(a.coefB + c) - (v - PV::ld(a.mean + c)) * PV::ld(a.invstd + c) * PV::ld(a.coefD + c));
+        if (a.accum) o += Act<T>::ldv(dx + i * V);
+        Act<T>::stv(dx + i * V, o);
     }
 }
 
@@ -309,10 +302,10 @@ int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s)
 
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)
 {
-    LBC_REQUIRE(a.C % 4 == 0 && a.pixels > 0, "bn_apply: bad shape");
+    LBC_REQUIRE(a.C % 8 == 0 && a.pixels > 0, "bn_apply: bad shape");
     LbcProfScope prof("bn_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * a.C * (a.resid ? 3 : 2), s);
 #define LBC_K(T, g) hipLaunchKernelGGL((bn_apply_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
-    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.C / 4)));
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.C / (a.act_bf16 ? 8 : 4))));
 #undef LBC_K
     return lbc_check_launch("bn_apply");
 }
@@ -335,7 +328,7 @@ int lbc_chan_reduce_rows(long long pixels, int C)
 
 int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
 {
-    LBC_REQUIRE(a.C % 4 == 0 && a.C / 4 <= 256, "chan_reduce: C=%d unsupported", a.C);
+    LBC_REQUIRE(a.C % 8 == 0 && a.C / 4 <= 256, "chan_reduce: C=%d unsupported", a.C);
     const int rows = lbc_chan_reduce_rows(a.pixels, a.C);
     a.pix_per_block = (a.pixels + rows - 1) / rows;
     LbcProfScope prof(op == 0 ? "channel_stats" : "bn_bwd_reduce", 0.0,
@@ -356,10 +349,10 @@ int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s)
 
 int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s)
 {
-    LBC_REQUIRE(a.C % 4 == 0 && a.Cout % 4 == 0 && a.Cout <= a.C, "bn_bwd_apply: bad channels");
+    LBC_REQUIRE(a.C % 8 == 0 && a.Cout % 8 == 0 && a.Cout <= a.C, "bn_bwd_apply: bad channels");
     LbcProfScope prof("bn_bwd_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * (a.C * (a.mask ? 3.0 : 2.0) + a.Cout * (a.accum ? 2.0 : 1.0)), s);
 #define LBC_K(T, g) hipLaunchKernelGGL((bn_bwd_apply_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
-    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.Cout / 4)));
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.Cout / (a.act_bf16 ? 8 : 4))));
 #undef LBC_K
     return lbc_check_launch("bn_bwd_apply");
 }

@@ -198,15 +198,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_f32(WgradArgs a, int rows_per_
 // banks, and a row is 36 dwords, so lanes of a group that differ only in their channel group (8 rows = 288 dwords = 0
 // mod 32) collide: the micro-tile index therefore puts KB channel-group bits and 4-KB pixel-group bits into the low 4
 // lane bits (KB = 1: f32 input conflict-free, bf16 input 2-way; loads still cover whole 128-byte lines per wave).
-template <int CG, int KB>
-__device__ __forceinline__ void wgrad_tile_coord(int u, int& cg, int& pg)
-{
-    constexpr int LCG = CG == 32 ? 5 : CG == 16 ? 4 : CG == 8 ? 3 : 2;
-    static_assert(KB <= LCG && KB <= 4, "wgrad: lane mapping");
-    cg = (u & ((1 << KB) - 1)) | (((u >> 4) & ((1 << (LCG - KB)) - 1)) << KB);
-    pg = ((u >> KB) & ((1 << (4 - KB)) - 1)) | (((u >> (4 + LCG - KB)) & ((1 << KB) - 1)) << (4 - KB));
-}
-
 template <int BP, int BQ, typename AT, int KB>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_per_split)
 {

@@ -647,7 +647,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
         LBC_TRY(lbc_bn_bwd_apply(ap, s));
         StemWgradArgs sw;
         sw.xp = W(xp_); sw.dy = W(g0_); sw.partial = W(wg_partial_);
-        sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels; sw.act_bf16 = act_bf16_;
+        sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels; sw.act_bf16 = act_bf16_; sw.bf16 = bf16_;
         sw.nsplit = lbc_stem_wgrad_split(N, H0, W0);
         LBC_TRY(lbc_stem_wgrad(sw, s));
         LBC_TRY(lbc_splitk_reduce(sw.partial, sw.nsplit, (long long)64 * 49 * d_.in_channels, G(stem_w_), 0.f, s));

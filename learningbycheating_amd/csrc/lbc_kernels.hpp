@@ -95,6 +95,7 @@ struct StemWgradArgs {
     const float* xp; const void* dy; float* partial;   // partial [nsplit][64][7][7*Cin]; dy f32 or bf16
     int N, H, W, Cin, nsplit;
     int act_bf16;
+    int bf16;                    // 1: bf16 MFMA operands (f32 accumulation)
 };
 int lbc_stem_wgrad_split(int N, int H, int W);
 int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s);

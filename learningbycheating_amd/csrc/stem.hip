@@ -13,6 +13,7 @@
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include "lbc_kernels.hpp"
+#include <type_traits>
 
 namespace {
 
@@ -400,6 +401,141 @@ __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_pe
     }
 }
 
+// bf16-MFMA weight gradient of the stem (precision >= 1): contraction over pixels on v_mfma_f32_32x32x16_bf16, both
+// operands transposed in registers into [channel][64 pixels] LDS tiles exactly like conv_wgrad_bf16_k (4 pixels x 4
+// channels per thread, 8-byte column writes, conflict-aware lane order).  grid (split, filter row r).
+template <int CIN, typename T>
+__global__ __launch_bounds__(256) void stem_wgrad_bf16_k(StemWgradArgs a, int rows_per_split)
+{
+    constexpr bool ABF = Act<T>::kBf16;
+    using preg_t = typename std::conditional<ABF, bf16x4, f32x4>::type;
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    constexpr int L = 7 * CIN;
+    constexpr int LQ = (L + 31) / 32 * 32;   // 32 or 64 filter-row columns (zero padded)
+    constexpr int QT = LQ / 32;              // column tiles (1 or 2)
+    constexpr int KS = 2 / QT;               // with one column tile the two wave pairs split the 64-pixel depth of a chunk
+    constexpr int BRH = 64, LD = BRH + 8;
+    constexpr int CGQ = LQ / 4;              // 8 or 16 column groups
+    constexpr int TQ_ = 16 * CGQ;            // Q micro-tiles per chunk (128 or 256)
+    constexpr int KB = 2;
+    __shared__ __attribute__((aligned(16))) __bf16 sP[2][64 * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 sQ[2][LQ * LD];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int pt = wave & 1;                       // which 32 output channels
+    const int qt = QT == 2 ? (wave >> 1) : 0;      // which 32 filter-row columns
+    const int ks = QT == 2 ? 0 : (wave >> 1);      // which half of the chunk's pixels
+    const int OH = a.H / 2, OW = a.W / 2;
+    const int Hp = a.H + 6, Wp = a.W + 6;
+    const int M = a.N * OH * OW;
+    const int split = blockIdx.x, r = blockIdx.y;
+    const int mbeg = split * rows_per_split;
+    const int mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
+    const int nchunk = mend > mbeg ? (mend - mbeg + BRH - 1) / BRH : 0;
+    const T* dy = static_cast<const T*>(a.dy);
+
+    int pcg, ppg, qcg, qpg;
+    wgrad_tile_coord<16, KB>(tid, pcg, ppg);                 // P: 16 channel groups x 16 pixel groups = 256 micro-tiles
+    wgrad_tile_coord<CGQ, KB>(tid, qcg, qpg);
+    const bool qactive = tid < TQ_;
+    // coordinates of the first pixel of this thread's Q micro-tile, advanced by 64 per chunk without divisions
+    int qn, qy, qx;
+    {
+        const int m = mbeg + 4 * qpg;
+        qn = m / (OH * OW);
+        const int rem = m - qn * OH * OW;
+        qy = rem / OW; qx = rem - qy * OW;
+    }
+
+    f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+
+    preg_t rp[4];
+    f32x2 rq[4][2];
+    bool pok[4], qok[4];
+    for (int ch = -1; ch < nchunk; ++ch) {
+        const bool more = ch + 1 < nchunk;
+        if (more) {
+            const int mc = mbeg + (ch + 1) * BRH;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mc + 4 * ppg + i;
+                pok[i] = m < mend;
+                rp[i] = *reinterpret_cast<const preg_t*>(dy + (size_t)(pok[i] ? m : 0) * 64 + (size_t)(pcg * 4));
+            }
+            int n = qn, y = qy, x = qx;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mc + 4 * qpg + i;
+                qok[i] = (m < mend) && qactive;
+                const long long base = qok[i] ? (long long)((n * Hp + 2 * y + r) * Wp + 2 * x) * CIN + qcg * 4 : 0;
+                rq[i][0] = *reinterpret_cast<const f32x2*>(a.xp + base);        // 8-byte aligned: every offset is even
+                rq[i][1] = *reinterpret_cast<const f32x2*>(a.xp + base + 2);
+                if (++x >= OW) { x = 0; if (++y >= OH) { y = 0; ++n; } }
+            }
+            qx += BRH;
+            while (qx >= OW) { qx -= OW; ++qy; }
+            while (qy >= OH) { qy -= OH; ++qn; }
+        }
+        if (ch >= 0) {
+            const int buf = ch & 1;
+#pragma unroll
+            for (int g = 0; g < BRH / 16 / KS; ++g) {
+                const int gg = g + ks * (BRH / 16 / KS);
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sP[buf][(pt * 32 + l31) * LD + gg * 16 + kh * 8]);
+                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&sQ[buf][(qt * 32 + l31) * LD + gg * 16 + kh * 8]);
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc, 0, 0, 0);
+            }
+        }
+        if (more) {
+            const int buf = (ch + 1) & 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) col[i] = pok[i] ? (float)rp[i][c] : 0.f;
+                *reinterpret_cast<bf16x4*>(&sP[buf][(pcg * 4 + c) * LD + ppg * 4]) = __builtin_convertvector(col, bf16x4);
+            }
+            if (qactive) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    f32x4 col;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) col[i] = (qok[i] && (qcg * 4 + c) < L) ? rq[i][c >> 1][c & 1] : 0.f;   // pad columns: exact zeros
+                    *reinterpret_cast<bf16x4*>(&sQ[buf][(qcg * 4 + c) * LD + qpg * 4]) = __builtin_convertvector(col, bf16x4);
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (KS == 2) {
+        // combine the two depth halves: waves 2,3 hand their accumulators to waves 0,1 through LDS
+        float* red = reinterpret_cast<float*>(&sP[0][0]);   // [2 pt][16][64] floats = 8 KB (sP holds 18 KB)
+        if (ks == 1) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) red[(pt * 16 + e) * 64 + lane] = acc[e];
+        }
+        __syncthreads();
+        if (ks == 0) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[e] += red[(pt * 16 + e) * 64 + lane];
+        }
+    }
+    if (ks == 0) {
+        float* out = a.partial + (size_t)split * 64 * 7 * L;
+        const int j = qt * 32 + l31;
+        if (j < L) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                out[(size_t)co * (7 * L) + (size_t)(r * L + j)] = acc[e];
+            }
+        }
+    }
+}
+
 }  // namespace
 
 int lbc_prep_input(const float* img_nchw, float* xp, int N, int C, int H, int W, const NormConst& nc, hipStream_t s)
@@ -451,13 +587,20 @@ int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.Cin == 3 || a.Cin == 7, "stem_wgrad: Cin=%d unsupported", a.Cin);
     const long long M = (long long)a.N * (a.H / 2) * (a.W / 2);
-    const long long chunks = (M + 31) / 32;
-    const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 32;
+    const int br = a.bf16 ? 64 : 32;                         // pixels per chunk of the kernel
+    const long long chunks = (M + br - 1) / br;
+    const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * br;
     const dim3 grid((unsigned)a.nsplit, 7);
+    LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem_wgrad: bf16 gradients need bf16 = 1");
     LbcProfScope prof("stem_wgrad", 2.0 * M * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (double)M * 64), s);
-#define LBC_K(T, CI) hipLaunchKernelGGL((stem_wgrad_k<CI, T>), grid, dim3(256), 0, s, a, rows_per_split)
-    if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
-    else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
+    if (a.bf16) {
+#define LBC_K(T, CI) hipLaunchKernelGGL((stem_wgrad_bf16_k<CI, T>), grid, dim3(256), 0, s, a, rows_per_split)
+        if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
+        else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
 #undef LBC_K
+    } else {
+        if (a.Cin == 3) hipLaunchKernelGGL((stem_wgrad_k<3, float>), grid, dim3(256), 0, s, a, rows_per_split);
+        else            hipLaunchKernelGGL((stem_wgrad_k<7, float>), grid, dim3(256), 0, s, a, rows_per_split);
+    }
     return lbc_check_launch("stem_wgrad");
 }
