@@ -34,7 +34,9 @@ typedef struct lbc_conv_desc {
     int relu;           /* fuse ReLU into the epilogue */
     int bf16;           /* 0: exact f32 MFMA.  1: MFMA operands rounded to bf16 (RNE), f32 accumulate; tensors stay f32.
                            2: as 1, and the activation tensors (x, y, resid, dy, dx: the `void*` arguments) are bf16 in
-                           HBM; weights, bias, statistics and weight gradients stay f32 */
+                           HBM; weights, bias, statistics and weight gradients stay f32.
+                           3: as 2, and `w` of the forward / input-gradient entry points is a bf16 copy of the weights in
+                           the same (depth-contiguous) layout; weight gradients are still produced in f32 */
     int w_transposed;   /* lbc_conv2d_dgrad / lbc_deconv3x3s2_fwd only: `w` is the lbc_weight_transpose()d copy (depth-
                            contiguous for these GEMMs).  Required when bf16 = 1. */
 } lbc_conv_desc;
@@ -44,7 +46,7 @@ typedef struct lbc_conv_desc {
  * pre_scale != NULL (the producing BatchNorm applied on load; zero padding stays zero).
  * stats (nullable): per-workgroup partial (sum, sum^2) of y per channel, [rows][2][K];
  * *stats_rows receives the number of rows written (query with stats == NULL allowed). */
-int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
+int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const void* w, const float* bias,
                    const void* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
                    void* y, float* stats, int* stats_rows, lbc_stream_t stream);
 
@@ -54,7 +56,7 @@ int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc
 
 /* Input gradient of nn.Conv2d (autograd of the call sites above; loss.backward() at
  * training/train_image_phase1.py:204).  dx[N,H,W,C] = dgrad(dy[N,OH,OW,K], w) (+resid). */
-int lbc_conv2d_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, const void* resid,
+int lbc_conv2d_dgrad(const lbc_conv_desc* d, const void* dy, const void* w, const void* resid,
                      void* dx, lbc_stream_t stream);
 
 /* Weight gradient of nn.Conv2d.  dw[K][KH][KW][C] = beta*dw + sum_m dy[m][k] * x'[gather(m)][c].
@@ -66,10 +68,10 @@ int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
 
 /* nn.ConvTranspose2d(C,K,3,2,1,1) forward (reference bird_view/models/image.py:39,42,45;
  * birdview.py:37,40,43).  x[N,H,W,C] -> y[N,2H,2W,K]; d->KH=KW=3, S=2, P=1 required. */
-int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
+int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const void* w, const float* bias,
                         const float* pre_scale, const float* pre_shift, int pre_relu,
                         void* y, float* stats, int* stats_rows, lbc_stream_t stream);
-int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, void* dx, lbc_stream_t stream);
+int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const void* dy, const void* w, void* dx, lbc_stream_t stream);
 size_t lbc_deconv3x3s2_wgrad_workspace(const lbc_conv_desc* d);
 int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                           const float* pre_scale, const float* pre_shift, int pre_relu,

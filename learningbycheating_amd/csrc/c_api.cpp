@@ -22,11 +22,11 @@ static IgemmArgs conv_args(const lbc_conv_desc* d)
     a.N = d->N; a.H = d->H; a.W = d->W; a.C = d->C; a.K = d->K;
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
     a.relu = d->relu;
-    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
+    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 >= 2; a.w_bf16 = d->bf16 == 3;
     return a;
 }
 
-int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
+int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const void* w, const float* bias,
                    const void* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
                    void* y, float* stats, int* stats_rows, lbc_stream_t stream)
 {
@@ -45,7 +45,7 @@ int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const float* w, const 
 }
 
 // dgrad of a Conv2d with geometry d: gathered tensor = dy [N,OH,OW,K], output = dx [N,H,W,C]
-static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const float* w, int wmajor, const void* resid,
+static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const void* w, int wmajor, const void* resid,
                            const float* bias, const float* pre_scale, const float* pre_shift, int pre_relu,
                            int relu, void* dx, float* stats, int* stats_rows, hipStream_t s)
 {
@@ -53,7 +53,7 @@ static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const float* 
     const int OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu; a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
+    a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu; a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 >= 2; a.w_bf16 = d->bf16 == 3;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
     a.N = d->N; a.H = OH; a.W = OW; a.C = d->K;
     a.OH = d->H; a.OW = d->W; a.K = d->C;
@@ -92,7 +92,7 @@ int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc
     return lbc_weight_transpose(w, wt, A, T, B, (hipStream_t)stream);
 }
 
-int lbc_conv2d_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, const void* resid,
+int lbc_conv2d_dgrad(const lbc_conv_desc* d, const void* dy, const void* w, const void* resid,
                      void* dx, lbc_stream_t stream)
 {
     LBC_REQUIRE(d, "conv2d_dgrad: null desc");
@@ -113,7 +113,7 @@ static lbc_conv_desc deconv_as_conv(const lbc_conv_desc* d)
     return c;
 }
 
-int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const float* w, const float* bias,
+int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const void* w, const float* bias,
                         const float* pre_scale, const float* pre_shift, int pre_relu,
                         void* y, float* stats, int* stats_rows, lbc_stream_t stream)
 {
@@ -124,7 +124,7 @@ int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const float* w, c
                            stats_rows, (hipStream_t)stream);
 }
 
-int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const void* dy, const float* w, void* dx, lbc_stream_t stream)
+int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const void* dy, const void* w, void* dx, lbc_stream_t stream)
 {
     LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_dgrad: geometry must be k3 s2 p1 op1");
     lbc_conv_desc c = deconv_as_conv(d);
@@ -144,7 +144,7 @@ static WgradArgs conv_wgrad_args(const lbc_conv_desc* d)
     a.CP = d->K;
     a.H = d->H; a.W = d->W; a.CQ = d->C;
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
-    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
+    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 >= 2;
     a.nsplit = lbc_wgrad_pick_split(a);
     return a;
 }
@@ -179,7 +179,7 @@ static WgradArgs deconv_wgrad_args(const lbc_conv_desc* d)
     a.N = d->N; a.OH = d->H; a.OW = d->W; a.CP = d->C;
     a.H = 2 * d->H; a.W = 2 * d->W; a.CQ = d->K;
     a.KH = 3; a.KW = 3; a.S = 2; a.P = 1;
-    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 == 2;
+    a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 >= 2;
     a.nsplit = lbc_wgrad_pick_split(a);
     return a;
 }

@@ -19,6 +19,7 @@
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include <type_traits>
+#include <stdlib.h>
 
 namespace {
 
@@ -442,6 +443,7 @@ int lbc_igemm_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kCfgBM[cf
 
 int lbc_igemm_pick(long long M, int K)
 {
+    if (const char* e = getenv("LBC_FORCE_CFG")) { const int c = atoi(e); if (c >= 0 && c < 3 && K % kCfgBN[c] == 0) return c; }   // tests / tuning
     // Prefer the largest tile that still gives the 256 CUs >= 1.5 waves of workgroups.
     const long long want = 384;
     if (K % 128 == 0 && ((M + 127) / 128) * (K / 128) >= want) return 1;
@@ -473,6 +475,7 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * a.K * (double)a.C * taps,
                       (a.act_bf16 ? 2.0 : 4.0) * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) +
                                                   (double)a.M * a.K * (a.resid ? 2 : 1)) + (a.w_bf16 ? 2.0 : 4.0) * (double)taps * a.C * a.K, s);
+    if (cfg != 2 && wmajor && lbc_conv3x3_halo_eligible(a, mode)) return lbc_conv3x3_halo_launch(a, mode, kCfgBN[cfg], s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);
         case 1: return launch_cfg<128, 128>(a, wmajor, mode, s);

@@ -1,6 +1,6 @@
 """Per-layer timing of the convolution family through the C ABI (include/lbc_hip.h) on the ResNet-34 / decoder shapes
 of ImagePolicyModelSS at a given batch.  Prints ms and TFLOP/s per (layer, op, mode); mode 0 = exact f32, 1 = bf16 MFMA
-operands with f32 tensors, 2 = bf16 operands and bf16 tensors.  Usage: python scripts/bench_ops.py [batch] [modes] [ops]
+operands with f32 tensors, 2 = bf16 operands and bf16 tensors, 3 = 2 + bf16 weight copies (fwd / dgrad).  Usage: python scripts/bench_ops.py [batch] [modes] [ops]
 """
 import ctypes
 import sys
@@ -47,7 +47,7 @@ def main():
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * N * OH * OW * K * C * k * k
         for mode in modes:
-            at = torch.bfloat16 if mode == 2 else torch.float32
+            at = torch.bfloat16 if mode >= 2 else torch.float32
             x = torch.randn((N, H, W, C), device=dev).to(at)
             dy = torch.randn((N, OH, OW, K), device=dev).to(at)
             w = torch.randn((K, k, k, C), device=dev) * 0.05
@@ -62,6 +62,8 @@ def main():
             _lib.check(lib.lbc_weight_transpose_f32(P(w), P(wt), K, k * k, C, st))
             ws = torch.empty(lib.lbc_conv2d_wgrad_workspace(ctypes.byref(d)) // 4 + 1, device=dev)
             rows = ctypes.c_int(0)
+            if mode == 3:          # bf16 weight copies (what the executor's weight_prep produces)
+                w, wt = w.to(torch.bfloat16), wt.to(torch.bfloat16)
             runs = {
                 "fwd": lambda: _lib.check(lib.lbc_conv2d_fwd(ctypes.byref(d), P(x), P(w), None, None, None, None, 0, P(y), None, ctypes.byref(rows), st)),
                 "fwd+bn": lambda: _lib.check(lib.lbc_conv2d_fwd(ctypes.byref(d), P(x), P(w), None, None, P(ps), P(pt), 1, P(y), None, ctypes.byref(rows), st)),

@@ -26,7 +26,7 @@ def guarded(shape, device, fill=float("nan"), dtype=torch.float32):
 
 def act_dtype(bf16):
     """element type of the activation tensors for lbc_conv_desc.bf16 (2 = bf16 tensors in HBM)"""
-    return torch.bfloat16 if bf16 == 2 else torch.float32
+    return torch.bfloat16 if bf16 >= 2 else torch.float32
 
 
 def check_guard(buf, n):
@@ -55,6 +55,8 @@ class Conv:
         OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
         at = act_dtype(bf16)
         xh, wh = nhwc(x).to(self.dev).to(at), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
+        if bf16 == 3:
+            wh = wh.to(torch.bfloat16)       # bf16 weight copy, same [K][kh][kw][C] layout
         buf, y = guarded((N, OH, OW, K), self.dev, dtype=at)
         rows = ctypes.c_int(0)
         _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
@@ -75,6 +77,8 @@ class Conv:
         dyh, wh = nhwc(dy).to(self.dev).to(at), w.permute(0, 2, 3, 1).contiguous().to(self.dev)
         if transposed:
             wh = self.transpose(wh.view(K, k * k, C), K, k * k, C)
+        if bf16 == 3:
+            wh = wh.to(torch.bfloat16)
         r = nhwc(resid).to(self.dev).to(at) if resid is not None else None
         buf, dx = guarded((N, H, W, C), self.dev, dtype=at)
         _lib.check(self.lib.lbc_conv2d_dgrad(ctypes.byref(d), _lib.ptr(dyh), _lib.ptr(wh), _lib.ptr(r), _lib.ptr(dx), _lib.stream_for(dyh)))

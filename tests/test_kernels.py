@@ -268,3 +268,54 @@ def test_deconv_bf16_mode(env, cfg, mode):
     F.conv_transpose2d(xr, wr, None, 2, 1, 1).backward(rbf(dy))
     dx, dw = bwd(dy)
     assert relerr(dx, xr.grad) < 1e-4 + OUT_TOL[mode] and relerr(dw, wr.grad) < 5e-4
+
+
+# ---- halo-staged 3x3 / stride-1 kernel (conv_halo.hip): bf16 tensors + bf16 weight copies, 128-row tiles ------------------
+HALO_SMALL = [(1, 5, 12, 64, 64), (2, 6, 7, 128, 64), (1, 9, 8, 64, 128), (3, 4, 5, 64, 64)]
+HALO_REAL = [pytest.param(c, marks=gpu) for c in [(8, 40, 96, 64, 64), (4, 20, 48, 128, 128), (8, 10, 24, 256, 256), (16, 5, 12, 512, 512), (3, 48, 48, 64, 64)]]
+
+
+@pytest.fixture
+def force_cfg():
+    import os
+
+    def set_cfg(c):
+        os.environ["LBC_FORCE_CFG"] = str(c)
+    yield set_cfg
+    os.environ.pop("LBC_FORCE_CFG", None)
+
+
+@pytest.mark.parametrize("cfg", HALO_SMALL + HALO_REAL)
+def test_conv3x3_halo_fwd(env, cfg, force_cfg):
+    """forward with BatchNorm+ReLU on load, statistics partials, odd widths and tiles straddling images"""
+    dev, _ = env
+    N, H, W, C, K = cfg
+    force_cfg(1 if K % 128 == 0 else 0)
+    x, w = make((N, H, W, C, K, 3, 1, 1), 50)
+    x = rbf(x)
+    g = torch.Generator().manual_seed(51)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    ref = F.conv2d(rbf(xin), rbf(w), None, 1, 1)
+    y, st = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
+    assert relerr(y, ref) < 5e-4 + OUT_TOL[2]
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    # without the prologue, with a residual
+    r = rbf(torch.randn(ref.shape, generator=g))
+    y2, _ = Conv(dev).fwd(x, w, 1, 1, resid=r, relu=1, bf16=3)
+    assert relerr(y2, F.relu(F.conv2d(x, rbf(w), None, 1, 1) + r)) < 1e-4 + OUT_TOL[2]
+
+
+@pytest.mark.parametrize("cfg", HALO_SMALL[:3] + HALO_REAL[:3])
+def test_conv3x3_halo_dgrad(env, cfg, force_cfg):
+    dev, _ = env
+    N, H, W, C, K = cfg
+    force_cfg(1 if C % 128 == 0 else 0)     # the input gradient's output channels are the convolution's input channels
+    x, w = make((N, H, W, C, K, 3, 1, 1), 52)
+    x.requires_grad_(True)
+    y = F.conv2d(x, rbf(w), None, 1, 1)
+    dy = rbf(torch.randn(y.shape, generator=torch.Generator().manual_seed(53)))
+    y.backward(dy)
+    r = rbf(torch.randn(x.shape, generator=torch.Generator().manual_seed(54)))
+    dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=r, bf16=3, transposed=True)
+    assert relerr(dx, x.grad + r) < 1e-4 + OUT_TOL[2]
