@@ -29,192 +29,222 @@ __global__ __launch_bounds__(256) void conv3x3_halo_k(IgemmArgs a)
     constexpr int HJ = (kHaloRowsMax * 8 + 255) / 256;   // 16-byte halo loads per thread per slab (11)
     __shared__ __attribute__((aligned(16))) __bf16 sH[kHaloRowsMax * LDK];
     __shared__ __attribute__((aligned(16))) __bf16 sB[2][BN * LDK];
+    __shared__ float sRed[4 * BN];                   // statistics: [2 wm][2][BN]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
     const int ntn = a.K / BN;
-    int tile_id;
-    {   // XCD-aware tile order, see conv_igemm.hip
-        const int nwg = gridDim.x, b = blockIdx.x;
-        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
-        tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
-    }
-    const int mtile = tile_id / ntn;
-    const int m0 = mtile * BM;
-    const int n0 = (tile_id - mtile * ntn) * BN;
     const int W = a.W, H = a.H, C = a.C;
     const int M = a.M;                       // N * H * W
     const int HR = BM + 2 * W + 2;           // halo rows
-    const int hbase = m0 - W - 1;            // raster index of halo row 0
+    const int ntiles = ((M + BM - 1) / BM) * ntn;
+    const int G = (int)gridDim.x;
     const __bf16* xin = static_cast<const __bf16*>(a.x);
     const __bf16* win = static_cast<const __bf16*>(a.w);
-
-    // validity of the 9 taps for this lane's MT output pixels
-    int vmask[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-        const int m = m0 + (wm * MT + i) * 32 + l31;
-        int bits = 0;
-        if (m < M) {
-            const int x = m % W;
-            const int y = (m / W) % H;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, s = t - 3 * r;
-                const int dy = MODE == 0 ? r - 1 : 1 - r;
-                const int dx = MODE == 0 ? s - 1 : 1 - s;
-                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
-            }
-        }
-        vmask[i] = bits;
-    }
+    __bf16* yout = static_cast<__bf16*>(a.y);
+    const __bf16* resid = static_cast<const __bf16*>(a.resid);
 
     const int seg = tid & 7;        // 16-byte segment (8 channels) of a 64-channel row
     const int row0 = tid >> 3;      // staging row (+32 per pass)
     const float relu_floor = (a.pre_scale && a.pre_relu) ? 0.f : -INFINITY;
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    const int nslab = C / BK;
+    const int nit = nslab * 9;
 
     bf16x8 rh[HJ];
     bf16x8 rb[RB];
     f32x8 lps = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, lpt = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    const int nslab = C / BK;
-    const int nit = nslab * 9;
 
-    // it = -1: stage slab 0's halo and tap 0's weights; it >= 0: tap (it % 9) of slab (it / 9)
-    for (int it = -1; it < nit; ++it) {
-        const int ci = it < 0 ? -1 : it / 9;
-        const int t = it < 0 ? 8 : it - ci * 9;
-        const bool more = it + 1 < nit;
-        const bool halo_next = (t == 8) && (ci + 1 < nslab);    // slab ci+1 is needed after this iteration
-        // the halo of the next slab is requested at the first tap of the current one (or right away for slab 0)
-        const bool halo_load = (it < 0) || (t == 0 && ci + 1 < nslab);
-        if (halo_load) {
-            const int c0 = (ci + 1) * BK;
-            if (a.pre_scale) {
-                lps = ParamVec<8>::ld(a.pre_scale + c0 + seg * 8);
-                lpt = ParamVec<8>::ld(a.pre_shift + c0 + seg * 8);
-            }
-#pragma unroll
-            for (int j = 0; j < HJ; ++j) {
-                int q = hbase + row0 + 32 * j;                 // rows past HR / outside the tensor read a clamped address:
-                q = q < 0 ? 0 : (q >= M ? M - 1 : q);          // they are only ever consumed by masked taps
-                rh[j] = *reinterpret_cast<const bf16x8*>(xin + (size_t)q * (size_t)C + (size_t)(c0 + seg * 8));
-            }
+    // XCD-aware tile order (see conv_igemm.hip), applied to the persistent sequence lin = blockIdx.x + k * gridDim.x:
+    // gridDim.x is a multiple of 8 whenever it is smaller than the tile count, so a workgroup stays on one XCD's range.
+    const int xq = ntiles >> 3, xr = ntiles & 7;
+    int lin = (int)blockIdx.x;
+    int par = 0;                    // LDS weight buffer of the current step
+    bool first = true;
+    while (lin < ntiles) {
+        const int xcd = lin & 7;
+        const int tile_id = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (lin >> 3);
+        const int mtile = tile_id / ntn;
+        const int m0 = mtile * BM;
+        const int n0 = (tile_id - mtile * ntn) * BN;
+        const int hbase = m0 - W - 1;            // raster index of halo row 0
+        const int nlin = lin + G;
+        const bool has_next = nlin < ntiles;
+        int nx_hbase = 0, nx_n0 = 0;
+        if (has_next) {
+            const int xc2 = nlin & 7;
+            const int t2 = (xc2 < xr ? xc2 * (xq + 1) : xr * (xq + 1) + (xc2 - xr) * xq) + (nlin >> 3);
+            const int mt2 = t2 / ntn;
+            nx_hbase = mt2 * BM - W - 1;
+            nx_n0 = (t2 - mt2 * ntn) * BN;
         }
-        if (more) {
-            const int nx = it + 1;
-            const int ci2 = nx / 9, t2 = nx - ci2 * 9;
+
+        // validity of the 9 taps for this lane's MT output pixels
+        int vmask[MT];
 #pragma unroll
-            for (int j = 0; j < RB; ++j)
-                rb[j] = *reinterpret_cast<const bf16x8*>(win + (size_t)(n0 + row0 + 32 * j) * (size_t)(9 * C) + (size_t)(t2 * C + ci2 * BK + seg * 8));
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + (wm * MT + i) * 32 + l31;
+            int bits = 0;
+            if (m < M) {
+                const int x = m % W;
+                const int y = (m / W) % H;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int r = t / 3, s = t - 3 * r;
+                    const int dy = MODE == 0 ? r - 1 : 1 - r;
+                    const int dx = MODE == 0 ? s - 1 : 1 - s;
+                    if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
+                }
+            }
+            vmask[i] = bits;
         }
-        if (it >= 0) {
-            const int buf = it & 1;
-            const int r = t / 3, s = t - 3 * r;
-            const int shift = MODE == 0 ? r * W + s : (2 - r) * W + (2 - s);
-            bool ok[MT];
+
+        f32x16 acc[MT][NT];
 #pragma unroll
-            for (int i = 0; i < MT; ++i) ok[i] = (vmask[i] >> t) & 1;
+        for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int g = 0; g < BK / 16; ++g) {
-                bf16x8 af[MT], bf[NT];
+            for (int j = 0; j < NT; ++j)
 #pragma unroll
-                for (int i = 0; i < MT; ++i) {
-                    af[i] = *reinterpret_cast<const bf16x8*>(&sH[((wm * MT + i) * 32 + l31 + shift) * LDK + g * 16 + kh * 8]);
-                    if (!ok[i]) af[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+        // it = -1 (first tile of this workgroup only): stage slab 0's halo and tap 0's weights.  Every later tile finds
+        // them in place: they were requested under the previous tile's last slab.
+        for (int it = first ? -1 : 0; it < nit; ++it) {
+            const int ci = it < 0 ? -1 : it / 9;
+            const int t = it < 0 ? 8 : it - ci * 9;
+            const bool last = it == nit - 1;
+            // halo request: the next slab of this tile at its first tap, or slab 0 of the next tile under the last slab
+            bool reqH = false;
+            int rq_hbase = hbase, rq_c0 = 0;
+            if (it < 0) { reqH = true; }
+            else if (t == 0) {
+                if (ci + 1 < nslab) { reqH = true; rq_c0 = (ci + 1) * BK; }
+                else if (has_next) { reqH = true; rq_hbase = nx_hbase; }
+            }
+            if (reqH) {
+                if (a.pre_scale) {
+                    lps = ParamVec<8>::ld(a.pre_scale + rq_c0 + seg * 8);
+                    lpt = ParamVec<8>::ld(a.pre_shift + rq_c0 + seg * 8);
                 }
 #pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    bf[j] = *reinterpret_cast<const bf16x8*>(&sB[buf][((wn * NT + j) * 32 + l31) * LDK + g * 16 + kh * 8]);
+                for (int j = 0; j < HJ; ++j) {
+                    int q = rq_hbase + row0 + 32 * j;             // rows past HR / outside the tensor read a clamped address:
+                    q = q < 0 ? 0 : (q >= M ? M - 1 : q);         // they are only ever consumed by masked taps
+                    rh[j] = *reinterpret_cast<const bf16x8*>(xin + (size_t)q * (size_t)C + (size_t)(rq_c0 + seg * 8));
+                }
+            }
+            // weight request: the next (slab, tap) of this tile, or (0, 0) of the next tile
+            const bool reqB = !last || has_next;
+            if (reqB) {
+                const int nx = last ? 0 : it + 1;
+                const int ci2 = nx / 9, t2 = nx - ci2 * 9;
+                const int bn0 = last ? nx_n0 : n0;
 #pragma unroll
-                for (int i = 0; i < MT; ++i)
+                for (int j = 0; j < RB; ++j)
+                    rb[j] = *reinterpret_cast<const bf16x8*>(win + (size_t)(bn0 + row0 + 32 * j) * (size_t)(9 * C) + (size_t)(t2 * C + ci2 * BK + seg * 8));
+            }
+            if (it >= 0) {
+                const int r = t / 3, s = t - 3 * r;
+                const int shift = MODE == 0 ? r * W + s : (2 - r) * W + (2 - s);
+                bool ok[MT];
+#pragma unroll
+                for (int i = 0; i < MT; ++i) ok[i] = (vmask[i] >> t) & 1;
+#pragma unroll
+                for (int g = 0; g < BK / 16; ++g) {
+                    bf16x8 af[MT], bf[NT];
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) {
+                        af[i] = *reinterpret_cast<const bf16x8*>(&sH[((wm * MT + i) * 32 + l31 + shift) * LDK + g * 16 + kh * 8]);
+                        if (!ok[i]) af[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    }
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
-            }
-        }
-        if (more) {
-            const int buf = (it + 1) & 1;
+                        bf[j] = *reinterpret_cast<const bf16x8*>(&sB[par][((wn * NT + j) * 32 + l31) * LDK + g * 16 + kh * 8]);
 #pragma unroll
-            for (int j = 0; j < RB; ++j) *reinterpret_cast<bf16x8*>(&sB[buf][(row0 + 32 * j) * LDK + seg * 8]) = rb[j];
-        }
-        if (it < 0 || halo_next) {
-            if (it >= 0) __syncthreads();      // every wave is done reading the current slab's halo
+                    for (int i = 0; i < MT; ++i)
 #pragma unroll
-            for (int j = 0; j < HJ; ++j) {
-                const int hr = row0 + 32 * j;
-                if (hr < HR) {
-                    bf16x8 h = rh[j];
-                    if (a.pre_scale) {         // BatchNorm(+ReLU) of the producer, once per staged element
-                        f32x8 v = __builtin_convertvector(h, f32x8) * lps + lpt;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], relu_floor);
-                        h = __builtin_convertvector(v, bf16x8);
-                    }
-                    *reinterpret_cast<bf16x8*>(&sH[hr * LDK + seg * 8]) = h;
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
                 }
             }
-        }
-        __syncthreads();
-    }
+            const int nbuf = it < 0 ? par : par ^ 1;
+            if (reqB) {
+#pragma unroll
+                for (int j = 0; j < RB; ++j) *reinterpret_cast<bf16x8*>(&sB[nbuf][(row0 + 32 * j) * LDK + seg * 8]) = rb[j];
+            }
+            if (it >= 0) par ^= 1;
 
-    // ---- epilogue: dense output rows (pixel m), optional bias / residual / ReLU, statistics partials -------------------
-    float s1[NT], s2[NT];
+            if (last) {
+                // ---- epilogue of this tile: dense output rows, optional bias / residual / ReLU, statistics partials ----
+                float s1[NT], s2[NT];
 #pragma unroll
-    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    __bf16* yout = static_cast<__bf16*>(a.y);
-    const __bf16* resid = static_cast<const __bf16*>(a.resid);
+                for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 #pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
+                for (int mi = 0; mi < MT; ++mi) {
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            const int m = m0 + row;
-            if (m < M) {
-                const size_t obase = (size_t)m * (size_t)a.K;
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                        const int m = m0 + row;
+                        if (m < M) {
+                            const size_t obase = (size_t)m * (size_t)a.K;
 #pragma unroll
-                for (int nj = 0; nj < NT; ++nj) {
-                    const int col = n0 + (wn * NT + nj) * 32 + l31;
-                    float v = acc[mi][nj][e];
-                    if (a.bias) v += a.bias[col];
-                    if (resid) v += (float)resid[obase + col];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    yout[obase + col] = (__bf16)v;
-                    s1[nj] += v;
-                    s2[nj] += v * v;
+                            for (int nj = 0; nj < NT; ++nj) {
+                                const int col = n0 + (wn * NT + nj) * 32 + l31;
+                                float v = acc[mi][nj][e];
+                                if (a.bias) v += a.bias[col];
+                                if (resid) v += (float)resid[obase + col];
+                                if (a.relu) v = fmaxf(v, 0.f);
+                                yout[obase + col] = (__bf16)v;
+                                s1[nj] += v;
+                                s2[nj] += v * v;
+                            }
+                        }
+                    }
+                }
+                if (a.stats) {
+#pragma unroll
+                    for (int nj = 0; nj < NT; ++nj) {
+                        s1[nj] += __shfl_xor(s1[nj], 32);
+                        s2[nj] += __shfl_xor(s2[nj], 32);
+                    }
+                    if (kh == 0) {
+#pragma unroll
+                        for (int nj = 0; nj < NT; ++nj) {
+                            const int c = (wn * NT + nj) * 32 + l31;
+                            sRed[(wm * 2 + 0) * BN + c] = s1[nj];
+                            sRed[(wm * 2 + 1) * BN + c] = s2[nj];
+                        }
+                    }
                 }
             }
-        }
-    }
-    if (a.stats) {
-        float* red = reinterpret_cast<float*>(&sB[0][0]);   // [2 wm][2][BN]; the main loop's last barrier has passed
+
+            const bool storeH = (it < 0) || (t == 8 && (ci + 1 < nslab || has_next));
+            if (storeH) {
+                if (it >= 0) __syncthreads();      // every wave is done reading the current halo
 #pragma unroll
-        for (int nj = 0; nj < NT; ++nj) {
-            s1[nj] += __shfl_xor(s1[nj], 32);
-            s2[nj] += __shfl_xor(s2[nj], 32);
-        }
-        if (kh == 0) {
+                for (int j = 0; j < HJ; ++j) {
+                    const int hr = row0 + 32 * j;
+                    if (hr < HR) {
+                        bf16x8 h = rh[j];
+                        if (a.pre_scale) {         // BatchNorm(+ReLU) of the producer, once per staged element
+                            f32x8 v = __builtin_convertvector(h, f32x8) * lps + lpt;
 #pragma unroll
-            for (int nj = 0; nj < NT; ++nj) {
-                const int c = (wn * NT + nj) * 32 + l31;
-                red[(wm * 2 + 0) * BN + c] = s1[nj];
-                red[(wm * 2 + 1) * BN + c] = s2[nj];
+                            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], relu_floor);
+                            h = __builtin_convertvector(v, bf16x8);
+                        }
+                        *reinterpret_cast<bf16x8*>(&sH[hr * LDK + seg * 8]) = h;
+                    }
+                }
+            }
+            __syncthreads();
+            if (last && a.stats && tid < BN) {     // sRed is rewritten a whole tile (>= 9 barriers) later
+                float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+                dst[n0 + tid] = sRed[tid] + sRed[2 * BN + tid];
+                dst[a.K + n0 + tid] = sRed[BN + tid] + sRed[3 * BN + tid];
             }
         }
-        __syncthreads();
-        if (tid < BN) {
-            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
-            dst[n0 + tid] = red[tid] + red[2 * BN + tid];
-            dst[a.K + n0 + tid] = red[BN + tid] + red[3 * BN + tid];
-        }
+        first = false;
+        lin = nlin;
     }
 }
 
@@ -233,7 +263,12 @@ int lbc_conv3x3_halo_launch(const IgemmArgs& a, int mode, int bn, hipStream_t s)
 {
     LBC_REQUIRE(lbc_conv3x3_halo_eligible(a, mode), "conv3x3_halo: launch not eligible");
     LBC_REQUIRE((bn == 64 || bn == 128) && a.K % bn == 0, "conv3x3_halo: bad column tile %d", bn);
-    const dim3 grid((unsigned)(lbc_cdiv(a.M, 128) * (a.K / bn)));
+    // persistent workgroups (2 fit a CU): the next tile's halo is prefetched under the current tile's MFMAs
+    int nblk = lbc_cdiv(a.M, 128) * (a.K / bn);
+    int cap = 512;
+    if (const char* e = getenv("LBC_HALO_BLOCKS")) { const int v = atoi(e); if (v >= 8) cap = v & ~7; }   // tests: force multi-tile workgroups
+    if (nblk > cap) nblk = cap;
+    const dim3 grid((unsigned)nblk);
     if (bn == 128) {
         if (mode == 0) hipLaunchKernelGGL((conv3x3_halo_k<128, 0>), grid, dim3(256), 0, s, a);
         else           hipLaunchKernelGGL((conv3x3_halo_k<128, 1>), grid, dim3(256), 0, s, a);

@@ -319,3 +319,32 @@ def test_conv3x3_halo_dgrad(env, cfg, force_cfg):
     r = rbf(torch.randn(x.shape, generator=torch.Generator().manual_seed(54)))
     dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=r, bf16=3, transposed=True)
     assert relerr(dx, x.grad + r) < 1e-4 + OUT_TOL[2]
+
+
+@pytest.mark.parametrize("cfg", [(1, 40, 48, 64, 64), pytest.param((8, 40, 96, 64, 64), marks=gpu), pytest.param((4, 20, 48, 128, 128), marks=gpu)])
+def test_conv3x3_halo_persistent_workgroups(env, cfg, force_cfg):
+    """fewer workgroups than tiles: every workgroup walks several tiles with the next tile's halo prefetched"""
+    import os
+    dev, _ = env
+    N, H, W, C, K = cfg
+    force_cfg(1 if K % 128 == 0 else 0)
+    os.environ["LBC_HALO_BLOCKS"] = "8"
+    try:
+        x, w = make((N, H, W, C, K, 3, 1, 1), 55)
+        x = rbf(x)
+        g = torch.Generator().manual_seed(56)
+        ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+        ref = F.conv2d(rbf(xin), rbf(w), None, 1, 1)
+        y, st = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
+        assert relerr(y, ref) < 5e-4 + OUT_TOL[2]
+        assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+        x.requires_grad_(True)
+        yy = F.conv2d(x, rbf(w), None, 1, 1)
+        dy = rbf(torch.randn(yy.shape, generator=g))
+        yy.backward(dy)
+        if C == K:
+            dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, bf16=3, transposed=True)
+            assert relerr(dx, x.grad) < 1e-4 + OUT_TOL[2]
+    finally:
+        os.environ.pop("LBC_HALO_BLOCKS", None)
