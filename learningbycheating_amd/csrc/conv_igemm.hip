@@ -475,7 +475,7 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * a.K * (double)a.C * taps,
                       (a.act_bf16 ? 2.0 : 4.0) * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) +
                                                   (double)a.M * a.K * (a.resid ? 2 : 1)) + (a.w_bf16 ? 2.0 : 4.0) * (double)taps * a.C * a.K, s);
-    if (cfg != 2 && wmajor && lbc_conv3x3_halo_eligible(a, mode)) return lbc_conv3x3_halo_launch(a, mode, kCfgBN[cfg], s);
+    if (cfg != 2 && wmajor && lbc_conv3x3_halo_eligible(a, mode)) return lbc_conv3x3_halo_launch(a, mode, s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);
         case 1: return launch_cfg<128, 128>(a, wmajor, mode, s);

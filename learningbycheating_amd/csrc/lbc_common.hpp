@@ -99,9 +99,10 @@ int lbc_igemm_rows(const IgemmArgs& a, int cfg);   // number of M tiles (= stats
 int lbc_igemm_pick(long long M, int K);
 int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s);
 int lbc_weight_transpose(const float* w, float* wt, int A, int T, int B, hipStream_t s);   // w[A][T][B] -> wt[B][T][A]
-// 3x3 / stride-1 / pad-1 launches on bf16 tensors + bf16 weight copies take the halo-staged kernel (conv_halo.hip)
+// 3x3 / stride-1 / pad-1, C = K = 64 launches on bf16 tensors + bf16 weight copies take the halo-staged,
+// weight-stationary kernel (conv_halo.hip); statistics rows are per 128-pixel tile like the 128-row igemm tiles
 bool lbc_conv3x3_halo_eligible(const IgemmArgs& a, int mode);
-int lbc_conv3x3_halo_launch(const IgemmArgs& a, int mode, int bn, hipStream_t s);
+int lbc_conv3x3_halo_launch(const IgemmArgs& a, int mode, hipStream_t s);
 
 // Weight-gradient GEMM (conv_wgrad.hip):
 //   out[p][tap][q] = sum_m  P[m][p] * Q[gather(m, tap)][q]

@@ -367,16 +367,21 @@ def test_native_trainer_runs_and_is_deterministic(env):
     assert not torch.equal(before, student.deconv[1].weight.detach())
 
 
-@pytest.mark.parametrize("precision", [1, 2])
+@pytest.mark.parametrize("precision", [1, 2, "2-tiles128"])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),
                                                  pytest.param("birdview", "resnet18", 192, 192, 8, marks=gpu)])
-def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision):
+def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, monkeypatch):
     """precision=1: convolution MFMA operands rounded to bf16, everything else f32.  Every kernel of this mode is checked
     tightly in tests/test_kernels.py against rounded-operand references; end to end the comparison can only be
     statistical, because a bf16 rounding boundary (relative step 2^-8) crossed by one element after a 1e-7 perturbation
     moves downstream activations by ~1e-2 (measured: the bf16-emulating oracle itself moves by 3e-2 under 1e-7 input
     noise on small shapes).  Checked: predictions close to the bf16-emulating oracle, gradients strongly aligned."""
     dev, _ = env
+    if precision == "2-tiles128":
+        # the tile policy of large batches (128-row tiles: the halo-staged layer-1 kernel, 128 x 64 / 128 x 128 igemm tiles)
+        # on a test-sized batch
+        monkeypatch.setenv("LBC_FORCE_CFG", "0")
+        precision = 2
     sd = O.make_state_dict(kind, backbone, 3, h, w)
     x, speed, cmd = _inputs(kind, n, h, w, 4)
     eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
