@@ -1,0 +1,221 @@
+// Weight gradient of the 3x3 / stride-1 / pad-1 convolutions for bf16 tensors on gfx950, all nine taps in one workgroup.
+// reference: autograd of BasicBlock conv1/conv2 (bird_view/models/resnet.py:15-22,38-54), loss.backward() at
+// training/train_image_phase1.py:204.
+//
+//   out[p][tap][q] = sum_m  P[m][p] * Q[m + (r-1)*W + (s-1)][q]          (taps leaving the image contribute nothing)
+//
+// The generic kernel (conv_wgrad.hip) launches one workgroup per (tile, tap, split): every tap re-loads the same P and
+// an almost identical Q, transposes both in registers on the way into LDS (the contraction runs over pixels, the slow
+// axis of NHWC) and gets 4-16 MFMAs per barrier: 184 TF/s on the stem-resolution layer.  Here
+//   * a workgroup owns a 64 x 64 (P x Q channel) tile for ALL taps over a contiguous pixel range: nine accumulators per
+//     wave (144 registers), P staged once per 64-pixel chunk, Q kept as a ring of 64 + 2W + 2 (+64 incoming) pixel rows
+//     to which every chunk appends 64 rows -- each element is loaded from HBM/L2 and written to LDS exactly once;
+//   * LDS holds plain [pixel][channel] images (16-byte stores straight from the loads, BatchNorm+ReLU of the producer
+//     applied once per element); the "8 consecutive pixels of one channel" MFMA fragments come from
+//     ds_read_b64_tr_b16, and the tap shift is just a row offset of the read;
+//   * out-of-image taps are removed on the P fragment: with W % 8 == 0 a lane's 8-pixel group lies in one image row, so
+//     a tap is either invalid for the whole group (top / bottom row) or for its first / last pixel (left / right column);
+//   * one barrier per chunk, 36 MFMAs per wave between barriers, two workgroups per CU.
+#include "lbc_common.hpp"
+#include "lbc_act.hpp"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int kRing = 328;      // ring rows: 64 + 2W + 2 live rows + 64 incoming, W <= 96
+constexpr int kRS = 80;         // LDS row stride in elements (160 B): spreads the 4 pixel rows of a transpose read over the banks
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_per_split)
+{
+    constexpr int BRH = 64;
+    __shared__ __attribute__((aligned(16))) __bf16 sP[2][BRH * kRS];
+    __shared__ __attribute__((aligned(16))) __bf16 sQ[kRing * kRS];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wp = wave >> 1, wq = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int G1 = (lane >> 4) & 1, t16 = lane & 15;
+    const int W = a.W, H = a.H;
+    const int M = a.N * H * W;
+    const int HRW = BRH + 2 * W + 2;                  // live halo rows of a chunk
+    const int qtiles = a.CQ / 64;
+    const int ntiles = (a.CP / 64) * qtiles;
+    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    const int tp = tile / qtiles, tq = tile - tp * qtiles;
+    const int p0 = tp * 64, q0 = tq * 64;
+    const int mbeg = split * rows_per_split;
+    const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
+    const int nchunk = (mend > mbeg) ? (mend - mbeg + BRH - 1) / BRH : 0;
+    const int qorg = mbeg - W - 1;                    // pixel held by ring row 0 (before wrapping)
+    const __bf16* pin = static_cast<const __bf16*>(a.p);
+    const __bf16* qin = static_cast<const __bf16*>(a.q);
+
+    const int seg = tid & 7, srow = tid >> 3;         // staging: 16-byte segment (8 channels), row (+32 per pass)
+    const float relu_floor = (a.q_scale && a.q_relu) ? 0.f : -INFINITY;
+    f32x8 qsc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, qsh = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    if (a.q_scale) { qsc = ParamVec<8>::ld(a.q_scale + q0 + seg * 8); qsh = ParamVec<8>::ld(a.q_shift + q0 + seg * 8); }
+
+    f32x16 acc[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+    if (nchunk > 0) {
+        // ---- prologue: the halo of chunk 0 and its P rows ---------------------------------------------------------------
+        for (int rel = srow; rel < HRW; rel += 32) {
+            int q = qorg + rel;
+            q = q < 0 ? 0 : (q >= M ? M - 1 : q);     // rows outside the tensor only ever meet masked taps; keep them finite
+            bf16x8 h = *reinterpret_cast<const bf16x8*>(qin + ((unsigned)q * (unsigned)a.CQ + (unsigned)(q0 + seg * 8)));
+            if (a.q_scale) {
+                f32x8 v = __builtin_convertvector(h, f32x8) * qsc + qsh;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], relu_floor);
+                h = __builtin_convertvector(v, bf16x8);
+            }
+            *reinterpret_cast<bf16x8*>(&sQ[rel * kRS + seg * 8]) = h;
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = mbeg + srow + 32 * j;
+            bf16x8 h = *reinterpret_cast<const bf16x8*>(pin + ((unsigned)(m < mend ? m : mbeg) * (unsigned)a.CP + (unsigned)(p0 + seg * 8)));
+            if (m >= mend) h = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            *reinterpret_cast<bf16x8*>(&sP[0][(srow + 32 * j) * kRS + seg * 8]) = h;
+        }
+    }
+    __syncthreads();
+
+    int base = 0;                                     // ring row of the current chunk's first halo pixel
+    // coordinates of this lane's first 8-pixel group (chunk 0, g = 0): pixel mbeg + 8*kh
+    int gx, gy;
+    {
+        const int pm = mbeg + 8 * kh;
+        gx = pm % W;
+        gy = (pm / W) % H;
+    }
+    for (int c = 0; c < nchunk; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nchunk;
+        bf16x8 rp[2], rq[2];
+        if (more) {
+            const int mc = mbeg + (c + 1) * BRH;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = mc + srow + 32 * j;
+                rp[j] = *reinterpret_cast<const bf16x8*>(pin + ((unsigned)(m < mend ? m : mbeg) * (unsigned)a.CP + (unsigned)(p0 + seg * 8)));
+                int q = qorg + c * BRH + HRW + srow + 32 * j;
+                q = q < 0 ? 0 : (q >= M ? M - 1 : q);
+                rq[j] = *reinterpret_cast<const bf16x8*>(qin + ((unsigned)q * (unsigned)a.CQ + (unsigned)(q0 + seg * 8)));
+            }
+        }
+
+        // ---- 4 groups of 16 pixels x 9 taps ------------------------------------------------------------------------------
+        int x0 = gx, y = gy;
+#pragma unroll
+        for (int g = 0; g < BRH / 16; ++g) {
+            // P^T fragment: channel p0 + 32*wp + (lane & 31), pixels 16g + 8kh + 0..7 of the chunk
+            const int prow = 16 * g + 8 * kh + (t16 >> 2);
+            const int pcol = 32 * wp + 16 * G1 + (t16 & 3) * 4;
+            const bf16x4 a0 = lds_read_tr16(&sP[buf][prow * kRS + pcol]);
+            const bf16x4 a1 = lds_read_tr16(&sP[buf][(prow + 4) * kRS + pcol]);
+            // tap validity of this 8-pixel group (one image row because W % 8 == 0)
+            const bool top = y == 0, bottom = y == H - 1, left = x0 == 0, right = x0 == W - 8;
+            bf16x4 a0l = a0, a1r = a1;
+            if (left) a0l[0] = (__bf16)0.f;           // pixel 0 of the group has no left neighbour
+            if (right) a1r[3] = (__bf16)0.f;          // pixel 7 has no right neighbour
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s = t - 3 * r;
+                int row = base + 16 * g + 8 * kh + (t16 >> 2) + r * W + s;       // halo row of pixel + (r-1, s-1)
+                row = row >= kRing ? row - kRing : row;
+                int row4 = row + 4;
+                row4 = row4 >= kRing ? row4 - kRing : row4;
+                const int qcol = 32 * wq + 16 * G1 + (t16 & 3) * 4;
+                const bf16x4 b0 = lds_read_tr16(&sQ[row * kRS + qcol]);
+                const bf16x4 b1 = lds_read_tr16(&sQ[row4 * kRS + qcol]);
+                bf16x4 u0 = s == 0 ? a0l : a0;
+                bf16x4 u1 = s == 2 ? a1r : a1;
+                if ((r == 0 && top) || (r == 2 && bottom)) {
+                    u0 = bf16x4{0, 0, 0, 0};
+                    u1 = bf16x4{0, 0, 0, 0};
+                }
+                const bf16x8 af = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+                const bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+            }
+            x0 += 16;
+            if (x0 >= W) { x0 -= W; if (++y >= H) y = 0; }
+        }
+        // next chunk's first group: 64 pixels on
+        gx += BRH;
+        while (gx >= W) { gx -= W; if (++gy >= H) gy = 0; }
+
+        if (more) {
+            const int mc = mbeg + (c + 1) * BRH;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int m = mc + srow + 32 * j;
+                bf16x8 h = rp[j];
+                if (m >= mend) h = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                *reinterpret_cast<bf16x8*>(&sP[buf ^ 1][(srow + 32 * j) * kRS + seg * 8]) = h;
+                bf16x8 hq = rq[j];
+                if (a.q_scale) {
+                    f32x8 v = __builtin_convertvector(hq, f32x8) * qsc + qsh;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], relu_floor);
+                    hq = __builtin_convertvector(v, bf16x8);
+                }
+                int slot = base + HRW + srow + 32 * j;          // appended rows never overlap the live halo (HRW + 64 <= kRing)
+                slot = slot >= kRing ? slot - kRing : slot;
+                *reinterpret_cast<bf16x8*>(&sQ[slot * kRS + seg * 8]) = hq;
+            }
+        }
+        base += BRH;
+        base = base >= kRing ? base - kRing : base;
+        __syncthreads();
+    }
+
+    float* out = a.partial + (size_t)split * (size_t)a.CP * 9 * (size_t)a.CQ;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int prow = p0 + 32 * wp + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            const int qcol = q0 + 32 * wq + l31;
+            out[((size_t)prow * 9 + (size_t)t) * (size_t)a.CQ + (size_t)qcol] = acc[t][e];
+        }
+}
+
+}  // namespace
+
+bool lbc_wgrad_tr_eligible(const WgradArgs& a)
+{
+    static const bool off = getenv("LBC_NO_WGRAD_TR") && getenv("LBC_NO_WGRAD_TR")[0] == '1';   // A/B switch
+    return !off && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.OH == a.H && a.OW == a.W && !a.p_scale &&
+           a.W % 8 == 0 && a.W >= 16 && 64 + 2 * a.W + 2 + 64 <= kRing && a.CP % 64 == 0 && a.CQ % 64 == 0;
+}
+
+int lbc_wgrad_tr_pick_split(const WgradArgs& a)
+{
+    static const long long target = getenv("LBC_WGRAD_TR_BLOCKS") ? atoll(getenv("LBC_WGRAD_TR_BLOCKS")) : 512;   // tuning knob
+    const long long tiles = (long long)(a.CP / 64) * (a.CQ / 64);
+    const long long M = (long long)a.N * a.H * a.W;
+    const long long chunks = (M + 63) / 64;
+    long long ns = (target + tiles - 1) / tiles;
+    const long long maxns = chunks / 8 > 0 ? chunks / 8 : 1;     // >= 8 chunks per split: the halo prologue is ~4 chunks of loads
+    if (ns > maxns) ns = maxns;
+    if (ns > 1024) ns = 1024;
+    if (ns < 1) ns = 1;
+    return (int)ns;
+}
+
+int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(lbc_wgrad_tr_eligible(a), "wgrad_tr: launch not eligible");
+    const long long M = (long long)a.N * a.H * a.W;
+    const long long chunks = (M + 63) / 64;
+    const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 64;
+    const unsigned blocks = (unsigned)((a.CP / 64) * (a.CQ / 64) * a.nsplit);
+    hipLaunchKernelGGL(conv_wgrad_tr_k, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
+    return lbc_check_launch("conv_wgrad_tr");
+}

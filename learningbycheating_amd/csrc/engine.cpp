@@ -170,6 +170,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
         WgradArgs a;
         memset(&a, 0, sizeof(a));
         a.N = N; a.OH = OH; a.OW = OW; a.CP = CP; a.H = Hq; a.W = Wq; a.CQ = CQ; a.KH = k; a.KW = k; a.S = s; a.P = p;
+        a.bf16 = bf16_; a.act_bf16 = act_bf16_;      // the split policy depends on the kernel that will run
         return (size_t)lbc_wgrad_pick_split(a) * CP * k * k * CQ;
     };
     for (const Block& b : blocks_) {

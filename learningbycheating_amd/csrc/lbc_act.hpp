@@ -31,6 +31,15 @@ template <> struct Act<__bf16> {
     static __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
 };
 
+// LDS transpose read (ds_read_b64_tr_b16): each lane passes the address of 4 contiguous bf16; within a 16-lane group lane
+// t's chunk is row t>>2, columns (t&3)*4.. of a 4 x 16 block and lane t receives column t (4 rows).  It turns a
+// [pixel][channel] LDS image into the "8 consecutive pixels of one channel" fragments of a pixel-contracting MFMA.
+__device__ __forceinline__ bf16x4 lds_read_tr16(const __bf16* p)
+{
+    typedef __attribute__((address_space(3))) bf16x4 lds_bf16x4;
+    return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_bf16x4*)p);
+}
+
 // V consecutive per-channel f32 parameters (V = 4 or 8) as a vector
 template <int V> struct ParamVec;
 template <> struct ParamVec<4> {

@@ -126,6 +126,10 @@ struct WgradArgs {
     int bf16;             // 1: bf16 MFMA operands (f32 accumulation)
     int act_bf16;         // 1: p / q are bf16 tensors (requires bf16 = 1)
 };
-int lbc_wgrad_pick_split(const WgradArgs& a);
+int lbc_wgrad_pick_split(const WgradArgs& a);      // needs bf16 / act_bf16 set: the tap-fused kernel has its own split policy
 int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s);
+// 3x3 / stride-1 weight gradients on bf16 tensors: all nine taps per workgroup, transpose reads (conv_wgrad_tr.hip)
+bool lbc_wgrad_tr_eligible(const WgradArgs& a);
+int lbc_wgrad_tr_pick_split(const WgradArgs& a);
+int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s);
 int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* out, float beta, hipStream_t s);

@@ -215,6 +215,25 @@ static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_bf16x8 a, emu_bf16x8 b, 
 }
 #define __builtin_amdgcn_mfma_f32_32x32x16_bf16 emu_mfma_f32_32x32x16_bf16
 
+// ds_read_b64_tr_b16 (gfx950): every lane supplies the address of 4 contiguous 16-bit elements; within a 16-lane group
+// lane t's chunk is B[t>>2][(t&3)*4 .. +3] of a 4 x 16 matrix and lane t receives column t (checked against the
+// hardware by scripts/probe/tr16_probe.hip).
+typedef __bf16 emu_bf16x4 __attribute__((ext_vector_type(4)));
+static inline emu_bf16x4 emu_ds_read_tr16_b64(const void* p) {
+    emu::Slot* s = emu::wave_slots_begin();
+    const int l = emu::lane_id();
+    memcpy(s[l].b, &p, sizeof(p));
+    emu::wave_rendezvous();
+    emu_bf16x4 r;
+    for (int j = 0; j < 4; ++j) {
+        const __bf16* q;
+        memcpy(&q, s[(l & ~15) + j * 4 + ((l & 15) >> 2)].b, sizeof(q));
+        r[j] = q[(l & 15) & 3];
+    }
+    return r;
+}
+#define __builtin_amdgcn_ds_read_tr16_b64_v4bf16(p) emu_ds_read_tr16_b64((const void*)(p))
+
 // ---- misc device builtins ----------------------------------------------------
 template <typename T> static inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
 #define __expf(x) expf(x)

@@ -348,3 +348,29 @@ def test_conv3x3_halo_persistent_workgroups(env, cfg, force_cfg):
             assert relerr(dx, x.grad) < 1e-4 + OUT_TOL[2]
     finally:
         os.environ.pop("LBC_HALO_BLOCKS", None)
+
+
+# ---- tap-fused 3x3 / stride-1 weight gradient with transpose reads (conv_wgrad_tr.hip): bf16 tensors, W % 8 == 0 ----------
+WTR_SMALL = [(1, 4, 16, 64, 64), (2, 3, 24, 64, 128), (1, 9, 16, 128, 64), (3, 2, 16, 64, 64), (4, 16, 16, 64, 64)]   # the last: 16 chunks, ring wrap, 2 splits
+WTR_REAL = [pytest.param(c, marks=gpu) for c in [(8, 40, 96, 64, 64), (4, 20, 48, 128, 128), (8, 10, 24, 256, 256), (3, 48, 48, 64, 64), (2, 20, 48, 64, 128)]]
+
+
+@pytest.mark.parametrize("cfg", WTR_SMALL + WTR_REAL)
+def test_conv_wgrad_tap_fused(env, cfg):
+    """plain and with the producer's BatchNorm+ReLU applied to x on load; image borders, several images per split"""
+    dev, _ = env
+    N, H, W, C, K = cfg
+    x, w = make((N, H, W, C, K, 3, 1, 1), 60)
+    x = rbf(x)
+    g = torch.Generator().manual_seed(61)
+    dy = rbf(torch.randn((N, K, H, W), generator=g))
+    w1 = w.clone().requires_grad_(True)
+    F.conv2d(x, w1, None, 1, 1).backward(dy)
+    dw = Conv(dev).wgrad(x, dy, 3, 1, 1, bf16=2)
+    assert relerr(dw, w1.grad) < 1e-4
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    w2 = w.clone().requires_grad_(True)
+    F.conv2d(rbf(xin), w2, None, 1, 1).backward(dy)
+    dw2 = Conv(dev).wgrad(x, dy, 3, 1, 1, pre=(ps, pt, True), bf16=2)
+    assert relerr(dw2, w2.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
