@@ -439,7 +439,11 @@ int lbc_weight_prep(const WeightPrepArgs& a, hipStream_t s)
     return lbc_check_launch("weight_prep");
 }
 
-int lbc_igemm_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kCfgBM[cfg]); }
+int lbc_igemm_rows(const IgemmArgs& a, int cfg)
+{
+    if (lbc_conv3x3_halo_eligible(a, 0)) return lbc_cdiv(a.M, 128);   // that kernel always works on 128-pixel tiles
+    return lbc_cdiv(a.M, kCfgBM[cfg]);
+}
 
 int lbc_igemm_pick(long long M, int K)
 {
@@ -475,7 +479,7 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * a.K * (double)a.C * taps,
                       (a.act_bf16 ? 2.0 : 4.0) * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) +
                                                   (double)a.M * a.K * (a.resid ? 2 : 1)) + (a.w_bf16 ? 2.0 : 4.0) * (double)taps * a.C * a.K, s);
-    if (cfg != 2 && wmajor && lbc_conv3x3_halo_eligible(a, mode)) return lbc_conv3x3_halo_launch(a, mode, s);
+    if (wmajor && lbc_conv3x3_halo_eligible(a, mode)) return lbc_conv3x3_halo_launch(a, mode, s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);
         case 1: return launch_cfg<128, 128>(a, wmajor, mode, s);

@@ -15,6 +15,7 @@
 //     ds_read_b64_tr_b16, and the tap shift is just a row offset of the read;
 //   * out-of-image taps are removed on the P fragment: with W % 8 == 0 a lane's 8-pixel group lies in one image row, so
 //     a tap is either invalid for the whole group (top / bottom row) or for its first / last pixel (left / right column);
+//     other widths (the 5 x 12 maps of layer 4) build per-pixel keep-masks for the four border classes;
 //   * one barrier per chunk, 36 MFMAs per wave between barriers, two workgroups per CU.
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
@@ -25,6 +26,9 @@ namespace {
 constexpr int kRing = 328;      // ring rows: 64 + 2W + 2 live rows + 64 incoming, W <= 96
 constexpr int kRS = 80;         // LDS row stride in elements (160 B): spreads the 4 pixel rows of a transpose read over the banks
 
+// ALIGNED: W % 8 == 0 (a lane's 8-pixel group lies in one image row: whole-group / first-pixel / last-pixel masks).
+// Otherwise (W >= 8, e.g. the 5 x 12 maps of layer 4) the group may straddle two rows and every pixel gets its own flags.
+template <bool ALIGNED>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_per_split)
 {
     constexpr int BRH = 64;
@@ -118,11 +122,29 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
             const int pcol = 32 * wp + 16 * G1 + (t16 & 3) * 4;
             const bf16x4 a0 = lds_read_tr16(&sP[buf][prow * kRS + pcol]);
             const bf16x4 a1 = lds_read_tr16(&sP[buf][(prow + 4) * kRS + pcol]);
-            // tap validity of this 8-pixel group (one image row because W % 8 == 0)
-            const bool top = y == 0, bottom = y == H - 1, left = x0 == 0, right = x0 == W - 8;
+            // tap validity of the group's 8 pixels
+            bool top = false, bottom = false, left = false, right = false;
+            unsigned mt[4], mb[4], ml[4], mr[4];      // !ALIGNED: per-dword keep-masks (two bf16 each) of the four border classes
+            if constexpr (ALIGNED) {
+                top = y == 0; bottom = y == H - 1; left = x0 == 0; right = x0 == W - 8;
+            } else {
+#pragma unroll
+                for (int d = 0; d < 4; ++d) { mt[d] = 0xffffffffu; mb[d] = 0xffffffffu; ml[d] = 0xffffffffu; mr[d] = 0xffffffffu; }
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const bool wrap = x0 + i >= W;             // W >= 8: at most one row change inside a group
+                    const int xi = wrap ? x0 + i - W : x0 + i;
+                    const int yi = wrap ? (y + 1 == H ? 0 : y + 1) : y;
+                    const unsigned clr = ~(0xffffu << (16 * (i & 1)));
+                    if (yi == 0) mt[i >> 1] &= clr;
+                    if (yi == H - 1) mb[i >> 1] &= clr;
+                    if (xi == 0) ml[i >> 1] &= clr;
+                    if (xi == W - 1) mr[i >> 1] &= clr;
+                }
+            }
             bf16x4 a0l = a0, a1r = a1;
-            if (left) a0l[0] = (__bf16)0.f;           // pixel 0 of the group has no left neighbour
-            if (right) a1r[3] = (__bf16)0.f;          // pixel 7 has no right neighbour
+            if (ALIGNED && left) a0l[0] = (__bf16)0.f;           // pixel 0 of the group has no left neighbour
+            if (ALIGNED && right) a1r[3] = (__bf16)0.f;          // pixel 7 has no right neighbour
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int r = t / 3, s = t - 3 * r;
@@ -133,18 +155,35 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                 const int qcol = 32 * wq + 16 * G1 + (t16 & 3) * 4;
                 const bf16x4 b0 = lds_read_tr16(&sQ[row * kRS + qcol]);
                 const bf16x4 b1 = lds_read_tr16(&sQ[row4 * kRS + qcol]);
-                bf16x4 u0 = s == 0 ? a0l : a0;
-                bf16x4 u1 = s == 2 ? a1r : a1;
-                if ((r == 0 && top) || (r == 2 && bottom)) {
-                    u0 = bf16x4{0, 0, 0, 0};
-                    u1 = bf16x4{0, 0, 0, 0};
+                bf16x8 af;
+                if constexpr (ALIGNED) {
+                    bf16x4 u0 = s == 0 ? a0l : a0;
+                    bf16x4 u1 = s == 2 ? a1r : a1;
+                    if ((r == 0 && top) || (r == 2 && bottom)) {
+                        u0 = bf16x4{0, 0, 0, 0};
+                        u1 = bf16x4{0, 0, 0, 0};
+                    }
+                    af = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
+                } else {
+                    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                    const bf16x8 full = __builtin_shufflevector(a0, a1, 0, 1, 2, 3, 4, 5, 6, 7);
+                    u32x4 bits = __builtin_bit_cast(u32x4, full);
+#pragma unroll
+                    for (int d = 0; d < 4; ++d) {
+                        unsigned keep = 0xffffffffu;
+                        if (r == 0) keep &= mt[d];
+                        if (r == 2) keep &= mb[d];
+                        if (s == 0) keep &= ml[d];
+                        if (s == 2) keep &= mr[d];
+                        bits[d] &= keep;
+                    }
+                    af = __builtin_bit_cast(bf16x8, bits);
                 }
-                const bf16x8 af = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
                 const bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
             }
             x0 += 16;
-            if (x0 >= W) { x0 -= W; if (++y >= H) y = 0; }
+            while (x0 >= W) { x0 -= W; if (++y >= H) y = 0; }
         }
         // next chunk's first group: 64 pixels on
         gx += BRH;
@@ -192,7 +231,7 @@ bool lbc_wgrad_tr_eligible(const WgradArgs& a)
 {
     static const bool off = getenv("LBC_NO_WGRAD_TR") && getenv("LBC_NO_WGRAD_TR")[0] == '1';   // A/B switch
     return !off && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.OH == a.H && a.OW == a.W && !a.p_scale &&
-           a.W % 8 == 0 && a.W >= 16 && 64 + 2 * a.W + 2 + 64 <= kRing && a.CP % 64 == 0 && a.CQ % 64 == 0;
+           a.W >= 8 && 64 + 2 * a.W + 2 + 64 <= kRing && a.CP % 64 == 0 && a.CQ % 64 == 0;
 }
 
 int lbc_wgrad_tr_pick_split(const WgradArgs& a)
@@ -216,6 +255,7 @@ int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s)
     const long long chunks = (M + 63) / 64;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 64;
     const unsigned blocks = (unsigned)((a.CP / 64) * (a.CQ / 64) * a.nsplit);
-    hipLaunchKernelGGL(conv_wgrad_tr_k, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
+    if (a.W % 8 == 0) hipLaunchKernelGGL(conv_wgrad_tr_k<true>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
+    else              hipLaunchKernelGGL(conv_wgrad_tr_k<false>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("conv_wgrad_tr");
 }

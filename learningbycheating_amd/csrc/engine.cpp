@@ -209,11 +209,11 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     a.OH = c.OH; a.OW = c.OW; a.K = c.Cout;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
     a.M = N * c.OH * c.OW; a.LH = c.OH; a.LW = c.OW; a.ostep = 1;
+    a.bf16 = bf16_; a.act_bf16 = act_bf16_;
+    if (act_bf16_) { a.w = W(c.wn); a.w_bf16 = 1; }
     const int cfg = lbc_igemm_pick(a.M, a.K);
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? W(partial_) : nullptr;
-    a.bf16 = bf16_; a.act_bf16 = act_bf16_;
-    if (act_bf16_) { a.w = W(c.wn); a.w_bf16 = 1; }
     return lbc_igemm_launch(a, 1, 0, cfg, s);
 }
 

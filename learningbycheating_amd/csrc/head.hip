@@ -20,6 +20,7 @@
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include "lbc_kernels.hpp"
+#include <stdlib.h>
 
 namespace {
 
@@ -61,7 +62,10 @@ __device__ __forceinline__ void fold_branch(const HeadArgs& a, int b, float* sW 
     const float* inv = a.invstd[b];
     for (int idx = tid; idx < 320; idx += nthr) {
         const int c = idx & 63;
-        sW[idx] = a.w[b][idx] * a.gamma[b][c] * inv[c];
+        const float wf = a.w[b][idx] * a.gamma[b][c] * inv[c];
+        // bf16 activations: the forward multiplies on the bf16 MFMA, so the folded weight is a bf16 value everywhere
+        // (forward, and the backward's recomputation of the logits) -- the saved soft-max statistics stay consistent
+        sW[idx] = a.act_bf16 ? (float)(__bf16)wf : wf;
     }
     if (tid < 5) {
         float t = a.bias[b][tid];
@@ -138,6 +142,78 @@ __global__ __launch_bounds__(256) void head_fwd_k(HeadArgs a)
             soft_merge(t, o);
         }
         const size_t o2 = (((size_t)n * 4 + b) * 5 + tid) * 2;
+        a.pred_all[o2] = t.sx / t.l;
+        a.pred_all[o2 + 1] = t.sy / t.l;
+        if (a.rowstat) { a.rowstat[o2] = t.m; a.rowstat[o2 + 1] = t.l; }
+    }
+}
+
+// bf16 activations: the 64 -> 4 x 5 projection of all four branches on v_mfma_f32_32x32x16_bf16 (20 of 32 columns
+// used), A fragments straight from HBM (a lane's 8 consecutive channels of one pixel are one 16-byte load: no LDS
+// staging at all), folded weights stationary in registers, online soft-argmax per column.  One workgroup per image.
+__global__ __launch_bounds__(256) void head_fwd_mfma_k(HeadArgs a)
+{
+    __shared__ float sWf[4 * 320];
+    __shared__ float sBf[4 * 8];
+    __shared__ float sRed[4 * 32 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.x;
+    const int HW = a.OH * a.OW;
+    for (int b = 0; b < 4; ++b) fold_branch(a, b, sWf + b * 320, sBf + b * 8, tid, 256);
+    __syncthreads();
+    const bool colok = l31 < 20;
+    const int cb = colok ? l31 / 5 : 0, cs = colok ? l31 - 5 * cb : 0;     // branch and step of this lane's column
+    bf16x8 wb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wb[g][j] = (__bf16)(colok ? sWf[cb * 320 + cs * 64 + g * 16 + kh * 8 + j] : 0.f);
+    const float bias = colok ? sBf[cb * 8 + cs] : 0.f;
+    const float* posx = a.pos_x[cb];
+    const float* posy = a.pos_y[cb];
+    const __bf16* h = static_cast<const __bf16*>(a.h) + (size_t)n * HW * 64;
+
+    SoftAcc st; st.m = -INFINITY; st.l = 0.f; st.sx = 0.f; st.sy = 0.f;
+    const int ngroup = (HW + 31) / 32;
+    for (int grp = wave; grp < ngroup; grp += 4) {
+        const int pbase = grp * 32;
+        const int pl = pbase + l31 < HW ? pbase + l31 : HW - 1;       // rows past the map are computed on a valid pixel and skipped below
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        bf16x8 af[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) af[g] = *reinterpret_cast<const bf16x8*>(h + (size_t)pl * 64 + (size_t)(g * 16 + kh * 8));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], wb[g], acc, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            if (p < HW && colok) {
+                SoftAcc o; o.m = acc[e] + bias; o.l = 1.f; o.sx = posx[p]; o.sy = posy[p];
+                soft_merge(st, o);
+            }
+        }
+    }
+    {   // the two half-waves hold different pixel rows of the same column
+        SoftAcc o;
+        o.m = __shfl_xor(st.m, 32); o.l = __shfl_xor(st.l, 32); o.sx = __shfl_xor(st.sx, 32); o.sy = __shfl_xor(st.sy, 32);
+        soft_merge(st, o);
+    }
+    if (kh == 0) {
+        sRed[(wave * 32 + l31) * 4 + 0] = st.m; sRed[(wave * 32 + l31) * 4 + 1] = st.l;
+        sRed[(wave * 32 + l31) * 4 + 2] = st.sx; sRed[(wave * 32 + l31) * 4 + 3] = st.sy;
+    }
+    __syncthreads();
+    if (tid < 20) {
+        SoftAcc t; t.m = sRed[tid * 4]; t.l = sRed[tid * 4 + 1]; t.sx = sRed[tid * 4 + 2]; t.sy = sRed[tid * 4 + 3];
+        for (int w = 1; w < 4; ++w) {
+            SoftAcc o; o.m = sRed[(w * 32 + tid) * 4]; o.l = sRed[(w * 32 + tid) * 4 + 1];
+            o.sx = sRed[(w * 32 + tid) * 4 + 2]; o.sy = sRed[(w * 32 + tid) * 4 + 3];
+            soft_merge(t, o);
+        }
+        const size_t o2 = ((size_t)n * 20 + tid) * 2;      // column = branch * 5 + step
         a.pred_all[o2] = t.sx / t.l;
         a.pred_all[o2 + 1] = t.sy / t.l;
         if (a.rowstat) { a.rowstat[o2] = t.m; a.rowstat[o2 + 1] = t.l; }
@@ -376,9 +452,10 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
     LbcProfScope prof("head_fwd", 2.0 * a.N * a.OH * a.OW * 64.0 * 20, 4.0 * a.N * (double)a.OH * a.OW * 64, s);
-#define LBC_K(T, d) hipLaunchKernelGGL((head_fwd_k<T>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a)
-    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 0);
-#undef LBC_K
+    const bool no_mfma = getenv("LBC_HEAD_NO_MFMA") && getenv("LBC_HEAD_NO_MFMA")[0] == '1';   // A/B switch
+    if (a.act_bf16 && !no_mfma) hipLaunchKernelGGL(head_fwd_mfma_k, dim3((unsigned)a.N), dim3(256), 0, s, a);
+    else if (a.act_bf16) hipLaunchKernelGGL((head_fwd_k<__bf16>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((head_fwd_k<float>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
     int rc = lbc_check_launch("head_fwd");
     if (rc) return rc;
     if (a.pred_sel) {

@@ -13,24 +13,27 @@ namespace {
 template <typename T>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
 {
+    constexpr int V = Act<T>::kVec;          // 16-byte accesses: 4 f32 or 8 bf16 channels per thread
+    using vec = typename Act<T>::vec;
+    using PV = ParamVec<V>;
     const T* y = static_cast<const T*>(a.y);
     T* pout = static_cast<T*>(a.p);
     const int OH = a.H / 2, OW = a.W / 2;
-    const int c4n = a.C / 4;
-    const long long total = (long long)a.N * OH * OW * c4n;
+    const int cvn = a.C / V;
+    const long long total = (long long)a.N * OH * OW * cvn;
     const long long stride = (long long)gridDim.x * blockDim.x;
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int cg = (int)(i % c4n);
-        long long t = i / c4n;
+        const int cg = (int)(i % cvn);
+        long long t = i / cvn;
         const int ox = (int)(t % OW); t /= OW;
         const int oy = (int)(t % OH);
         const int n = (int)(t / OH);
-        const int c = cg * 4;
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
-        const float ninf = -INFINITY;
-        f32x4 best = {ninf, ninf, ninf, ninf};
-        int bi[4] = {0, 0, 0, 0};
+        const int c = cg * V;
+        const vec sc = PV::ld(a.scale + c), sh = PV::ld(a.shift + c);
+        vec best = PV::splat(-INFINITY);
+        int bi[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) bi[e] = 0;
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = 2 * oy - 1 + r;
@@ -39,21 +42,24 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
             for (int s = 0; s < 3; ++s) {
                 const int ix = 2 * ox - 1 + s;
                 if ((unsigned)ix >= (unsigned)a.W) continue;
-                f32x4 v = Act<T>::ld4(y + ((size_t)(n * a.H + iy) * a.W + (size_t)ix) * a.C + c);
+                vec v = Act<T>::ldv(y + ((size_t)(n * a.H + iy) * a.W + (size_t)ix) * a.C + c);
                 v = v * sc + sh;
                 const int tap = r * 3 + s;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+                for (int e = 0; e < V; ++e) {
                     const float z = fmaxf(v[e], 0.f);
                     if (z > best[e]) { best[e] = z; bi[e] = tap; }
                 }
             }
         }
-        Act<T>::st4(pout + i * 4, best);
+        Act<T>::stv(pout + i * V, best);
         if (a.idx) {
-            uchar4 u;
-            u.x = (unsigned char)bi[0]; u.y = (unsigned char)bi[1]; u.z = (unsigned char)bi[2]; u.w = (unsigned char)bi[3];
-            reinterpret_cast<uchar4*>(a.idx)[i] = u;
+#pragma unroll
+            for (int q = 0; q < V / 4; ++q) {
+                uchar4 u;
+                u.x = (unsigned char)bi[4 * q]; u.y = (unsigned char)bi[4 * q + 1]; u.z = (unsigned char)bi[4 * q + 2]; u.w = (unsigned char)bi[4 * q + 3];
+                reinterpret_cast<uchar4*>(a.idx)[i * (V / 4) + q] = u;
+            }
         }
     }
 }
@@ -63,22 +69,23 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
 {
-    __shared__ __attribute__((aligned(16))) float red[2 * 256 * 4];
+    constexpr int V = Act<T>::kVec;
+    using vec = typename Act<T>::vec;
+    using PV = ParamVec<V>;
+    __shared__ __attribute__((aligned(16))) float red[2 * 256 * V];
     const T* dp = static_cast<const T*>(a.dp);
     const T* y = static_cast<const T*>(a.y);
     T* gout = static_cast<T*>(a.g);
     const int OH = a.H / 2, OW = a.W / 2;
-    const int c4n = a.C / 4;
-    const int rl = 256 / c4n;
-    const int cg = threadIdx.x % c4n;
-    const int pl = threadIdx.x / c4n;
-    const int c = cg * 4;
-    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    const int cvn = a.C / V;
+    const int rl = 256 / cvn;
+    const int cg = threadIdx.x % cvn;
+    const int pl = threadIdx.x / cvn;
+    const int c = cg * V;
+    vec s1 = PV::splat(0.f), s2 = s1;
     if (pl < rl) {
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(a.scale + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(a.shift + c);
-        const f32x4 mean = *reinterpret_cast<const f32x4*>(a.mean + c);
-        const f32x4 inv = *reinterpret_cast<const f32x4*>(a.invstd + c);
+        const vec sc = PV::ld(a.scale + c), sh = PV::ld(a.shift + c);
+        const vec mean = PV::ld(a.mean + c), inv = PV::ld(a.invstd + c);
         const long long pixels = (long long)a.N * a.H * a.W;
         const long long p0 = (long long)blockIdx.x * a.pix_per_block;
         long long p1 = p0 + a.pix_per_block;
@@ -88,7 +95,7 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
             const long long t = p / a.W;
             const int yy = (int)(t % a.H);
             const int n = (int)(t / a.H);
-            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            vec g = PV::splat(0.f);
             const int oy0 = yy >> 1, oy1 = (yy + 1) >> 1;   // windows covering row y (equal when y is even)
             const int ox0 = x >> 1, ox1 = (x + 1) >> 1;
             for (int oy = oy0; oy <= oy1; ++oy) {
@@ -98,36 +105,39 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
                     if (ox >= OW) continue;
                     const int s = x - (2 * ox - 1);
                     const int tap = r * 3 + s;
-                    const size_t o = ((size_t)(n * OH + oy) * OW + (size_t)ox) * c4n + cg;
-                    const uchar4 u = reinterpret_cast<const uchar4*>(a.idx)[o];
-                    const f32x4 d = Act<T>::ld4(dp + o * 4);
-                    if (u.x == tap) g[0] += d[0];
-                    if (u.y == tap) g[1] += d[1];
-                    if (u.z == tap) g[2] += d[2];
-                    if (u.w == tap) g[3] += d[3];
+                    const size_t o = ((size_t)(n * OH + oy) * OW + (size_t)ox) * cvn + cg;
+                    const vec d = Act<T>::ldv(dp + o * V);
+#pragma unroll
+                    for (int q = 0; q < V / 4; ++q) {
+                        const uchar4 u = reinterpret_cast<const uchar4*>(a.idx)[o * (V / 4) + q];
+                        if (u.x == tap) g[4 * q] += d[4 * q];
+                        if (u.y == tap) g[4 * q + 1] += d[4 * q + 1];
+                        if (u.z == tap) g[4 * q + 2] += d[4 * q + 2];
+                        if (u.w == tap) g[4 * q + 3] += d[4 * q + 3];
+                    }
                 }
             }
-            const f32x4 v = Act<T>::ld4(y + (p * c4n + cg) * 4);
-            const f32x4 z = v * sc + sh;
+            const vec v = Act<T>::ldv(y + (p * cvn + cg) * V);
+            const vec z = v * sc + sh;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
-            Act<T>::st4(gout + (p * c4n + cg) * 4, g);
+            for (int e = 0; e < V; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+            Act<T>::stv(gout + (p * cvn + cg) * V, g);
             s1 += g;
             s2 += g * (v - mean) * inv;
         }
     }
-    reinterpret_cast<f32x4*>(red)[threadIdx.x] = s1;
-    reinterpret_cast<f32x4*>(red)[256 + threadIdx.x] = s2;
+    PV::st(red + threadIdx.x * V, s1);
+    PV::st(red + (256 + threadIdx.x) * V, s2);
     __syncthreads();
-    if (threadIdx.x < c4n) {
-        f32x4 t1 = {0.f, 0.f, 0.f, 0.f}, t2 = t1;
+    if (threadIdx.x < cvn) {
+        vec t1 = PV::splat(0.f), t2 = t1;
         for (int k = 0; k < rl; ++k) {
-            t1 += reinterpret_cast<const f32x4*>(red)[k * c4n + threadIdx.x];
-            t2 += reinterpret_cast<const f32x4*>(red)[256 + k * c4n + threadIdx.x];
+            t1 += PV::ld(red + (k * cvn + threadIdx.x) * V);
+            t2 += PV::ld(red + (256 + k * cvn + threadIdx.x) * V);
         }
         float* dst = a.partial + (size_t)blockIdx.x * 2 * a.C;
-        *reinterpret_cast<f32x4*>(dst + c) = t1;
-        *reinterpret_cast<f32x4*>(dst + a.C + c) = t2;
+        PV::st(dst + c, t1);
+        PV::st(dst + a.C + c, t2);
     }
 }
 
@@ -135,9 +145,9 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
 
 int lbc_bn_relu_maxpool_fwd(const PoolFwdArgs& a, hipStream_t s)
 {
-    LBC_REQUIRE(a.C % 4 == 0 && a.H % 2 == 0 && a.W % 2 == 0, "maxpool: bad shape");
+    LBC_REQUIRE(a.C % 8 == 0 && a.H % 2 == 0 && a.W % 2 == 0, "maxpool: bad shape");
     const long long total = (long long)a.N * (a.H / 2) * (a.W / 2) * (a.C / 4);
-    long long blocks = (total + 255) / 256;
+    long long blocks = (total / (a.act_bf16 ? 2 : 1) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     LbcProfScope prof("bn_relu_maxpool_fwd", 0.0, (a.act_bf16 ? 2.0 : 4.0) * total * 4 * (4.0 + 1.0) + total * 4.0, s);
 #define LBC_K(T, g) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
@@ -150,7 +160,7 @@ int lbc_pool_bwd_rows(int N, int H, int W, int C) { return lbc_chan_reduce_rows(
 
 int lbc_maxpool_relu_bwd_reduce(PoolBwdArgs a, hipStream_t s)
 {
-    LBC_REQUIRE(a.C % 4 == 0 && a.C / 4 <= 256, "maxpool_bwd: bad C");
+    LBC_REQUIRE(a.C % 8 == 0 && a.C / 4 <= 256, "maxpool_bwd: bad C");
     const long long pixels = (long long)a.N * a.H * a.W;
     const int rows = lbc_pool_bwd_rows(a.N, a.H, a.W, a.C);
     a.pix_per_block = (pixels + rows - 1) / rows;

@@ -351,8 +351,8 @@ def test_conv3x3_halo_persistent_workgroups(env, cfg, force_cfg):
 
 
 # ---- tap-fused 3x3 / stride-1 weight gradient with transpose reads (conv_wgrad_tr.hip): bf16 tensors, W % 8 == 0 ----------
-WTR_SMALL = [(1, 4, 16, 64, 64), (2, 3, 24, 64, 128), (1, 9, 16, 128, 64), (3, 2, 16, 64, 64), (4, 16, 16, 64, 64)]   # the last: 16 chunks, ring wrap, 2 splits
-WTR_REAL = [pytest.param(c, marks=gpu) for c in [(8, 40, 96, 64, 64), (4, 20, 48, 128, 128), (8, 10, 24, 256, 256), (3, 48, 48, 64, 64), (2, 20, 48, 64, 128)]]
+WTR_SMALL = [(2, 5, 12, 64, 64), (1, 3, 9, 64, 64), (1, 4, 16, 64, 64), (2, 3, 24, 64, 128), (1, 9, 16, 128, 64), (3, 2, 16, 64, 64), (4, 16, 16, 64, 64)]   # the last: 16 chunks, ring wrap, 2 splits
+WTR_REAL = [pytest.param(c, marks=gpu) for c in [(16, 5, 12, 512, 512), (8, 40, 96, 64, 64), (4, 20, 48, 128, 128), (8, 10, 24, 256, 256), (3, 48, 48, 64, 64), (2, 20, 48, 64, 128)]]
 
 
 @pytest.mark.parametrize("cfg", WTR_SMALL + WTR_REAL)

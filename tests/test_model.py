@@ -428,3 +428,19 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, monkeypa
     # yardstick is the emulation itself: the executor's gradients must be as close to exact f32 as the emulation's are.
     assert c_ef[0] > c_mf[0] - 0.08 and c_ef[1] > c_mf[1] - 0.12, (c_ef, c_mf)
     assert c_ee[0] > (0.8 if precision == 1 else 0.6) and c_ee[1] > (0.6 if precision == 1 else 0.45), c_ee
+
+
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])
+def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, monkeypatch):
+    """bf16 activations: the waypoint head's projection runs on the bf16 MFMA with folded weights rounded to bf16; the
+    LDS/f32 head kernel on the same bf16 decoder output and the same rounded weights must agree to f32 summation order"""
+    dev, _ = env
+    sd = O.make_state_dict(kind, backbone, 9, h, w)
+    x, speed, cmd = _inputs(kind, n, h, w, 8)
+    eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=2)
+    for train in (True, False):
+        ps1, pa1 = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), train)
+        monkeypatch.setenv("LBC_HEAD_NO_MFMA", "1")
+        ps2, pa2 = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), train)
+        monkeypatch.delenv("LBC_HEAD_NO_MFMA")
+        assert (pa1 - pa2).abs().max().item() < 2e-5 and (ps1 - ps2).abs().max().item() < 2e-5
