@@ -36,37 +36,44 @@ __global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict_
     out[(size_t)blockIdx.y * cols + c] = (float)((s0 + s1) + (s2 + s3));
 }
 
-// Sums column c of a [rows][2][C] partial buffer.  The finalize kernels run 256 threads = 64 channels x 4 row-lanes: lane q
-// takes rows q, q+4, ... with two loads in flight, the four lanes are combined through LDS in a fixed order (deterministic).
+// Sums column c of a [rows][2][C] partial buffer.  The finalize kernels run 1024 threads = 16 channels x 64 row-lanes: lane q
+// takes rows q, q+64, ... with four row pairs in flight, the 64 lanes are combined through LDS in a fixed order
+// (deterministic).  Up to ~1024 rows this is one short launch; larger row counts are pre-reduced by partial_reduce_k.
+constexpr int kFinCh = 16, kFinLanes = 64;
 __device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int rows, int C, int c, bool valid, double& o1, double& o2)
 {
-    __shared__ double red[2][4][64];
-    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-    double a0 = 0.0, a1 = 0.0, b0 = 0.0, b1 = 0.0;
+    __shared__ double red[2][kFinLanes][kFinCh];
+    const int cl = threadIdx.x & (kFinCh - 1), q = threadIdx.x / kFinCh;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     if (valid) {
+        const size_t rs = (size_t)2 * C;
         int r = q;
-        for (; r + 4 < rows; r += 8) {
-            const float* p = partial + (size_t)r * 2 * C + c;
-            a0 += (double)p[0];             b0 += (double)p[C];
-            a1 += (double)p[8 * C];         b1 += (double)p[9 * C];
+        for (; r + 3 * kFinLanes < rows; r += 4 * kFinLanes) {
+            const float* p = partial + (size_t)r * rs + c;
+            a0 += (double)p[0];                      b0 += (double)p[C];
+            a1 += (double)p[kFinLanes * rs];         b1 += (double)p[kFinLanes * rs + C];
+            a2 += (double)p[2 * kFinLanes * rs];     b2 += (double)p[2 * kFinLanes * rs + C];
+            a3 += (double)p[3 * kFinLanes * rs];     b3 += (double)p[3 * kFinLanes * rs + C];
         }
-        for (; r < rows; r += 4) {
-            a0 += (double)partial[(size_t)r * 2 * C + c];
-            b0 += (double)partial[(size_t)r * 2 * C + C + c];
+        for (; r < rows; r += kFinLanes) {
+            a0 += (double)partial[(size_t)r * rs + c];
+            b0 += (double)partial[(size_t)r * rs + C + c];
         }
     }
-    red[0][q][cl] = a0 + a1;
-    red[1][q][cl] = b0 + b1;
+    red[0][q][cl] = (a0 + a1) + (a2 + a3);
+    red[1][q][cl] = (b0 + b1) + (b2 + b3);
     __syncthreads();
-    o1 = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-    o2 = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    o1 = 0.0; o2 = 0.0;
+    if (q == 0) {
+        for (int k = 0; k < kFinLanes; ++k) { o1 += red[0][k][cl]; o2 += red[1][k][cl]; }
+    }
 }
 
 // ---- forward finalize ----------------------------------------------------------
-__global__ __launch_bounds__(256) void bn_finalize_k(BnFinalizeArgs a)
+__global__ __launch_bounds__(1024) void bn_finalize_k(BnFinalizeArgs a)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const bool lead = threadIdx.x < 64;
+    const int c = blockIdx.x * kFinCh + (threadIdx.x & (kFinCh - 1));
+    const bool lead = threadIdx.x < kFinCh;
     if (c == 0 && lead && a.num_batches_tracked && a.train) *a.num_batches_tracked += 1;
     double s1 = 0.0, s2 = 0.0;
     if (a.train) sum_rows2(a.partial, a.rows, a.C, c, c < a.C, s1, s2);
@@ -198,12 +205,12 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
 //   dx = A*(g - k1 - xhat*k2),  A = gamma*invstd, k1 = sum(g)/n, k2 = sum(g*xhat)/n,
 //   xhat recomputed per element as (x-mean)*invstd (factoring it into B*x + D would put a
 //   systematic per-channel rounding offset on dx that downstream channel sums amplify).
-__global__ __launch_bounds__(256) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
+__global__ __launch_bounds__(1024) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
 {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int c = blockIdx.x * kFinCh + (threadIdx.x & (kFinCh - 1));
     double s1, s2;
     sum_rows2(a.partial, a.rows, a.C, c, c < a.C, s1, s2);
-    if (c >= a.C || threadIdx.x >= 64) return;
+    if (c >= a.C || threadIdx.x >= kFinCh) return;
     if (a.dbeta) a.dbeta[c] = (float)s1;
     if (a.dgamma) a.dgamma[c] = (float)s2;
     if (a.coefA) {
@@ -296,7 +303,7 @@ int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C > 0 && a.scale && a.shift, "bn_finalize: bad args");
     LbcProfScope prof("bn_finalize", 0.0, 4.0 * (double)a.rows * 2 * a.C, s);
-    hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)lbc_cdiv(a.C, kFinCh)), dim3(1024), 0, s, a);
     return lbc_check_launch("bn_finalize");
 }
 
@@ -343,7 +350,7 @@ int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
 int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s)
 {
     LbcProfScope prof("bn_bwd_finalize", 0.0, 4.0 * (double)a.rows * 2 * a.C, s);
-    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((unsigned)lbc_cdiv(a.C, 64)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(bn_bwd_finalize_k, dim3((unsigned)lbc_cdiv(a.C, kFinCh)), dim3(1024), 0, s, a);
     return lbc_check_launch("bn_bwd_finalize");
 }
 

@@ -244,7 +244,7 @@ int Net::weight_prep(hipStream_t s)
 int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running)
 {
     const float* part = W(partial_);
-    if (train && rows > 64) {
+    if (train && rows > kLbcFinalizeRows) {
         LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * bn.C, W(partial2_), 64, s));
         part = W(partial2_);
         rows = 64;
@@ -392,6 +392,7 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     ha.cmd = W(cmd_);
     ha.pred_all = W(pred_all_); ha.pred_sel = pred_sel; ha.rowstat = W(rowstat_);
     ha.N = N; ha.OH = HH_; ha.OW = HW_; ha.act_bf16 = act_bf16_;
+    ha.scratch = W(head_partial_);       // max_batch * 20 * 65 floats >= N * 16 * 20 * 4
     LBC_TRY(lbc_head_fwd(ha, s));
     if (hipMemcpyAsync(pred_all, W(pred_all_), sizeof(float) * 40 * N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
         lbc_set_error("net.forward: output copy failed");
@@ -413,7 +414,7 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
     LBC_TRY(lbc_chan_reduce(r, 1, s));
     int rows = lbc_chan_reduce_rows(pixels, bn.C);
     const float* part = W(partial_);
-    if (rows > 64) {
+    if (rows > kLbcFinalizeRows) {
         LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * bn.C, W(partial2_), 64, s));
         part = W(partial2_); rows = 64;
     }
@@ -571,7 +572,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
             LBC_TRY(lbc_chan_reduce(r, 1, s));
             int rows = lbc_chan_reduce_rows(opix, D.Cout);
             const float* part = W(partial_);
-            if (rows > 64) {
+            if (rows > kLbcFinalizeRows) {
                 LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * D.Cout, W(partial2_), 64, s));
                 part = W(partial2_); rows = 64;
             }
@@ -629,7 +630,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
         int rows = lbc_pool_bwd_rows(N, H0 / 2, W0 / 2, 64);
         const long long pix = (long long)N * (H0 / 2) * (W0 / 2);
         const float* part = W(partial_);
-        if (rows > 64) {
+        if (rows > kLbcFinalizeRows) {
             LBC_TRY(lbc_partial_reduce(W(partial_), rows, 128, W(partial2_), 64, s));
             part = W(partial2_); rows = 64;
         }

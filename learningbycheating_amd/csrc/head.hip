@@ -160,6 +160,7 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(HeadArgs a)
     const int l31 = lane & 31, kh = lane >> 5;
     const int n = blockIdx.x;
     const int HW = a.OH * a.OW;
+    const int S = a.nslice, slice = blockIdx.y;      // small batches: the image's pixel groups are split over S workgroups
     for (int b = 0; b < 4; ++b) fold_branch(a, b, sWf + b * 320, sBf + b * 8, tid, 256);
     __syncthreads();
     const bool colok = l31 < 20;
@@ -176,7 +177,7 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(HeadArgs a)
 
     SoftAcc st; st.m = -INFINITY; st.l = 0.f; st.sx = 0.f; st.sy = 0.f;
     const int ngroup = (HW + 31) / 32;
-    for (int grp = wave; grp < ngroup; grp += 4) {
+    for (int grp = slice * 4 + wave; grp < ngroup; grp += 4 * S) {
         const int pbase = grp * 32;
         const int pl = pbase + l31 < HW ? pbase + l31 : HW - 1;       // rows past the map are computed on a valid pixel and skipped below
         f32x16 acc;
@@ -213,11 +214,34 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(HeadArgs a)
             o.sx = sRed[(w * 32 + tid) * 4 + 2]; o.sy = sRed[(w * 32 + tid) * 4 + 3];
             soft_merge(t, o);
         }
-        const size_t o2 = ((size_t)n * 20 + tid) * 2;      // column = branch * 5 + step
-        a.pred_all[o2] = t.sx / t.l;
-        a.pred_all[o2 + 1] = t.sy / t.l;
-        if (a.rowstat) { a.rowstat[o2] = t.m; a.rowstat[o2 + 1] = t.l; }
+        if (S > 1) {
+            float* dst = a.scratch + (((size_t)n * S + slice) * 20 + tid) * 4;
+            dst[0] = t.m; dst[1] = t.l; dst[2] = t.sx; dst[3] = t.sy;
+        } else {
+            const size_t o2 = ((size_t)n * 20 + tid) * 2;      // column = branch * 5 + step
+            a.pred_all[o2] = t.sx / t.l;
+            a.pred_all[o2 + 1] = t.sy / t.l;
+            if (a.rowstat) { a.rowstat[o2] = t.m; a.rowstat[o2 + 1] = t.l; }
+        }
     }
+}
+
+// merges the per-slice partials of head_fwd_mfma_k in slice order
+__global__ __launch_bounds__(256) void head_merge_k(HeadArgs a)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;   // over N*20
+    if (i >= a.N * 20) return;
+    const int n = i / 20, col = i - n * 20;
+    const float* src = a.scratch + ((size_t)n * a.nslice * 20 + col) * 4;
+    SoftAcc t; t.m = src[0]; t.l = src[1]; t.sx = src[2]; t.sy = src[3];
+    for (int k = 1; k < a.nslice; ++k) {
+        const float* p = src + (size_t)k * 80;
+        SoftAcc o; o.m = p[0]; o.l = p[1]; o.sx = p[2]; o.sy = p[3];
+        soft_merge(t, o);
+    }
+    a.pred_all[(size_t)i * 2] = t.sx / t.l;
+    a.pred_all[(size_t)i * 2 + 1] = t.sy / t.l;
+    if (a.rowstat) { a.rowstat[(size_t)i * 2] = t.m; a.rowstat[(size_t)i * 2 + 1] = t.l; }
 }
 
 __global__ __launch_bounds__(256) void select_branch_k(const float* __restrict__ all, const float* __restrict__ cmd,
@@ -453,7 +477,16 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
     LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
     LbcProfScope prof("head_fwd", 2.0 * a.N * a.OH * a.OW * 64.0 * 20, 4.0 * a.N * (double)a.OH * a.OW * 64, s);
     const bool no_mfma = getenv("LBC_HEAD_NO_MFMA") && getenv("LBC_HEAD_NO_MFMA")[0] == '1';   // A/B switch
-    if (a.act_bf16 && !no_mfma) hipLaunchKernelGGL(head_fwd_mfma_k, dim3((unsigned)a.N), dim3(256), 0, s, a);
+    if (a.act_bf16 && !no_mfma) {
+        HeadArgs b = a;
+        b.nslice = 1;
+        if (a.scratch && a.N < 128) {                    // fill the chip at small batch: 2..16 slices per image
+            b.nslice = (256 + a.N - 1) / a.N;
+            if (b.nslice > 16) b.nslice = 16;
+        }
+        hipLaunchKernelGGL(head_fwd_mfma_k, dim3((unsigned)a.N, (unsigned)b.nslice), dim3(256), 0, s, b);
+        if (b.nslice > 1) hipLaunchKernelGGL(head_merge_k, dim3((unsigned)lbc_cdiv(a.N * 20, 256)), dim3(256), 0, s, b);
+    }
     else if (a.act_bf16) hipLaunchKernelGGL((head_fwd_k<__bf16>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((head_fwd_k<float>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
     int rc = lbc_check_launch("head_fwd");

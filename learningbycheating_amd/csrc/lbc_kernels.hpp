@@ -4,6 +4,8 @@
 #include "lbc_common.hpp"
 
 // ---- BatchNorm forward -----------------------------------------------------------
+// the finalize kernels sum up to this many partial rows themselves; beyond it lbc_partial_reduce runs first
+constexpr int kLbcFinalizeRows = 1024;
 struct BnFinalizeArgs {
     const float* partial;        // [rows][2][C] (sum, sum^2); unused in eval
     int rows, C;
@@ -141,6 +143,8 @@ struct HeadArgs {
     float* pred_sel;             // [N][5][2] (nullable)
     float* rowstat;              // [N][4][5][2] (max, sum exp) saved for backward (nullable)
     int N, OH, OW;               // softmax map is OH x OW (pos_x over OW, pos_y over OH)
+    float* scratch;              // >= N * 16 * 20 * 4 floats: per-slice soft-argmax partials of small-batch launches (nullable)
+    int nslice;                  // set by lbc_head_fwd
 };
 int lbc_head_fwd(const HeadArgs& a, hipStream_t s);
 struct HeadBwdArgs {
