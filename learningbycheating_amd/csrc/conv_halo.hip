@@ -132,20 +132,32 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_k(IgemmArgs a)
                 }
             }
         }
-        // epilogue
+        // epilogue.  The residual (identity gradient of the input-gradient launches) is fetched for the whole tile first:
+        // read inside the store loop, every 2-byte load is waited for on its own (32 serial L2 round trips per tile).
         float s1 = 0.f, s2 = 0.f;
         const int col = wn * 32 + l31;
 #pragma unroll
-        for (int mi = 0; mi < MT; ++mi) {
+        for (int hb = 0; hb < MT * 2; ++hb) {          // 8 accumulator rows at a time (the register file is full of weights)
+            const int mi = hb >> 1, e0 = (hb & 1) * 8;
+            float rv[8];
+            if (resid) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + k;
+                    const int m = m0 + (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    rv[k] = (float)resid[(unsigned)(m < M ? m : 0) * (unsigned)BN + (unsigned)col];
+                }
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int e = e0 + k;
                 const int row = (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
                 const int m = m0 + row;
                 if (m < M) {
                     const unsigned o = (unsigned)m * (unsigned)BN + (unsigned)col;
                     float v = acc[mi][e];
                     if (a.bias) v += a.bias[col];
-                    if (resid) v += (float)resid[o];
+                    if (resid) v += rv[k];
                     if (a.relu) v = fmaxf(v, 0.f);
                     yout[o] = (__bf16)v;
                     s1 += v;

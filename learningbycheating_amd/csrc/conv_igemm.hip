@@ -286,8 +286,22 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
 #pragma unroll
     for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
 
+    // The residual is fetched per 32-row block before that block's stores: read inside the store loop, every narrow load
+    // is waited for on its own (16 x NT serial L2 round trips per block of rows).
 #pragma unroll
     for (int mi = 0; mi < MT; ++mi) {
+        float rv[16][NT];
+        if (a.resid) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int m = m0 + row;
+                const size_t ob = (m < a.M) ? (a.ostep == 1 ? (size_t)m * (size_t)a.K : (size_t)sOpix[row] * (size_t)a.K) : 0;
+#pragma unroll
+                for (int nj = 0; nj < NT; ++nj)
+                    rv[r][nj] = Act<AT>::ld1(static_cast<const AT*>(a.resid) + ob + (size_t)(n0 + (wn * NT + nj) * 32 + l31));
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int row = (wm * MT + mi) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
@@ -304,7 +318,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
                     const int col = n0 + (wn * NT + nj) * 32 + l31;
                     float v = acc[mi][nj][r];
                     if (a.bias) v += a.bias[col];
-                    if (a.resid) v += Act<AT>::ld1(static_cast<const AT*>(a.resid) + obase + col);
+                    if (a.resid) v += rv[r][nj];
                     if (a.relu) v = fmaxf(v, 0.f);
                     Act<AT>::st1(static_cast<AT*>(a.y) + obase + col, v);
                     s1[nj] += v;
@@ -313,7 +327,6 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             }
         }
     }
-
     if (a.stats) {
         // combine the two half-waves (rows 4*kh+...), then the two M-waves through LDS
         float* red = reinterpret_cast<float*>(&sA[0][0]);   // [WM][2][BN]; the main loop's last barrier has passed

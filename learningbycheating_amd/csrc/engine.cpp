@@ -550,6 +550,10 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
         HeadBwdFinalizeArgs hf;
         memset(&hf, 0, sizeof(hf));
         hf.s_partial = W(head_partial_); hf.rows = N; hf.count = (long long)N * HH_ * HW_;
+        if (N > 8) {   // the finalize kernel is one workgroup walking the rows serially: hand it 8 pre-reduced rows
+            LBC_TRY(lbc_partial_reduce(W(head_partial_), N, 20 * 65, W(partial2_), 8, s));
+            hf.s_partial = W(partial2_); hf.rows = 8;
+        }
         for (int b = 0; b < 4; ++b) {
             hf.gamma[b] = P(head_bn_[b].g); hf.beta[b] = P(head_bn_[b].b); hf.w[b] = P(head_w_[b]);
             hf.dgamma[b] = G(head_bn_[b].g); hf.dbeta[b] = G(head_bn_[b].b);

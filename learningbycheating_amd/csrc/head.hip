@@ -514,6 +514,7 @@ int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s)
 
 int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s)
 {
+    LbcProfScope prof("head_bwd_finalize", 0.0, 4.0 * (double)a.rows * 20 * 65, s);
     hipLaunchKernelGGL(head_bwd_finalize_k, dim3(1), dim3(256), 0, s, a);
     return lbc_check_launch("head_bwd_finalize");
 }
