@@ -30,8 +30,11 @@ namespace {
 // AT = element type of the activation tensors x / y / resid in HBM (float, or __bf16 with BF16 = true): bf16 activations
 // are loaded 8 channels per 16-byte load and go to LDS without conversion unless a BatchNorm-on-load prologue is set.
 // WT = element type of the weight operand in HBM (float, or __bf16 with BF16 = true: a per-step bf16 copy, lbc_weight_prep).
-template <int BM, int BN, bool WMAJOR, int MODE, bool BF16, typename AT, typename WT>
-__global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
+// PF = prefetch distance in depth chunks: the global loads of chunk it+PF are issued while chunk it is multiplied and are
+// written to LDS one chunk before their use, from PF register sets.  With two workgroups per CU a chunk lasts about one
+// loaded-L2 round trip (measured 1.5 us per chunk = 7x its MFMA time at PF = 1), so the all-bf16 kernels run PF = 2.
+template <int BM, int BN, bool WMAJOR, int MODE, bool BF16, typename AT, typename WT, int PF>
+__global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a)
 {
     static_assert(!BF16 || WMAJOR, "the bf16 path needs depth-contiguous weights");
     static_assert(!Act<AT>::kBf16 || BF16, "bf16 activations need the bf16 MFMA path");
@@ -135,12 +138,14 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    areg_t ra[RA];          // native vector values (HIP's float4 struct would be copied through a scratch alloca)
-    breg_t rb[RB];
-    bool aok[RA];
-    f32x4 lps[AEL / 4], lpt[AEL / 4];
+    areg_t ra[PF][RA];      // native vector values (HIP's float4 struct would be copied through a scratch alloca)
+    breg_t rb[PF][RB];
+    bool aok[PF][RA];
+    f32x4 lps[PF][AEL / 4], lpt[PF][AEL / 4];
 #pragma unroll
-    for (int q = 0; q < AEL / 4; ++q) { lps[q] = f32x4{1.f, 1.f, 1.f, 1.f}; lpt[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    for (int u = 0; u < PF; ++u)
+#pragma unroll
+        for (int q = 0; q < AEL / 4; ++q) { lps[u][q] = f32x4{1.f, 1.f, 1.f, 1.f}; lpt[u][q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
     const float relu_floor = (a.pre_scale && a.pre_relu) ? 0.f : -INFINITY;
 
     // Software pipeline, written out once (no lambdas: the staging arrays must stay in registers):
@@ -151,12 +156,19 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
     // chunk it+1 stay in flight underneath the MFMAs of chunk it.
     const int l31 = lane & 31;
     const int kh = lane >> 5;
-    for (int it = -1; it < nit; ++it) {
-        const bool more = it + 1 < nit;
-        if (more) {
+    // it runs from -PF; the inner loop is unrolled PF times so that the register-set indices are compile-time constants:
+    // chunk it+PF is loaded into set u, chunk it+1 is stored from set (u+1) % PF.
+    for (int it0 = -PF; it0 < nit; it0 += PF) {
+#pragma unroll
+      for (int u = 0; u < PF; ++u) {
+        const int it = it0 + u;
+        if (it >= nit) break;
+        const int LS = u;                     // register set receiving the loads of this step
+        const int SS = (u + 1) % PF;          // register set written to LDS in this step
+        if (it + PF < nit) {
             // depth order: 32-channel slab outer, filter taps inner -- the (up to 9) shifted gathers of one slab re-read
             // the same few KB per workgroup back to back (L1/L2 hits) instead of streaming the whole tile 9 times
-            const int nx = it + 1;
+            const int nx = it + PF;
             const int ci = nx / ntap;
             const int ti = nx - ci * ntap;
             const int c0 = ci * BK;
@@ -165,8 +177,8 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
             if (a.pre_scale) {
 #pragma unroll
                 for (int q = 0; q < AEL / 4; ++q) {
-                    lps[q] = *reinterpret_cast<const f32x4*>(a.pre_scale + c0 + aseg * AEL + q * 4);
-                    lpt[q] = *reinterpret_cast<const f32x4*>(a.pre_shift + c0 + aseg * AEL + q * 4);
+                    lps[LS][q] = *reinterpret_cast<const f32x4*>(a.pre_scale + c0 + aseg * AEL + q * 4);
+                    lpt[LS][q] = *reinterpret_cast<const f32x4*>(a.pre_shift + c0 + aseg * AEL + q * 4);
                 }
             }
 #pragma unroll
@@ -177,8 +189,8 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
                 else { iy = ay[j] - r; ix = ax[j] - s; }
                 const bool ok = (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W;
                 const int pix = ok ? (pixbase[j] + iy * a.W + ix) : 0;
-                aok[j] = ok;
-                ra[j] = *reinterpret_cast<const areg_t*>(xin + ((size_t)pix * (size_t)a.C + (size_t)(c0 + aseg * AEL)));
+                aok[LS][j] = ok;
+                ra[LS][j] = *reinterpret_cast<const areg_t*>(xin + ((size_t)pix * (size_t)a.C + (size_t)(c0 + aseg * AEL)));
             }
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
                     const int s4 = idx - krow * (BN / 4);
                     off = (size_t)(c0 + krow) * (size_t)(T * a.K) + (size_t)(tap * a.K + n0 + s4 * 4);
                 }
-                rb[j] = *reinterpret_cast<const breg_t*>(static_cast<const WT*>(a.w) + off);
+                rb[LS][j] = *reinterpret_cast<const breg_t*>(static_cast<const WT*>(a.w) + off);
             }
         }
         if (it >= 0) {
@@ -239,25 +251,25 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
                 }
             }
         }
-        if (more) {
+        if (it + 1 >= 0 && it + 1 < nit) {
             const int buf = (it + 1) & 1;
 #pragma unroll
             for (int j = 0; j < RA; ++j) {
                 lds_t* dst = &sA[buf][(aarow + ARPP * j) * LDK + aseg * AEL];
                 if constexpr (ABF) {
-                    bf16x8 h = ra[j];
+                    bf16x8 h = ra[SS][j];
                     if (a.pre_scale) {      // BatchNorm(+ReLU) on load: unpack, f32 affine, repack
                         f32x8 v = __builtin_convertvector(h, f32x8);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * lps[e >> 2][e & 3] + lpt[e >> 2][e & 3], relu_floor);
+                        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * lps[SS][e >> 2][e & 3] + lpt[SS][e >> 2][e & 3], relu_floor);
                         h = __builtin_convertvector(v, bf16x8);
                     }
-                    if (!aok[j]) h = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                    if (!aok[SS][j]) h = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
                     *reinterpret_cast<bf16x8*>(dst) = h;
                 } else {
-                    f32x4 v = ra[j] * lps[0] + lpt[0];
+                    f32x4 v = ra[SS][j] * lps[SS][0] + lpt[SS][0];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = aok[j] ? fmaxf(v[e], relu_floor) : 0.f;
+                    for (int e = 0; e < 4; ++e) v[e] = aok[SS][j] ? fmaxf(v[e], relu_floor) : 0.f;
                     if constexpr (BF16) *reinterpret_cast<bf16x4*>(dst) = __builtin_convertvector(v, bf16x4);
                     else                *reinterpret_cast<f32x4*>(dst) = v;
                 }
@@ -265,20 +277,21 @@ __global__ __launch_bounds__(256) void conv_igemm_k(IgemmArgs a)
 #pragma unroll
             for (int j = 0; j < RB; ++j) {
                 if constexpr (WBF) {
-                    *reinterpret_cast<bf16x8*>(&sB[buf][(arow + RPP * j) * LDK + seg * 8]) = rb[j];
+                    *reinterpret_cast<bf16x8*>(&sB[buf][(arow + RPP * j) * LDK + seg * 8]) = rb[SS][j];
                 } else if constexpr (BF16) {
-                    *reinterpret_cast<bf16x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = __builtin_convertvector(rb[j], bf16x4);
+                    *reinterpret_cast<bf16x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = __builtin_convertvector(rb[SS][j], bf16x4);
                 } else if (WMAJOR) {
-                    *reinterpret_cast<f32x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = rb[j];
+                    *reinterpret_cast<f32x4*>(&sB[buf][(arow + RPP * j) * LDK + seg * 4]) = rb[SS][j];
                 } else {
                     const int idx = tid + 256 * j;
                     const int krow = idx / (BN / 4);
                     const int s4 = idx - krow * (BN / 4);
-                    *reinterpret_cast<f32x4*>(&sB[buf][krow * LDN + s4 * 4]) = rb[j];
+                    *reinterpret_cast<f32x4*>(&sB[buf][krow * LDN + s4 * 4]) = rb[SS][j];
                 }
             }
         }
         __syncthreads();
+      }
     }
 
     // ---- epilogue ------------------------------------------------------------
@@ -415,18 +428,18 @@ int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
     dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN)));
     if (a.w_bf16) {
-        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, __bf16>), grid, dim3(256), 0, s, a);
-        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, __bf16>), grid, dim3(256), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, __bf16, 2>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, __bf16, 2>), grid, dim3(256), 0, s, a);
     } else if (a.act_bf16) {
-        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, float>), grid, dim3(256), 0, s, a);
-        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, float>), grid, dim3(256), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, float, 1>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, float, 1>), grid, dim3(256), 0, s, a);
     } else if (a.bf16) {
-        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, float, float>), grid, dim3(256), 0, s, a);
-        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, float, float>), grid, dim3(256), 0, s, a);
-    } else if (wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, false, float, float>), grid, dim3(256), 0, s, a);
-    else if (wmajor && mode == 1)   hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, false, float, float>), grid, dim3(256), 0, s, a);
-    else if (!wmajor && mode == 0)  hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 0, false, float, float>), grid, dim3(256), 0, s, a);
-    else                            hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 1, false, float, float>), grid, dim3(256), 0, s, a);
+        if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, float, float, 1>), grid, dim3(256), 0, s, a);
+        else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, float, float, 1>), grid, dim3(256), 0, s, a);
+    } else if (wmajor && mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, false, float, float, 1>), grid, dim3(256), 0, s, a);
+    else if (wmajor && mode == 1)   hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, false, float, float, 1>), grid, dim3(256), 0, s, a);
+    else if (!wmajor && mode == 0)  hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 0, false, float, float, 1>), grid, dim3(256), 0, s, a);
+    else                            hipLaunchKernelGGL((conv_igemm_k<BM, BN, false, 1, false, float, float, 1>), grid, dim3(256), 0, s, a);
     return lbc_check_launch("conv_igemm");
 }
 
