@@ -26,9 +26,10 @@ namespace {
 constexpr int kRing = 328;      // ring rows: 64 + 2W + 2 live rows + 64 incoming, W <= 96
 constexpr int kRS = 80;         // LDS row stride in elements (160 B): spreads the 4 pixel rows of a transpose read over the banks
 
-// ALIGNED: W % 8 == 0 (a lane's 8-pixel group lies in one image row: whole-group / first-pixel / last-pixel masks).
-// Otherwise (W >= 8, e.g. the 5 x 12 maps of layer 4) the group may straddle two rows and every pixel gets its own flags.
-template <bool ALIGNED>
+// ALIGN = 8: W % 8 == 0 (a lane's 8-pixel group lies in one image row: whole-group / first-pixel / last-pixel masks).
+// ALIGN = 4: W % 4 == 0 (the 5 x 12 maps of layer 4): the same per 4-pixel half of the group (the second half may sit in
+// the next row).  ALIGN = 0: any W >= 8, every pixel gets its own flags.
+template <int ALIGN>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_per_split)
 {
     constexpr int BRH = 64;
@@ -122,11 +123,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
             const int pcol = 32 * wp + 16 * G1 + (t16 & 3) * 4;
             const bf16x4 a0 = lds_read_tr16(&sP[buf][prow * kRS + pcol]);
             const bf16x4 a1 = lds_read_tr16(&sP[buf][(prow + 4) * kRS + pcol]);
-            // tap validity of the group's 8 pixels
-            bool top = false, bottom = false, left = false, right = false;
-            unsigned mt[4], mb[4], ml[4], mr[4];      // !ALIGNED: per-dword keep-masks (two bf16 each) of the four border classes
-            if constexpr (ALIGNED) {
-                top = y == 0; bottom = y == H - 1; left = x0 == 0; right = x0 == W - 8;
+            // tap validity of the group's 8 pixels (two halves of 4: the elements of the two transpose reads)
+            bool top[2] = {false, false}, bottom[2] = {false, false}, left[2] = {false, false}, right[2] = {false, false};
+            unsigned mt[4], mb[4], ml[4], mr[4];      // ALIGN 0: per-dword keep-masks (two bf16 each) of the four border classes
+            if constexpr (ALIGN == 8) {
+                top[0] = top[1] = y == 0; bottom[0] = bottom[1] = y == H - 1;
+                left[0] = x0 == 0; right[1] = x0 == W - 8;
+            } else if constexpr (ALIGN == 4) {
+                const bool wrap = x0 + 4 >= W;                 // the second half starts the next image row
+                const int x1 = wrap ? 0 : x0 + 4;
+                const int y1 = wrap ? (y + 1 == H ? 0 : y + 1) : y;
+                top[0] = y == 0; bottom[0] = y == H - 1; left[0] = x0 == 0; right[0] = x0 == W - 4;
+                top[1] = y1 == 0; bottom[1] = y1 == H - 1; left[1] = x1 == 0; right[1] = x1 == W - 4;
             } else {
 #pragma unroll
                 for (int d = 0; d < 4; ++d) { mt[d] = 0xffffffffu; mb[d] = 0xffffffffu; ml[d] = 0xffffffffu; mr[d] = 0xffffffffu; }
@@ -142,9 +150,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                     if (xi == W - 1) mr[i >> 1] &= clr;
                 }
             }
-            bf16x4 a0l = a0, a1r = a1;
-            if (ALIGNED && left) a0l[0] = (__bf16)0.f;           // pixel 0 of the group has no left neighbour
-            if (ALIGNED && right) a1r[3] = (__bf16)0.f;          // pixel 7 has no right neighbour
+            // halves with their first / last pixel removed (no left / right neighbour)
+            bf16x4 a0l = a0, a0r = a0, a1l = a1, a1r = a1;
+            if (ALIGN != 0) {
+                if (left[0]) a0l[0] = (__bf16)0.f;
+                if (right[0]) a0r[3] = (__bf16)0.f;
+                if (left[1]) a1l[0] = (__bf16)0.f;
+                if (right[1]) a1r[3] = (__bf16)0.f;
+            }
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int r = t / 3, s = t - 3 * r;
@@ -156,13 +169,11 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                 const bf16x4 b0 = lds_read_tr16(&sQ[row * kRS + qcol]);
                 const bf16x4 b1 = lds_read_tr16(&sQ[row4 * kRS + qcol]);
                 bf16x8 af;
-                if constexpr (ALIGNED) {
-                    bf16x4 u0 = s == 0 ? a0l : a0;
-                    bf16x4 u1 = s == 2 ? a1r : a1;
-                    if ((r == 0 && top) || (r == 2 && bottom)) {
-                        u0 = bf16x4{0, 0, 0, 0};
-                        u1 = bf16x4{0, 0, 0, 0};
-                    }
+                if constexpr (ALIGN != 0) {
+                    bf16x4 u0 = s == 0 ? a0l : (s == 2 ? a0r : a0);
+                    bf16x4 u1 = s == 0 ? a1l : (s == 2 ? a1r : a1);
+                    if ((r == 0 && top[0]) || (r == 2 && bottom[0])) u0 = bf16x4{0, 0, 0, 0};
+                    if ((r == 0 && top[1]) || (r == 2 && bottom[1])) u1 = bf16x4{0, 0, 0, 0};
                     af = __builtin_shufflevector(u0, u1, 0, 1, 2, 3, 4, 5, 6, 7);
                 } else {
                     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -255,7 +266,8 @@ int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s)
     const long long chunks = (M + 63) / 64;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 64;
     const unsigned blocks = (unsigned)((a.CP / 64) * (a.CQ / 64) * a.nsplit);
-    if (a.W % 8 == 0) hipLaunchKernelGGL(conv_wgrad_tr_k<true>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
-    else              hipLaunchKernelGGL(conv_wgrad_tr_k<false>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
+    if (a.W % 8 == 0)      hipLaunchKernelGGL(conv_wgrad_tr_k<8>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
+    else if (a.W % 4 == 0) hipLaunchKernelGGL(conv_wgrad_tr_k<4>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
+    else                   hipLaunchKernelGGL(conv_wgrad_tr_k<0>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("conv_wgrad_tr");
 }

@@ -282,12 +282,12 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     nc.enabled = d_.normalize;
     const float m3[3] = {0.485f, 0.456f, 0.406f}, s3[3] = {0.229f, 0.224f, 0.225f};
     for (int i = 0; i < 3; ++i) { nc.mean[i] = m3[i]; nc.stdv[i] = s3[i]; }
-    LBC_TRY(lbc_prep_input(image, W(xp_), N, Cin, H0, W0, nc, s));
+    LBC_TRY(lbc_prep_input(image, W(xp_), bf16_, N, Cin, H0, W0, nc, s));   // bf16 modes: the padded image is bf16 too
     if (act_bf16_) LBC_TRY(weight_prep(s));   // the caller's optimizer may have stepped: refresh the bf16 weight copies
 
     // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
     StemArgs st;
-    st.xp = W(xp_); st.w = P(stem_w_); st.y = W(y0_); st.stats = tr ? W(partial_) : nullptr;
+    st.xp = W(xp_); st.xp_bf16 = bf16_; st.w = P(stem_w_); st.y = W(y0_); st.stats = tr ? W(partial_) : nullptr;
     st.N = N; st.H = H0; st.W = W0; st.Cin = Cin; st.act_bf16 = act_bf16_; st.bf16 = bf16_;
     LBC_TRY(lbc_stem_fwd(st, s));
     LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), train, s));
@@ -652,7 +652,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
         ap.dx = W(g0_); ap.pixels = pix; ap.C = 64; ap.Cout = 64; ap.act_bf16 = act_bf16_;
         LBC_TRY(lbc_bn_bwd_apply(ap, s));
         StemWgradArgs sw;
-        sw.xp = W(xp_); sw.dy = W(g0_); sw.partial = W(wg_partial_);
+        sw.xp = W(xp_); sw.xp_bf16 = bf16_; sw.dy = W(g0_); sw.partial = W(wg_partial_);
         sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels; sw.act_bf16 = act_bf16_; sw.bf16 = bf16_;
         sw.nsplit = lbc_stem_wgrad_split(N, H0, W0);
         LBC_TRY(lbc_stem_wgrad(sw, s));

@@ -81,9 +81,10 @@ int lbc_concat_velocity(const void* t, const float* vel, void* h, int N, int hw,
 // prep: NCHW fp32 image -> (optionally ImageNet-normalised) NHWC fp32 with a 3-pixel
 // zero border: xp[N][H+6][W+6][C]
 struct NormConst { float mean[8]; float stdv[8]; int enabled; };
-int lbc_prep_input(const float* img_nchw, float* xp, int N, int C, int H, int W, const NormConst& nc, hipStream_t s);
+int lbc_prep_input(const float* img_nchw, void* xp, int xp_bf16, int N, int C, int H, int W, const NormConst& nc, hipStream_t s);
 struct StemArgs {
-    const float* xp;             // [N][H+6][W+6][Cin]
+    const void* xp;              // [N][H+6][W+6][Cin] zero-bordered image: f32, or bf16 (xp_bf16; the bf16 kernels)
+    int xp_bf16;
     const float* w;              // [64][7][7][Cin]
     void* y;                     // [N][H/2][W/2][64] f32 or bf16 (act_bf16)
     float* stats;                // [rows][2][64] or nullptr
@@ -94,7 +95,7 @@ struct StemArgs {
 int lbc_stem_rows(const StemArgs& a);
 int lbc_stem_fwd(const StemArgs& a, hipStream_t s);
 struct StemWgradArgs {
-    const float* xp; const void* dy; float* partial;   // partial [nsplit][64][7][7*Cin]; dy f32 or bf16
+    const void* xp; int xp_bf16; const void* dy; float* partial;   // partial [nsplit][64][7][7*Cin]; dy f32 or bf16
     int N, H, W, Cin, nsplit;
     int act_bf16;
     int bf16;                    // 1: bf16 MFMA operands (f32 accumulation)

@@ -17,7 +17,9 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void prep_input_k(const float* __restrict__ img, float* __restrict__ xp, int N, int C,
+// XT = element type of the padded image: float, or __bf16 in the bf16 modes (the stem rounds it to bf16 anyway)
+template <typename XT>
+__global__ __launch_bounds__(256) void prep_input_k(const float* __restrict__ img, XT* __restrict__ xp, int N, int C,
                                                     int H, int W, NormConst nc)
 {
     const long long total = (long long)N * H * W;
@@ -28,14 +30,20 @@ __global__ __launch_bounds__(256) void prep_input_k(const float* __restrict__ im
         const long long t = i / W;
         const int y = (int)(t % H);
         const int n = (int)(t / H);
-        float* dst = xp + ((size_t)(n * Hp + y + 3) * Wp + (size_t)(x + 3)) * C;
+        XT* dst = xp + ((size_t)(n * Hp + y + 3) * Wp + (size_t)(x + 3)) * C;
         for (int c = 0; c < C; ++c) {
             float v = img[((size_t)(n * C + c) * H + y) * W + x];
             if (nc.enabled) v = (v - nc.mean[c]) / nc.stdv[c];
-            dst[c] = v;
+            dst[c] = (XT)v;
         }
     }
 }
+
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+// two consecutive elements of the padded image (even offsets: 8- or 4-byte aligned)
+__device__ __forceinline__ f32x2_t load2(const float* p) { return *reinterpret_cast<const f32x2_t*>(p); }
+__device__ __forceinline__ f32x2_t load2(const __bf16* p) { return __builtin_convertvector(*reinterpret_cast<const bf16x2_t*>(p), f32x2_t); }
 
 template <int CIN, typename T>
 __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
@@ -82,7 +90,7 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
 #pragma unroll
         for (int q = 0; q < HALF / 2; ++q) {
             // unconditional load (rows past M read pixel 0); masking is deferred to store_chunk()
-            ra[q] = *reinterpret_cast<const float2*>(a.xp + (abase >= 0 ? abase : half * HALF) + (long long)(r * Wp * CIN + 2 * q));
+            ra[q] = *reinterpret_cast<const float2*>(static_cast<const float*>(a.xp) + (abase >= 0 ? abase : half * HALF) + (long long)(r * Wp * CIN + 2 * q));
         }
 #pragma unroll
         for (int q = 0; q < NB; ++q) {
@@ -162,9 +170,10 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
 // bf16-MFMA variant (precision >= 1): the same walk, operands rounded to bf16 when the chunk is written to LDS, k padded
 // to a multiple of 16 (32 or 64 columns per filter row; the pad columns are zeroed once and never written again),
 // v_mfma_f32_32x32x16_bf16 with f32 accumulation.  16x the MFMA rate turns the stem from MFMA-bound into staging-bound.
-template <int CIN, typename T>
+template <int CIN, typename T, typename XT>
 __global__ __launch_bounds__(256) void stem_fwd_bf16_k(StemArgs a)
 {
+    const XT* xpad = static_cast<const XT*>(a.xp);
     constexpr int L = 7 * CIN;
     constexpr int L8 = (L + 7) / 8 * 8;        // 24 or 56: what the staging covers (two threads per pixel row)
     constexpr int L16 = (L + 15) / 16 * 16;    // 32 or 64: what the MFMAs read
@@ -220,7 +229,7 @@ __global__ __launch_bounds__(256) void stem_fwd_bf16_k(StemArgs a)
         if (more) {
 #pragma unroll
             for (int q = 0; q < HALF / 2; ++q)
-                ra[q] = *reinterpret_cast<const f32x2*>(a.xp + abase + (long long)((r + 1) * Wp * CIN + 2 * q));   // 8-byte aligned: all offsets even
+                ra[q] = load2(xpad + abase + (long long)((r + 1) * Wp * CIN + 2 * q));   // all offsets even
 #pragma unroll
             for (int q = 0; q < NB; ++q) {
                 const int j = wcol[q] < L ? wcol[q] : 0;
@@ -343,7 +352,7 @@ __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_pe
         for (int q = 0; q < QPT; q += 2) {
             float2 v = make_float2(0.f, 0.f);
             const int j = qseg * QPT + q;
-            if (ok && j < L) v = *reinterpret_cast<const float2*>(a.xp + base + q);   // 8-byte aligned (all offsets even)
+            if (ok && j < L) v = *reinterpret_cast<const float2*>(static_cast<const float*>(a.xp) + base + q);   // 8-byte aligned (all offsets even)
             if (j + 1 >= L) v.y = 0.f;
             rq[q] = v.x; rq[q + 1] = v.y;
         }
@@ -404,9 +413,10 @@ __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_pe
 // bf16-MFMA weight gradient of the stem (precision >= 1): contraction over pixels on v_mfma_f32_32x32x16_bf16, both
 // operands transposed in registers into [channel][64 pixels] LDS tiles exactly like conv_wgrad_bf16_k (4 pixels x 4
 // channels per thread, 8-byte column writes, conflict-aware lane order).  grid (split, filter row r).
-template <int CIN, typename T>
+template <int CIN, typename T, typename XT>
 __global__ __launch_bounds__(256) void stem_wgrad_bf16_k(StemWgradArgs a, int rows_per_split)
 {
+    const XT* xpad = static_cast<const XT*>(a.xp);
     constexpr bool ABF = Act<T>::kBf16;
     using preg_t = typename std::conditional<ABF, bf16x4, f32x4>::type;
     typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -471,8 +481,8 @@ __global__ __launch_bounds__(256) void stem_wgrad_bf16_k(StemWgradArgs a, int ro
                 const int m = mc + 4 * qpg + i;
                 qok[i] = (m < mend) && qactive;
                 const long long base = qok[i] ? (long long)((n * Hp + 2 * y + r) * Wp + 2 * x) * CIN + qcg * 4 : 0;
-                rq[i][0] = *reinterpret_cast<const f32x2*>(a.xp + base);        // 8-byte aligned: every offset is even
-                rq[i][1] = *reinterpret_cast<const f32x2*>(a.xp + base + 2);
+                rq[i][0] = load2(xpad + base);        // every offset is even
+                rq[i][1] = load2(xpad + base + 2);
                 if (++x >= OW) { x = 0; if (++y >= OH) { y = 0; ++n; } }
             }
             qx += BRH;
@@ -538,16 +548,17 @@ __global__ __launch_bounds__(256) void stem_wgrad_bf16_k(StemWgradArgs a, int ro
 
 }  // namespace
 
-int lbc_prep_input(const float* img_nchw, float* xp, int N, int C, int H, int W, const NormConst& nc, hipStream_t s)
+int lbc_prep_input(const float* img_nchw, void* xp, int xp_bf16, int N, int C, int H, int W, const NormConst& nc, hipStream_t s)
 {
     LBC_REQUIRE(C <= 8, "prep_input: at most 8 channels");
-    const size_t bytes = (size_t)N * (H + 6) * (W + 6) * C * sizeof(float);
+    const size_t bytes = (size_t)N * (H + 6) * (W + 6) * C * (xp_bf16 ? 2 : 4);
     if (hipMemsetAsync(xp, 0, bytes, s) != hipSuccess) { lbc_set_error("prep_input: memset failed"); return LBC_ELAUNCH; }
     const long long total = (long long)N * H * W;
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    LbcProfScope prof("prep_input", 0.0, 4.0 * (2.0 * total * C + (double)N * (H + 6) * (W + 6) * C), s);
-    hipLaunchKernelGGL(prep_input_k, dim3((unsigned)blocks), dim3(256), 0, s, img_nchw, xp, N, C, H, W, nc);
+    LbcProfScope prof("prep_input", 0.0, 4.0 * total * C + (xp_bf16 ? 2.0 : 4.0) * (total * C + (double)N * (H + 6) * (W + 6) * C), s);
+    if (xp_bf16) hipLaunchKernelGGL(prep_input_k<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, img_nchw, static_cast<__bf16*>(xp), N, C, H, W, nc);
+    else         hipLaunchKernelGGL(prep_input_k<float>, dim3((unsigned)blocks), dim3(256), 0, s, img_nchw, static_cast<float*>(xp), N, C, H, W, nc);
     return lbc_check_launch("prep_input");
 }
 
@@ -560,10 +571,11 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
     LBC_REQUIRE((long long)a.N * (a.H + 6) * (a.W + 6) * a.Cin < (1ll << 31), "stem: input too large");
     const dim3 grid((unsigned)lbc_stem_rows(a));
     const double Ms = (double)a.N * (a.H / 2) * (a.W / 2);
-    LbcProfScope prof("stem_fwd", 2.0 * Ms * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + Ms * 64), s);
+    LbcProfScope prof("stem_fwd", 2.0 * Ms * 64 * 49 * a.Cin, (a.xp_bf16 ? 2.0 : 4.0) * (double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (a.act_bf16 ? 2.0 : 4.0) * Ms * 64, s);
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem: bf16 output needs bf16 = 1");
     if (a.bf16) {
-#define LBC_K(T, CI) hipLaunchKernelGGL((stem_fwd_bf16_k<CI, T>), grid, dim3(256), 0, s, a)
+        LBC_REQUIRE(a.xp_bf16, "stem: the bf16 kernels read a bf16 padded image");
+#define LBC_K(T, CI) hipLaunchKernelGGL((stem_fwd_bf16_k<CI, T, __bf16>), grid, dim3(256), 0, s, a)
         if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
         else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
 #undef LBC_K
@@ -594,7 +606,8 @@ int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s)
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem_wgrad: bf16 gradients need bf16 = 1");
     LbcProfScope prof("stem_wgrad", 2.0 * M * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (double)M * 64), s);
     if (a.bf16) {
-#define LBC_K(T, CI) hipLaunchKernelGGL((stem_wgrad_bf16_k<CI, T>), grid, dim3(256), 0, s, a, rows_per_split)
+        LBC_REQUIRE(a.xp_bf16, "stem_wgrad: the bf16 kernels read a bf16 padded image");
+#define LBC_K(T, CI) hipLaunchKernelGGL((stem_wgrad_bf16_k<CI, T, __bf16>), grid, dim3(256), 0, s, a, rows_per_split)
         if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
         else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
 #undef LBC_K
