@@ -64,4 +64,7 @@ def broadcast_module(module, src=0, group=None):
     if not dist.is_initialized() or dist.get_world_size(group) == 1:
         return
     for t in list(module.parameters()) + list(module.buffers()):
-        dist.broadcast(t.data, src, group=group)
+        d = t.data
+        if d.dim() == 4 and not d.is_contiguous() and d.is_contiguous(memory_format=torch.channels_last):
+            d = d.permute(0, 2, 3, 1)       # the channels_last weights as the plain-contiguous view of the same memory
+        dist.broadcast(d, src, group=group)

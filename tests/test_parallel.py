@@ -59,7 +59,15 @@ def _reduce_worker(rank, world, port, q):
     for st in range(6):
         red.launch(st)
     red.wait()
-    q.put((rank, mine[::100003].clone(), flat[::100003].clone()))
+    # initial weights: rank 0's values everywhere, including the channels_last 4-D tensors
+    from learningbycheating_amd.parallel import broadcast_module
+    from learningbycheating_amd.bird_view.models import BirdViewPolicyModelSS
+    torch.manual_seed(7 + rank)
+    net = BirdViewPolicyModelSS("resnet18")
+    broadcast_module(net)
+    w = net.conv.layer2[0].conv1.weight.data
+    assert not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last)
+    q.put((rank, mine[::100003].clone(), flat[::100003].clone(), w.clone(), net.deconv[1].bias.data.clone()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -77,6 +85,7 @@ def test_staged_allreduce_gloo_world2():
         assert p.exitcode == 0
     want = res[0][1] + res[1][1]
     assert torch.allclose(res[0][2], want) and torch.allclose(res[1][2], want)
+    assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])      # broadcast_module
 
 
 def _dp_worker(rank, world, port, q):
