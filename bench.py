@@ -31,13 +31,18 @@ PEAK_BF16_MFMA_TFLOPS = 2500.0      # dense bf16 MFMA (same table)
 PEAK_HBM_GBS = 8000.0
 
 
-def synthetic_batch(n, device, seed):
+def synthetic_batch(n, device, seed, uint8_frames=False):
+    """frames as the reference's LMDB dataset holds them (uint8 HWC; bird-view 7 binary channels stored as 0/255) and, by
+    default, decoded the way its loader hands them to the model (float32 CHW in [0,1]); uint8_frames keeps them uint8 NHWC
+    for the executor's fused input pass (lbc_net_forward_u8)"""
     g = torch.Generator(device="cpu").manual_seed(seed)
     rgb = torch.randint(0, 256, (n, 160, 384, 3), generator=g, dtype=torch.uint8)
-    bv = (torch.rand((n, 7, 192, 192), generator=g) < 0.1).float()
+    bv = ((torch.rand((n, 192, 192, 7), generator=g) < 0.1).to(torch.uint8) * 255)
     speed = torch.rand(n, generator=g) * 10
     cmd = torch.randint(1, 5, (n,), generator=g).float()
-    rgb = (rgb.permute(0, 3, 1, 2).float() / 255.0).contiguous()
+    if not uint8_frames:
+        rgb = (rgb.permute(0, 3, 1, 2).float() / 255.0).contiguous()
+        bv = (bv.permute(0, 3, 1, 2).float() / 255.0).contiguous()
     return rgb.to(device), bv.to(device), speed.to(device), cmd
 
 
@@ -91,6 +96,8 @@ def main():
                     help="f32: exact-f32 MFMA everywhere (the parity path). bf16: mixed precision of BASELINE.json config 3 -- bf16 MFMA "
                          "operands and bf16 activation storage, f32 accumulation / master weights / gradients / BatchNorm / soft-argmax / "
                          "loss / Adam. bf16_mfma: bf16 MFMA operands only, every tensor f32")
+    ap.add_argument("--float-input", action="store_true",
+                    help="feed float32 NCHW frames (the reference loader's output) instead of the dataset's uint8 NHWC frames")
     ap.add_argument("--init-steps", type=int, default=40, help="below-horizon warm start (stands in for the phase-0 checkpoint)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short exact-f32 run reported under 'also'")
@@ -118,7 +125,7 @@ def main():
 
     per_gpu = args.global_batch // world
     assert per_gpu * world == args.global_batch, "global batch must divide by the number of GPUs"
-    rgb, bv, speed, cmd = synthetic_batch(per_gpu, device, 1000 + rank)
+    rgb, bv, speed, cmd = synthetic_batch(per_gpu, device, 1000 + rank, uint8_frames=not args.float_input)
     from learningbycheating_amd.bird_view.utils.train_utils import one_hot
     onehot = one_hot(cmd).to(device)
     # Warm start below the horizon: the phase-1 unprojection has a 1/y pole at the horizon and the reference always
@@ -198,8 +205,8 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                "config": {"workload": "ImagePolicyModelSS(resnet34) phase-1 step vs BirdViewPolicyModelSS(resnet18) teacher, "
-                                      "160x384 RGB + 7x192x192 bird-view, global batch %d (%d/GPU), %s, local BatchNorm, "
-                                      "Adam lr 1e-4" % (args.global_batch, per_gpu, {"bf16_mfma": "bf16 MFMA operands + f32 tensors/accumulate/master/BN/loss/Adam", "bf16": "bf16 MFMA operands and bf16 activation storage + f32 accumulate/master weights/gradients/BN/loss/Adam", "f32": "exact-f32 MFMA"}[args.dtype]),
+                                      "160x384 RGB + 7x192x192 bird-view (%s, resident in HBM), global batch %d (%d/GPU), %s, local BatchNorm, "
+                                      "Adam lr 1e-4" % ("float32 NCHW frames" if args.float_input else "uint8 NHWC frames as the dataset stores them", args.global_batch, per_gpu, {"bf16_mfma": "bf16 MFMA operands + f32 tensors/accumulate/master/BN/loss/Adam", "bf16": "bf16 MFMA operands and bf16 activation storage + f32 accumulate/master weights/gradients/BN/loss/Adam", "f32": "exact-f32 MFMA"}[args.dtype]),
                           "global_batch": args.global_batch, "parallelism": "dp%d" % world},
                "loss": loss_mean, "loss_finite": bool(loss_mean == loss_mean and abs(loss_mean) != float("inf")),
                "algorithmic_tflops": round(value * FLOP_PER_IMAGE_STEP / 1e12, 2),

@@ -112,6 +112,11 @@ int lbc_net_bind(lbc_net* net, void* workspace, void* const* tensor_ptrs, float*
  * running-stat update, activations kept for backward. */
 int lbc_net_forward(lbc_net* net, int N, int train, const float* image, const float* velocity,
                     const float* command, float* pred_sel, float* pred_all, lbc_stream_t stream);
+/* Same with the frames as the dataset stores them: uint8 NHWC [N,H,W,C], 0..255 (reference
+ * bird_view/utils/datasets/image_lmdb.py:128-222 converts them to f32 CHW /255 on the host: 4x the H2D and input bytes).
+ * /255, the ImageNet normalisation and the NHWC repack are fused into the stem's input pass. */
+int lbc_net_forward_u8(lbc_net* net, int N, int train, const unsigned char* image_nhwc, const float* velocity,
+                       const float* command, float* pred_sel, float* pred_all, lbc_stream_t stream);
 /* Backward of the last training-mode forward: gradients of a scalar wrt pred_sel / pred_all
  * (either may be NULL) -> every bound parameter gradient (overwritten, not accumulated).
  * stage = -1 runs everything; stages 0..lbc_net_num_stages()-1 run in order (head+decoder,

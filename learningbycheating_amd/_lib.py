@@ -50,6 +50,7 @@ _SIGNATURES = {
     "lbc_net_workspace_bytes": (c_size_t, [c_void_p]),
     "lbc_net_bind": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
     "lbc_net_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),
+    "lbc_net_forward_u8": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),
     "lbc_net_num_stages": (c_int, []),
     "lbc_net_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lbc_loss": (c_int, [c_int, ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),

@@ -261,7 +261,7 @@ int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStre
     return lbc_bn_finalize(f, s);
 }
 
-int Net::forward(int N, int train, const float* image, const float* velocity, const float* command, float* pred_sel,
+int Net::forward(int N, int train, const void* image, int image_u8, const float* velocity, const float* command, float* pred_sel,
                  float* pred_all, hipStream_t s)
 {
     LBC_REQUIRE(N >= 1 && N <= d_.max_batch, "net.forward: batch %d outside [1,%d]", N, d_.max_batch);
@@ -282,7 +282,9 @@ int Net::forward(int N, int train, const float* image, const float* velocity, co
     nc.enabled = d_.normalize;
     const float m3[3] = {0.485f, 0.456f, 0.406f}, s3[3] = {0.229f, 0.224f, 0.225f};
     for (int i = 0; i < 3; ++i) { nc.mean[i] = m3[i]; nc.stdv[i] = s3[i]; }
-    LBC_TRY(lbc_prep_input(image, W(xp_), bf16_, N, Cin, H0, W0, nc, s));   // bf16 modes: the padded image is bf16 too
+    // bf16 modes: the padded image is bf16 too
+    if (image_u8) LBC_TRY(lbc_prep_input_u8(static_cast<const unsigned char*>(image), W(xp_), bf16_, N, Cin, H0, W0, nc, s));
+    else          LBC_TRY(lbc_prep_input(static_cast<const float*>(image), W(xp_), bf16_, N, Cin, H0, W0, nc, s));
     if (act_bf16_) LBC_TRY(weight_prep(s));   // the caller's optimizer may have stepped: refresh the bf16 weight copies
 
     // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
@@ -714,7 +716,13 @@ int lbc_net_forward(lbc_net* net, int N, int train, const float* image, const fl
                     float* pred_sel, float* pred_all, lbc_stream_t stream)
 {
     LBC_REQUIRE(net, "net_forward: null net");
-    return net->impl.forward(N, train, image, velocity, command, pred_sel, pred_all, (hipStream_t)stream);
+    return net->impl.forward(N, train, image, 0, velocity, command, pred_sel, pred_all, (hipStream_t)stream);
+}
+int lbc_net_forward_u8(lbc_net* net, int N, int train, const unsigned char* image_nhwc, const float* velocity, const float* command,
+                       float* pred_sel, float* pred_all, lbc_stream_t stream)
+{
+    LBC_REQUIRE(net, "net_forward_u8: null net");
+    return net->impl.forward(N, train, image_nhwc, 1, velocity, command, pred_sel, pred_all, (hipStream_t)stream);
 }
 int lbc_net_num_stages(void) { return lbc::Net::kNumStages; }
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream)

@@ -67,7 +67,8 @@ public:
     void set_workspace(void* p) { ws_ = static_cast<float*>(p); }
     int check_bound(bool need_grads) const;
 
-    int forward(int N, int train, const float* image_nchw, const float* velocity, const float* command, float* pred_sel,
+    // image: f32 NCHW in [0,1] (the reference signature) or, with image_u8, uint8 NHWC frames (0..255)
+    int forward(int N, int train, const void* image, int image_u8, const float* velocity, const float* command, float* pred_sel,
                 float* pred_all, hipStream_t s);
     // stage: -1 = everything; otherwise 0 = head+decoder, 1..4 = layer4..layer1, 5 = stem (call in order)
     int backward(const float* d_sel, const float* d_all, int stage, hipStream_t s);

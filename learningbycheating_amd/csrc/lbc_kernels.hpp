@@ -82,6 +82,7 @@ int lbc_concat_velocity(const void* t, const float* vel, void* h, int N, int hw,
 // zero border: xp[N][H+6][W+6][C]
 struct NormConst { float mean[8]; float stdv[8]; int enabled; };
 int lbc_prep_input(const float* img_nchw, void* xp, int xp_bf16, int N, int C, int H, int W, const NormConst& nc, hipStream_t s);
+int lbc_prep_input_u8(const unsigned char* img_nhwc, void* xp, int xp_bf16, int N, int C, int H, int W, const NormConst& nc, hipStream_t s);
 struct StemArgs {
     const void* xp;              // [N][H+6][W+6][Cin] zero-bordered image: f32, or bf16 (xp_bf16; the bf16 kernels)
     int xp_bf16;

@@ -91,11 +91,18 @@ class PolicyEngine:
 
     # ---- execution --------------------------------------------------------------------
     def forward(self, image, velocity, command, train):
+        """image: float32 (N,C,H,W) in [0,1] (the reference signature) or uint8 (N,H,W,C) frames as the dataset stores them"""
         n = image.shape[0]
         pred_sel = torch.empty((n, 5, 2), dtype=torch.float32, device=image.device)
         pred_all = torch.empty((n, 4, 5, 2), dtype=torch.float32, device=image.device)
-        _lib.check(_lib.get().lbc_net_forward(self.handle, n, int(train), _lib.ptr(image), _lib.ptr(velocity), _lib.ptr(command),
-                                              _lib.ptr(pred_sel), _lib.ptr(pred_all), _lib.stream_for(image)), "net_forward")
+        if image.dtype == torch.uint8:
+            if image.dim() != 4 or not image.is_contiguous():
+                raise RuntimeError("engine.forward: uint8 frames must be a contiguous (N,H,W,C) tensor")
+            fn = _lib.get().lbc_net_forward_u8
+        else:
+            fn = _lib.get().lbc_net_forward
+        _lib.check(fn(self.handle, n, int(train), _lib.ptr(image), _lib.ptr(velocity), _lib.ptr(command),
+                      _lib.ptr(pred_sel), _lib.ptr(pred_all), _lib.stream_for(image)), "net_forward")
         return pred_sel, pred_all
 
     def backward(self, d_sel, d_all, stage=-1):

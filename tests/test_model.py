@@ -444,3 +444,21 @@ def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, mon
         ps2, pa2 = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), train)
         monkeypatch.delenv("LBC_HEAD_NO_MFMA")
         assert (pa1 - pa2).abs().max().item() < 2e-5 and (ps1 - ps2).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), ("birdview", "resnet18", 64, 64, 2),
+                                                 pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])
+def test_uint8_nhwc_frames_equal_float_nchw_input(env, kind, backbone, h, w, n):
+    """lbc_net_forward_u8: the dataset's uint8 NHWC frames give exactly the reference path's float (x/255, NCHW) result"""
+    dev, _ = env
+    sd = O.make_state_dict(kind, backbone, 10, h, w)
+    c = 3 if kind == "image" else 7
+    g = torch.Generator().manual_seed(11)
+    u8 = torch.randint(0, 256, (n, h, w, c), generator=g, dtype=torch.uint8)
+    xf = (u8.float() / 255.0).permute(0, 3, 1, 2).contiguous()
+    speed = torch.rand(n, generator=g) * 10
+    cmd = torch.eye(4)[torch.randint(0, 4, (n,), generator=g)]
+    eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=0)
+    ps1, pa1 = eng.forward(xf.to(dev), speed.to(dev), cmd.to(dev), False)
+    ps2, pa2 = eng.forward(u8.to(dev), speed.to(dev), cmd.to(dev), False)
+    assert torch.equal(pa1, pa2) and torch.equal(ps1, ps2)
