@@ -103,6 +103,23 @@ __global__ __launch_bounds__(1024) void bn_finalize_k(BnFinalizeArgs a)
     a.shift[c] = b - mean * sc;
 }
 
+// ---- eval mode: every BatchNorm of the network in one launch (blockIdx.x = BatchNorm, threads stride channels) ----------
+__global__ __launch_bounds__(256) void bn_eval_prep_k(BnEvalArgs a)
+{
+    const BnEvalItem& it = a.item[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += 256) {
+        const float mean = it.running_mean[c];
+        const float invstd = 1.0f / sqrtf(it.running_var[c] + a.eps);     // same expression as bn_finalize_k's eval branch
+        const float g = it.gamma ? it.gamma[c] : 1.f;
+        const float b = it.beta ? it.beta[c] : 0.f;
+        const float sc = g * invstd;
+        it.scale[c] = sc;
+        it.shift[c] = b - mean * sc;
+        it.mean[c] = mean;
+        it.invstd[c] = invstd;
+    }
+}
+
 // ---- elementwise apply: y = relu?(x*s + t (+ r [* rs + rt])) ------------------
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
@@ -305,6 +322,14 @@ int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s)
     LbcProfScope prof("bn_finalize", 0.0, 4.0 * (double)a.rows * 2 * a.C, s);
     hipLaunchKernelGGL(bn_finalize_k, dim3((unsigned)lbc_cdiv(a.C, kFinCh)), dim3(1024), 0, s, a);
     return lbc_check_launch("bn_finalize");
+}
+
+int lbc_bn_eval_prep(const BnEvalArgs& a, hipStream_t s)
+{
+    LBC_REQUIRE(a.count >= 1 && a.count <= BnEvalArgs::kMax, "bn_eval_prep: bad table");
+    LbcProfScope prof("bn_eval_prep", 0.0, 0.0, s);
+    hipLaunchKernelGGL(bn_eval_prep_k, dim3((unsigned)a.count), dim3(256), 0, s, a);
+    return lbc_check_launch("bn_eval_prep");
 }
 
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)

@@ -156,6 +156,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_k(IgemmArgs a)
                 if (m < M) {
                     const unsigned o = (unsigned)m * (unsigned)BN + (unsigned)col;
                     float v = acc[mi][e];
+                    if (a.post_scale) v = v * a.post_scale[col] + a.post_shift[col];
                     if (a.bias) v += a.bias[col];
                     if (resid) v += rv[k];
                     if (a.relu) v = fmaxf(v, 0.f);

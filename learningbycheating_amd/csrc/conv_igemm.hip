@@ -330,6 +330,7 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a
                 for (int nj = 0; nj < NT; ++nj) {
                     const int col = n0 + (wn * NT + nj) * 32 + l31;
                     float v = acc[mi][nj][r];
+                    if (a.post_scale) v = v * a.post_scale[col] + a.post_shift[col];
                     if (a.bias) v += a.bias[col];
                     if (a.resid) v += rv[r][nj];
                     if (a.relu) v = fmaxf(v, 0.f);

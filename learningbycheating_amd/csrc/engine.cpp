@@ -199,12 +199,15 @@ int Net::check_bound(bool need_grads) const
 }
 
 // ---------------------------------------------------------------------------------------
-int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre)
+int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre, const BN* post,
+                  const float* resid, bool relu, float* out)
 {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
-    a.x = x; a.w = P(c.w); a.y = W(c.y);
+    a.x = x; a.w = P(c.w); a.y = out ? out : W(c.y);
     if (pre) { a.pre_scale = W(pre->scale); a.pre_shift = W(pre->shift); a.pre_relu = 1; }
+    if (post) { a.post_scale = W(post->scale); a.post_shift = W(post->shift); }
+    a.resid = resid; a.relu = relu ? 1 : 0;
     a.N = N; a.H = c.H; a.W = c.W; a.C = c.Cin;
     a.OH = c.OH; a.OW = c.OW; a.K = c.Cout;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
@@ -239,6 +242,29 @@ int Net::weight_prep(hipStream_t s)
     LBC_REQUIRE(ok, "net: more than %d convolution weights", WeightPrepArgs::kMax);
     a.count = n; a.tiles = tiles;
     return lbc_weight_prep(a, s);
+}
+
+// eval mode: scale / shift / mean / invstd of all BatchNorms from the running statistics, one launch
+int Net::bn_eval_prep(hipStream_t s)
+{
+    BnEvalArgs a;
+    memset(&a, 0, sizeof(a));
+    int n = 0;
+    bool ok = true;
+    auto add = [&](const BN& bn) {
+        if (n >= BnEvalArgs::kMax) { ok = false; return; }
+        BnEvalItem& it = a.item[n++];
+        it.gamma = P(bn.g); it.beta = P(bn.b); it.running_mean = P(bn.rm); it.running_var = P(bn.rv);
+        it.scale = W(bn.scale); it.shift = W(bn.shift); it.mean = W(bn.mean); it.invstd = W(bn.invstd);
+        it.C = bn.C;
+    };
+    add(stem_bn_);
+    for (const Block& b : blocks_) { add(b.b1); add(b.b2); if (b.has_ds) add(b.bd); }
+    for (int i = 0; i < 3; ++i) add(dec_[i].bn);
+    for (int b = 0; b < 4; ++b) add(head_bn_[b]);
+    LBC_REQUIRE(ok, "net: more than %d BatchNorms", BnEvalArgs::kMax);
+    a.count = n; a.eps = kBnEps;
+    return lbc_bn_eval_prep(a, s);
 }
 
 int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running)
@@ -286,13 +312,14 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
     if (image_u8) LBC_TRY(lbc_prep_input_u8(static_cast<const unsigned char*>(image), W(xp_), bf16_, N, Cin, H0, W0, nc, s));
     else          LBC_TRY(lbc_prep_input(static_cast<const float*>(image), W(xp_), bf16_, N, Cin, H0, W0, nc, s));
     if (act_bf16_) LBC_TRY(weight_prep(s));   // the caller's optimizer may have stepped: refresh the bf16 weight copies
+    if (!tr) LBC_TRY(bn_eval_prep(s));        // eval: every BatchNorm's affine from its running statistics, one launch
 
     // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
     StemArgs st;
     st.xp = W(xp_); st.xp_bf16 = bf16_; st.w = P(stem_w_); st.y = W(y0_); st.stats = tr ? W(partial_) : nullptr;
     st.N = N; st.H = H0; st.W = W0; st.Cin = Cin; st.act_bf16 = act_bf16_; st.bf16 = bf16_;
     LBC_TRY(lbc_stem_fwd(st, s));
-    LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), train, s));
+    if (tr) LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), train, s));
     PoolFwdArgs pf;
     pf.y = W(y0_); pf.scale = W(stem_bn_.scale); pf.shift = W(stem_bn_.shift); pf.p = W(p0_);
     pf.idx = reinterpret_cast<unsigned char*>(W(idx_));
@@ -303,6 +330,19 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
     const float* x = W(p0_);
     for (Block& b : blocks_) {
         const long long pix = (long long)N * b.c1.OH * b.c1.OW;
+        if (!tr) {
+            // eval: BatchNorms folded into the convolution epilogues -- conv1 writes z1 = relu(bn1(.)), the downsample
+            // writes bn_d(.), conv2 writes relu(bn2(.) + identity) straight into the block output: no BatchNorm pass at all
+            LBC_TRY(conv_fwd(b.c1, x, N, false, &rows, s, nullptr, &b.b1, nullptr, true));
+            const float* identity = x;
+            if (b.has_ds) {
+                LBC_TRY(conv_fwd(b.ds, x, N, false, &rows, s, nullptr, &b.bd, nullptr, false));
+                identity = W(b.ds.y);
+            }
+            LBC_TRY(conv_fwd(b.c2, W(b.c1.y), N, false, &rows, s, nullptr, &b.b2, identity, true, W(b.out)));
+            x = W(b.out);
+            continue;
+        }
         LBC_TRY(conv_fwd(b.c1, x, N, tr, &rows, s));
         LBC_TRY(bn_finalize(b.b1, rows, pix, train, s));
         BnApplyArgs ap;
@@ -341,7 +381,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         LBC_TRY(lbc_chan_reduce(cr, 0, s));
         rows = lbc_chan_reduce_rows(cr.pixels, 640);
     }
-    LBC_TRY(bn_finalize(dec_[0].bn, rows, (long long)N * th * tw, train, s));
+    if (tr) LBC_TRY(bn_finalize(dec_[0].bn, rows, (long long)N * th * tw, train, s));
     const float* din = W(hcat_);
     for (int i = 0; i < 3; ++i) {
         Deconv& D = dec_[i];
@@ -371,7 +411,9 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
         }
         const long long opix = (long long)N * 4 * D.H * D.W;
-        if (i < 2) {
+        if (!tr) {
+            // eval: statistics come from bn_eval_prep
+        } else if (i < 2) {
             LBC_TRY(bn_finalize(dec_[i + 1].bn, 4 * per, opix, train, s));
         } else {
             // image.py:54-60: the four branch BatchNorms see the same tensor -> same batch statistics

@@ -84,7 +84,11 @@ private:
     float* P(int ti) const { return static_cast<float*>(t_[ti].ptr); }
     float* G(int ti) const { return t_[ti].grad; }
 
-    int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre = nullptr);
+    // pre: BatchNorm(+ReLU) of the producer applied on load.  Eval mode folds the consumer-side BatchNorm into the epilogue:
+    // y = relu?(conv * post.scale + post.shift + resid), written to `out` (default: the layer's raw-output buffer).
+    int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre = nullptr,
+                 const BN* post = nullptr, const float* resid = nullptr, bool relu = false, float* out = nullptr);
+    int bn_eval_prep(hipStream_t s);
     int conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s);
     bool dgrad_wt_ = false;  // optional: input-gradient GEMMs read a per-step transposed copy of the weights (measured: no gain)
     size_t wt_ = 0;

@@ -58,6 +58,8 @@ struct IgemmArgs {
     const void* x;        // gathered tensor, NHWC [N][H][W][C]; f32, or bf16 when act_bf16
     const void* w;        // weights: f32, or bf16 when w_bf16 (needs bf16 = 1; see lbc_weight_prep)
     void* y;              // NHWC [N][OH][OW][K]; same element type as x
+    const float* post_scale;   // [K] or nullptr: per-output-channel affine applied to the accumulator first (eval-mode
+    const float* post_shift;   //   BatchNorm folded into the producing convolution): v = acc * post_scale + post_shift
     const float* bias;    // [K] or nullptr
     const void* resid;    // like y (may alias y) or nullptr; added before relu
     float* stats;         // [rows][2][K] per-block (sum, sum of squares) of the stored value, or nullptr

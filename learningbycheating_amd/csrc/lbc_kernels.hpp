@@ -22,6 +22,19 @@ struct BnFinalizeArgs {
     float* save_mean;            // out (nullable)
     float* save_invstd;
 };
+// Eval mode: scale / shift / mean / invstd of every BatchNorm of a network from its running statistics, one launch.
+struct BnEvalItem {
+    const float* gamma; const float* beta; const float* running_mean; const float* running_var;
+    float* scale; float* shift; float* mean; float* invstd;
+    int C;
+};
+struct BnEvalArgs {
+    static const int kMax = 48;
+    BnEvalItem item[kMax];
+    int count;
+    float eps;
+};
+int lbc_bn_eval_prep(const BnEvalArgs& a, hipStream_t s);
 int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s);
 int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 
