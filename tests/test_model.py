@@ -462,3 +462,27 @@ def test_uint8_nhwc_frames_equal_float_nchw_input(env, kind, backbone, h, w, n):
     ps1, pa1 = eng.forward(xf.to(dev), speed.to(dev), cmd.to(dev), False)
     ps2, pa2 = eng.forward(u8.to(dev), speed.to(dev), cmd.to(dev), False)
     assert torch.equal(pa1, pa2) and torch.equal(ps1, ps2)
+
+
+@gpu
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_training_scripts_chain_phase0_to_phase1(env, tmp_path, precision):
+    """the reference's workflow with its flag names: phase-0 script -> model-1.th -> phase-1 script --ckpt; config.json and
+    .th files in the reference's layout (strict load into the oracle's key/shape table)"""
+    import json
+    from learningbycheating_amd.training import train_image_phase0, train_image_phase1
+    d0, d1 = tmp_path / "p0", tmp_path / "p1"
+    common = ["--synthetic", "16", "--batch_size", "4", "--iters_per_epoch", "3", "--max_epoch", "1", "--log_iterations", "1",
+              "--precision", precision]
+    # more, larger phase-0 steps than phase-1: phase 1's unprojection has a 1/y pole at the horizon, the reference always starts it
+    # from a phase-0 checkpoint whose waypoints are below the horizon
+    train_image_phase0.main(["--log_dir", str(d0), "--lr", "1e-3"] + [("12" if c == "3" else c) for c in common])
+    ck = d0 / "model-1.th"
+    assert ck.exists() and (d0 / "config.json").exists()
+    train_image_phase1.main(["--log_dir", str(d1), "--ckpt", str(ck)] + common)
+    cfg = json.loads((d1 / "config.json").read_text())
+    assert cfg["model_args"]["backbone"] == "resnet34" and cfg["phase0_ckpt"] == str(ck)
+    sd = torch.load(str(d1 / "model-1.th"), map_location="cpu")
+    layout = O.state_dict_layout("image", "resnet34")
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(shape)) for k, shape in layout]
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
