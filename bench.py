@@ -96,6 +96,9 @@ def main():
                     help="f32: exact-f32 MFMA everywhere (the parity path). bf16: mixed precision of BASELINE.json config 3 -- bf16 MFMA "
                          "operands and bf16 activation storage, f32 accumulation / master weights / gradients / BatchNorm / soft-argmax / "
                          "loss / Adam. bf16_mfma: bf16 MFMA operands only, every tensor f32")
+    ap.add_argument("--dist-backend", default="nccl",
+                    help="nccl (= RCCL over xGMI, one rank per GPU); gloo lets two ranks share one GPU to exercise the N > 1 code path "
+                         "on a single-GPU box (scripts/gpu_round.sh phase dp2) -- its numbers mean nothing")
     ap.add_argument("--float-input", action="store_true",
                     help="feed float32 NCHW frames (the reference loader's output) instead of the dataset's uint8 NHWC frames")
     ap.add_argument("--init-steps", type=int, default=40, help="below-horizon warm start (stands in for the phase-0 checkpoint)")
@@ -112,11 +115,12 @@ def main():
             raise SystemExit("launch multi-GPU runs with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..." % (args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm GPU (the HIP path has no CPU fallback)")
+    local = local % torch.cuda.device_count()      # (several ranks may share a device only in the gloo self-test below)
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(args.dist_backend, rank=rank, world_size=world)
 
     from learningbycheating_amd import _lib
     from learningbycheating_amd.parallel import broadcast_module
@@ -168,15 +172,20 @@ def main():
     tr, dt, loss_mean = timed_run(args.dtype, args.steps, args.warmup)
 
     # ---- one extra instrumented step: HIP events around every kernel launch -------------------------
+    # Every rank runs the step (it contains the gradient all-reduce: a rank-0-only step would deadlock N > 1); only rank 0
+    # switches the per-launch HIP events on and reports.
     roof, breakdown = None, None
+    import ctypes
+    lib = _lib.get()
+    lib.lbc_profile_enable.restype = ctypes.c_int
+    lib.lbc_profile_report.restype = ctypes.c_int
     if rank == 0:
-        import ctypes
-        lib = _lib.get()
-        lib.lbc_profile_enable.restype = ctypes.c_int
-        lib.lbc_profile_report.restype = ctypes.c_int
         lib.lbc_profile_enable(1)
-        tr.step(rgb, speed, onehot, birdview=bv)
-        torch.cuda.synchronize()
+    tr.step(rgb, speed, onehot, birdview=bv)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    if rank == 0:
         lib.lbc_profile_enable(0)
         buf = ctypes.create_string_buffer(1 << 16)
         nbytes = lib.lbc_profile_report(buf, len(buf))
@@ -224,7 +233,7 @@ def main():
     if rank == 0:
         out.pop("_alt")
         out["also"] = also
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 must not keep the other ranks waiting)
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

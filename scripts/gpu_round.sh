@@ -62,6 +62,15 @@ if [[ "$PHASES" == *prof* ]]; then
   # keep the (large) raw trace out of the merge budget
   find gpurun_out/prof -name "*kernel_trace*" -size +20M -delete
 fi
+if [[ "$PHASES" == *dp2* ]]; then
+  # the N > 1 code path of bench.py on ONE GPU: two ranks, gloo backend (rendezvous, broadcast, staged all-reduce, barriers,
+  # max-over-ranks timing, rank-0 report); checks that it completes and prints one JSON line -- not a performance number
+  HSA_ENABLE_IPC_MODE_LEGACY=0 timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
+      bench.py --gpus 2 --steps 3 --warmup 1 --init-steps 2 --global-batch 16 --dist-backend gloo --no-cpu-baseline > gpurun_out/bench_dp2_gloo.log 2>&1
+  echo "dp2 (gloo, shared GPU) exit $?" >> gpurun_out/summary.txt
+  grep -c '"metric"' gpurun_out/bench_dp2_gloo.log >> gpurun_out/summary.txt
+  tail -2 gpurun_out/bench_dp2_gloo.log | cut -c1-400 >> gpurun_out/summary.txt
+fi
 if [[ "$PHASES" == *p32* ]]; then
   # kernel trace at the per-GPU load of the 8-GPU run (32 images): sum of kernel durations vs wall = launch-gap share
   rm -rf gpurun_out/prof32
