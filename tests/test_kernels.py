@@ -374,3 +374,64 @@ def test_conv_wgrad_tap_fused(env, cfg):
     F.conv2d(rbf(xin), w2, None, 1, 1).backward(dy)
     dw2 = Conv(dev).wgrad(x, dy, 3, 1, 1, pre=(ps, pt, True), bf16=2)
     assert relerr(dw2, w2.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
+
+
+# ---- randomized small shapes on the emulator (and the GPU): ragged pixel counts, odd widths, images smaller than a tile -----
+def _rand_shapes(seed, count, wmin, wmax, wstep=1):
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(count):
+        n = int(torch.randint(1, 4, (1,), generator=g))
+        h = int(torch.randint(1, 9, (1,), generator=g))
+        w = int(torch.randint(wmin // wstep, wmax // wstep + 1, (1,), generator=g)) * wstep
+        out.append((n, h, w))
+    return out
+
+
+@pytest.mark.parametrize("shape", _rand_shapes(70, 6, 3, 20))
+def test_conv3x3_c64_random_shapes(env, shape, force_cfg):
+    dev, _ = env
+    N, H, W = shape
+    force_cfg(0)
+    x, w = make((N, H, W, 64, 64, 3, 1, 1), 71 + H * 31 + W)
+    x = rbf(x)
+    ref = F.conv2d(x, rbf(w), None, 1, 1)
+    y, st = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
+    assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    x.requires_grad_(True)
+    yy = F.conv2d(x, rbf(w), None, 1, 1)
+    dy = rbf(torch.randn(yy.shape, generator=torch.Generator().manual_seed(72)))
+    yy.backward(dy)
+    dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, bf16=3, transposed=True)
+    assert relerr(dx, x.grad) < 1e-4 + OUT_TOL[2]
+
+
+@pytest.mark.parametrize("shape", _rand_shapes(73, 6, 8, 24))
+def test_conv_wgrad_tap_fused_random_shapes(env, shape):
+    """widths with W % 8 == 0, W % 4 == 0 and neither; pixel counts that do not fill the last 64-pixel chunk"""
+    dev, _ = env
+    N, H, W = shape
+    x, w = make((N, H, W, 64, 128, 3, 1, 1), 74 + H * 17 + W)
+    x = rbf(x)
+    dy = rbf(torch.randn((N, 128, H, W), generator=torch.Generator().manual_seed(75)))
+    w1 = w.clone().requires_grad_(True)
+    F.conv2d(x, w1, None, 1, 1).backward(dy)
+    assert relerr(Conv(dev).wgrad(x, dy, 3, 1, 1, bf16=2), w1.grad) < 1e-4
+
+
+@pytest.mark.parametrize("cfgid", [0, 1, 2])
+@pytest.mark.parametrize("shape", _rand_shapes(76, 3, 3, 14))
+def test_conv_generic_bf16_weights_random_shapes(env, shape, cfgid, force_cfg):
+    """the prefetch-distance-2 pipeline of the all-bf16 generic kernel on every tile configuration, incl. depth chunks < 2"""
+    dev, _ = env
+    N, H, W = shape
+    force_cfg(cfgid)
+    for (C, K, k, s_, p_) in [(64, 128, 1, 1, 0), (128, 128, 3, 1, 1), (64, 128, 3, 2, 1)]:
+        if s_ == 2 and (H % 2 or W % 2):
+            continue
+        x, w = make((N, H, W, C, K, k, s_, p_), 77 + H + W + C)
+        x = rbf(x)
+        ref = F.conv2d(x, rbf(w), None, s_, p_)
+        y, _ = Conv(dev).fwd(x, w, s_, p_, bf16=3)
+        assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
