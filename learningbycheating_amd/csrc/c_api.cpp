@@ -77,13 +77,8 @@ static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const void* w
     const int per = lbc_igemm_rows(a, cfg);
     if (stats_rows) *stats_rows = 4 * per;
     if (!dx) return LBC_OK;
-    for (int ph = 0; ph < 4; ++ph) {
-        a.oy0 = ph >> 1; a.ox0 = ph & 1;
-        a.stat_row0 = ph * per;
-        int rc = lbc_igemm_launch(a, wmajor, 1, cfg, s);
-        if (rc) return rc;
-    }
-    return LBC_OK;
+    a.nphase = 4;        // one launch for the four output-parity phases (statistics rows ph * per + tile)
+    return lbc_igemm_launch(a, wmajor, 1, cfg, s);
 }
 
 int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc_stream_t stream)

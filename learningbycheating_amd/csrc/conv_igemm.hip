@@ -74,9 +74,19 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a
     // remap hands every XCD one contiguous range of tiles, column tiles of the same rows first, so neighbouring tiles
     // (shared halo rows, shared A rows across column tiles) hit in that XCD's private L2.  Bijective for any tile count.
     const int ntn = a.K / BN;
+    // all four output-parity phases of a stride-2 transposed launch in one grid: phase-major workgroup ranges
+    int oy0 = a.oy0, ox0 = a.ox0, stat_row0 = a.stat_row0;
+    int nwg = gridDim.x, wgb = blockIdx.x;
+    if (a.nphase == 4) {
+        nwg = gridDim.x >> 2;
+        const int ph = blockIdx.x / nwg;
+        wgb = blockIdx.x - ph * nwg;
+        oy0 = ph >> 1; ox0 = ph & 1;
+        stat_row0 += ph * (nwg / ntn);
+    }
     int tile_id;
     {
-        const int nwg = gridDim.x, b = blockIdx.x;
+        const int b = wgb;
         const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
         tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
     }
@@ -91,7 +101,7 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a
             bool ok = true;
             if (MODE == 1 && a.S == 2) {
                 const int r = t / a.KW, s = t - r * a.KW;
-                ok = (((a.oy0 + a.P - r) & 1) == 0) && (((a.ox0 + a.P - s) & 1) == 0);
+                ok = (((oy0 + a.P - r) & 1) == 0) && (((ox0 + a.P - s) & 1) == 0);
             }
             if (ok) sTap[nt++] = t;
         }
@@ -115,8 +125,8 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a
             const int rem = m - n * lhw;
             const int ly = rem / a.LW;
             const int lx = rem - ly * a.LW;
-            const int oy = ly * a.ostep + a.oy0;
-            const int ox = lx * a.ostep + a.ox0;
+            const int oy = ly * a.ostep + oy0;
+            const int ox = lx * a.ostep + ox0;
             pixbase[j] = n * a.H * a.W;
             if (MODE == 0) { ay[j] = oy * a.S - a.P; ax[j] = ox * a.S - a.P; }
             else           { ay[j] = oy + a.P;       ax[j] = ox + a.P; }
@@ -362,7 +372,7 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a
             float t1 = 0.f, t2 = 0.f;
 #pragma unroll
             for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
-            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+            float* dst = a.stats + (size_t)(stat_row0 + mtile) * 2 * (size_t)a.K;
             dst[n0 + tid] = t1;
             dst[a.K + n0 + tid] = t2;
         }
@@ -427,7 +437,7 @@ __global__ __launch_bounds__(256) void weight_prep_k(WeightPrepArgs a)
 template <int BM, int BN>
 int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
-    dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN)));
+    dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN) * (a.nphase == 4 ? 4 : 1)));
     if (a.w_bf16) {
         if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, __bf16, 2>), grid, dim3(256), 0, s, a);
         else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, __bf16, 2>), grid, dim3(256), 0, s, a);
@@ -496,16 +506,20 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     LBC_REQUIRE((long long)a.N * a.H * a.W * a.C < (1ll << 31) && (long long)a.N * a.OH * a.OW * a.K < (1ll << 31),
                 "igemm: tensor exceeds 2^31 elements");
     // algorithmic work: 2*M*K*C per valid tap; bytes: gathered tensor + output once, weights once
-    int taps = 0;
+    LBC_REQUIRE(a.nphase == 0 || a.nphase == 1 || (a.nphase == 4 && mode == 1 && a.S == 2 && a.ostep == 2), "igemm: bad nphase %d", a.nphase);
+    double taps = 0;     // per output row; with nphase = 4 every tap serves exactly one of the four phases: average = T / 4
     for (int t = 0; t < a.KH * a.KW; ++t) {
         const int r = t / a.KW, q = t - r * a.KW;
+        if (a.nphase == 4) { taps += 0.25; continue; }
         if (mode == 1 && a.S == 2 && ((((a.oy0 + a.P - r) & 1) != 0) || (((a.ox0 + a.P - q) & 1) != 0))) continue;
-        ++taps;
+        taps += 1;
     }
-    const double in_frac = (mode == 1 && a.S == 2) ? 1.0 : 1.0;
-    LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * a.K * (double)a.C * taps,
-                      (a.act_bf16 ? 2.0 : 4.0) * (in_frac * a.N * (double)a.H * a.W * a.C / ((mode == 1 && a.S == 2) ? 4.0 : 1.0) +
-                                                  (double)a.M * a.K * (a.resid ? 2 : 1)) + (a.w_bf16 ? 2.0 : 4.0) * (double)taps * a.C * a.K, s);
+    const double nph = a.nphase == 4 ? 4.0 : 1.0;
+    // bytes: the gathered tensor (a quarter of it per phase of a stride-2 transposed launch), the output (+ residual), the weights of the taps used
+    const double in_elems = (double)a.N * a.H * a.W * a.C * ((mode == 1 && a.S == 2) ? nph / 4.0 : 1.0);
+    LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * nph * a.K * (double)a.C * taps,
+                      (a.act_bf16 ? 2.0 : 4.0) * (in_elems + nph * (double)a.M * a.K * (a.resid ? 2 : 1)) +
+                          (a.w_bf16 ? 2.0 : 4.0) * taps * nph * a.C * a.K, s);
     if (wmajor && lbc_conv3x3_halo_eligible(a, mode)) return lbc_conv3x3_halo_launch(a, mode, s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);

@@ -406,10 +406,8 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         }
         const int cfg = lbc_igemm_pick(a.M, a.K);
         const int per = lbc_igemm_rows(a, cfg);
-        for (int ph = 0; ph < 4; ++ph) {
-            a.oy0 = ph >> 1; a.ox0 = ph & 1; a.stat_row0 = ph * per;
-            LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
-        }
+        a.nphase = 4;                       // the four output-parity phases in one launch; statistics rows ph * per + tile
+        LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
         const long long opix = (long long)N * 4 * D.H * D.W;
         if (!tr) {
             // eval: statistics come from bn_eval_prep
@@ -526,12 +524,8 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     a.LH = c.H / 2; a.LW = c.W / 2; a.ostep = 2;
     a.M = N * a.LH * a.LW;
     const int cfg = lbc_igemm_pick(a.M, a.K);
-    const int nph = c.k == 1 ? 1 : 4;
-    for (int ph = 0; ph < nph; ++ph) {
-        a.oy0 = ph >> 1; a.ox0 = ph & 1;
-        LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
-    }
-    return LBC_OK;
+    a.nphase = c.k == 1 ? 1 : 4;            // 1x1: only the even-even phase; 3x3: all four parity phases in one launch
+    return lbc_igemm_launch(a, wmajor, 1, cfg, s);
 }
 
 // D: gradient wrt the block output (consumed; becomes the masked gradient); on return D points at the

@@ -73,6 +73,8 @@ struct IgemmArgs {
     int M;                // rows handled by this launch
     int LH, LW;           // lattice extents; pixel = (ly*ostep + oy0, lx*ostep + ox0)
     int oy0, ox0, ostep;
+    int nphase;           // 4: one launch covers the four output-parity phases of a stride-2 transposed launch (oy0/ox0 ignored;
+                          //    workgroups [ph * tiles, (ph+1) * tiles) serve phase ph = 2*oy0 + ox0; statistics rows follow); else 1
     int relu;
     int stat_row0;
     int bf16;             // 1: bf16 MFMA operands (f32 accumulation), needs wmajor weights and C % 64 == 0
