@@ -33,7 +33,9 @@ namespace {
 // PF = prefetch distance in depth chunks: the global loads of chunk it+PF are issued while chunk it is multiplied and are
 // written to LDS one chunk before their use, from PF register sets.  With two workgroups per CU a chunk lasts about one
 // loaded-L2 round trip (measured 1.5 us per chunk = 7x its MFMA time at PF = 1), so the all-bf16 kernels run PF = 2.
-template <int BM, int BN, bool WMAJOR, int MODE, bool BF16, typename AT, typename WT, int PF>
+// BKV = channels per depth chunk (0: 64 for the bf16 paths, 32 for f32).  The 64 x 64 tiles of small launches take 128: a chunk
+// there is 4 MFMAs per wave, so its cost is the barrier and the load round trip, and twice the depth halves their number.
+template <int BM, int BN, bool WMAJOR, int MODE, bool BF16, typename AT, typename WT, int PF, int BKV = 0>
 __global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a)
 {
     static_assert(!BF16 || WMAJOR, "the bf16 path needs depth-contiguous weights");
@@ -45,8 +47,8 @@ __global__ __launch_bounds__(256, PF == 2 ? 2 : 1) void conv_igemm_k(IgemmArgs a
     constexpr int BEL = WBF ? 8 : 4;
     using areg_t = typename std::conditional<ABF, bf16x8, f32x4>::type;   // one 16-byte activation load
     using lds_t = typename std::conditional<BF16, __bf16, float>::type;
-    constexpr int BK = BF16 ? 64 : 32;      // channels per depth chunk
-    constexpr int LDK = BK + (BF16 ? 8 : 4);   // padded LDS row (elements): 144-byte rows either way -> conflict-free b128 reads
+    constexpr int BK = BKV ? BKV : (BF16 ? 64 : 32);      // channels per depth chunk
+    constexpr int LDK = BK + (BF16 ? 8 : 4);   // padded LDS row (elements): 144-byte (or 272-byte) rows -> conflict-free b128 reads
     constexpr int SEGS = BK / BEL;          // 16-byte segments per weight-tile row
     constexpr int RPP = 256 / SEGS;         // tile rows staged per pass of the 256 threads
     constexpr int WM = 2, WN = 2;
@@ -439,6 +441,13 @@ int launch_cfg(const IgemmArgs& a, int wmajor, int mode, hipStream_t s)
 {
     dim3 grid((unsigned)(lbc_cdiv(a.M, BM) * (a.K / BN) * (a.nphase == 4 ? 4 : 1)));
     if (a.w_bf16) {
+        if constexpr (BM == 64 && BN == 64) {
+            if (a.C % 128 == 0) {   // small launches: 128-channel chunks
+                if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, __bf16, 2, 128>), grid, dim3(256), 0, s, a);
+                else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, __bf16, 2, 128>), grid, dim3(256), 0, s, a);
+                return lbc_check_launch("conv_igemm");
+            }
+        }
         if (mode == 0) hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 0, true, __bf16, __bf16, 2>), grid, dim3(256), 0, s, a);
         else           hipLaunchKernelGGL((conv_igemm_k<BM, BN, true, 1, true, __bf16, __bf16, 2>), grid, dim3(256), 0, s, a);
     } else if (a.act_bf16) {
