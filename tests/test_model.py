@@ -443,7 +443,8 @@ def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, mon
         monkeypatch.setenv("LBC_HEAD_NO_MFMA", "1")
         ps2, pa2 = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), train)
         monkeypatch.delenv("LBC_HEAD_NO_MFMA")
-        assert (pa1 - pa2).abs().max().item() < 2e-5 and (ps1 - ps2).abs().max().item() < 2e-5
+        # f32 summation order over up to 3840 soft-argmax terms (measured 2.2e-5 at 40 x 96); a wrong projection gives > 1e-2
+        assert (pa1 - pa2).abs().max().item() < 1e-4 and (ps1 - ps2).abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), ("birdview", "resnet18", 64, 64, 2),
