@@ -1,3 +1,4 @@
+// Build: hipcc --offload-arch=gfx950 -O2 scripts/probe/tr16_probe.hip -o scripts/probe/tr16_probe ; run on the GPU box.
 // Probe of ds_read_b64_tr_b16 (gfx950) semantics with per-lane addresses: each lane supplies the address of 4 contiguous
 // bf16; within a 16-lane group lane t's chunk is taken as B[t>>2][(t&3)*4 .. +3] of a 4x16 matrix and lane t receives column t.
 #include <hip/hip_runtime.h>
