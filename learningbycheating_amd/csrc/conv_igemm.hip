@@ -1,5 +1,5 @@
-// Implicit-GEMM convolution for gfx950 (MI355X), fp32 on the exact-f32 MFMA
-// (v_mfma_f32_32x32x2_f32).  One kernel template serves
+// Implicit-GEMM convolution for gfx950 (MI355X): exact f32 on v_mfma_f32_32x32x2_f32, or bf16 operands (f32 / bf16
+// tensors, f32 / bf16 weight copies) on v_mfma_f32_32x32x16_bf16.  One kernel template serves
 //   * nn.Conv2d forward                (reference bird_view/models/resnet.py:15-22,102)
 //   * nn.Conv2d input gradient         (autograd of the same call sites)
 //   * nn.ConvTranspose2d forward       (reference bird_view/models/image.py:39,42,45)
@@ -10,12 +10,16 @@
 // BatchNorm(+ReLU) applied on the fly (pre_scale/pre_shift).
 //
 // Tiling: a 256-thread workgroup (4 waves, 2x2) owns a BM x BN output tile and
-// walks depth in (tap, 32-channel) chunks, double-buffered through LDS with the
-// next chunk's global loads in flight under the current chunk's MFMAs.  LDS rows
-// are padded to 36 floats so ds_read_b128 fragment reads are conflict free.
-// A lane's f32x4 fragment holds channels {4*(l>>5)+i}; MFMA step i therefore
+// walks depth in (tap, 32/64/128-channel) chunks, double-buffered through LDS with
+// the global loads of the next chunk (the chunk after next in the all-bf16
+// kernels) in flight under the current chunk's MFMAs.  LDS rows are padded by
+// 16 bytes (144 / 272-byte rows) so ds_read_b128 fragment reads are conflict free.
+// f32 path: a lane's f32x4 fragment holds channels {4*(l>>5)+i}; MFMA step i
 // contracts the channel pair {i, 4+i} of each 8-channel group -- A and B use the
-// same pairing, so the sum over depth is complete.
+// same pairing, so the sum over depth is complete.  Stride-2 transposed launches
+// split into four output-parity phases (no MFMA on structurally zero taps), all
+// four in one grid.  The C = K = 64 3x3 layers of the all-bf16 mode go to
+// conv_halo.hip instead.
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include <type_traits>

@@ -1,4 +1,4 @@
-// Weight-gradient GEMM for gfx950, fp32 MFMA (v_mfma_f32_32x32x2_f32).
+// Weight-gradient GEMM for gfx950: exact f32 (v_mfma_f32_32x32x2_f32) and bf16 operands (v_mfma_f32_32x32x16_bf16).
 //   out[p][tap][q] = sum over pixels m of  P[m][p] * Q[gather(m, tap)][q]
 // which is the dW of nn.Conv2d (P = dy, Q = x; reference call sites
 // bird_view/models/resnet.py:15-22,102) and, with the roles of input and output
@@ -8,9 +8,14 @@
 // writes its own partial slab and lbc_splitk_reduce adds the slabs in a fixed
 // order (deterministic, no atomics).
 //
-// Both operands are pixel-major in HBM (NHWC), i.e. "depth-outer" for this GEMM,
-// so LDS tiles are [pixel][channel] and MFMA fragments are ds_read_b32 reads of
+// Both operands are pixel-major in HBM (NHWC), i.e. "depth-outer" for this GEMM.
+// f32 kernel: LDS tiles are [pixel][channel] and MFMA fragments are ds_read_b32 reads of
 // 32 consecutive channels (conflict free); one MFMA consumes two pixels.
+// bf16 kernel: the MFMA wants 8 consecutive pixels of one channel per lane, so micro-tiles of 4 pixels x 4/8
+// channels are transposed in registers into [channel][64 pixels] tiles (see the kernel for the lane order that
+// avoids LDS write conflicts).  The 3x3 / stride-1 launches on bf16 tensors go to conv_wgrad_tr.hip instead
+// (all nine taps per workgroup, transpose reads); this file keeps the stride-2, 1x1, transposed-convolution and
+// f32-tensor cases.
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include <type_traits>
