@@ -447,9 +447,10 @@ def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, mon
         assert (pa1 - pa2).abs().max().item() < 1e-4 and (ps1 - ps2).abs().max().item() < 1e-4
 
 
+@pytest.mark.parametrize("precision", [0, 2])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), ("birdview", "resnet18", 64, 64, 2),
                                                  pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])
-def test_uint8_nhwc_frames_equal_float_nchw_input(env, kind, backbone, h, w, n):
+def test_uint8_nhwc_frames_equal_float_nchw_input(env, kind, backbone, h, w, n, precision):
     """lbc_net_forward_u8: the dataset's uint8 NHWC frames give exactly the reference path's float (x/255, NCHW) result"""
     dev, _ = env
     sd = O.make_state_dict(kind, backbone, 10, h, w)
@@ -459,10 +460,11 @@ def test_uint8_nhwc_frames_equal_float_nchw_input(env, kind, backbone, h, w, n):
     xf = (u8.float() / 255.0).permute(0, 3, 1, 2).contiguous()
     speed = torch.rand(n, generator=g) * 10
     cmd = torch.eye(4)[torch.randint(0, 4, (n,), generator=g)]
-    eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=0)
-    ps1, pa1 = eng.forward(xf.to(dev), speed.to(dev), cmd.to(dev), False)
-    ps2, pa2 = eng.forward(u8.to(dev), speed.to(dev), cmd.to(dev), False)
-    assert torch.equal(pa1, pa2) and torch.equal(ps1, ps2)
+    eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
+    for train in (False, True):
+        ps1, pa1 = eng.forward(xf.to(dev), speed.to(dev), cmd.to(dev), train)
+        ps2, pa2 = eng.forward(u8.to(dev), speed.to(dev), cmd.to(dev), train)
+        assert torch.equal(pa1, pa2) and torch.equal(ps1, ps2)
 
 
 @gpu
