@@ -181,6 +181,7 @@ def main():
     lib.lbc_profile_report.restype = ctypes.c_int
     if rank == 0:
         lib.lbc_profile_enable(1)
+    tr.overlap_teacher = False       # one stream: the HIP events of this step bracket kernels that run alone
     tr.step(rgb, speed, onehot, birdview=bv)
     torch.cuda.synchronize()
     if world > 1:

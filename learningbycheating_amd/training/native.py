@@ -42,6 +42,10 @@ class NativeTrainer:
         self.dpred_all = torch.zeros((batch, 4, 5, 2), dtype=torch.float32, device=device)
         self.dpred_sel = torch.zeros((batch, 5, 2), dtype=torch.float32, device=device)
         self.nstages = PolicyEngine.num_stages()
+        # the frozen teacher's forward is independent of the student's: it runs on a side stream, which fills the GPU at
+        # small per-GPU batches (both networks launch kernels far smaller than the chip there)
+        self.side = torch.cuda.Stream(device=device) if (teacher is not None and torch.device(device).type == "cuda") else None
+        self.overlap_teacher = True      # False: one stream (per-kernel timing of an instrumented step stays meaningful)
 
     def _loss(self, kind, pred, target, rows, dpred):
         n = pred.shape[0]
@@ -52,9 +56,18 @@ class NativeTrainer:
         """x: student input (N,C,H,W) fp32; command one-hot (N,4); returns per-sample loss (device tensor)."""
         n = x.shape[0]
         if self.phase in (0, 1):
-            t_sel, t_all = self.teng.forward(birdview, speed, command, False)
+            if self.side is not None and self.overlap_teacher:
+                main = torch.cuda.current_stream(self.device)
+                self.side.wait_stream(main)                      # inputs (and last step's use of the teacher outputs) are ordered before
+                with torch.cuda.stream(self.side):
+                    t_sel, t_all = self.teng.forward(birdview, speed, command, False)
+                t_sel.record_stream(main); t_all.record_stream(main)
+            else:
+                t_sel, t_all = self.teng.forward(birdview, speed, command, False)
             self.last_teacher = (t_sel, t_all)
         p_sel, p_all = self.eng.forward(x, speed, command, True)
+        if self.phase in (0, 1) and self.side is not None and self.overlap_teacher:
+            torch.cuda.current_stream(self.device).wait_stream(self.side)      # the loss reads the teacher's waypoints
         d_sel = d_all = None
         if self.phase == 1:
             self._loss(1, p_all, t_all, 20, self.dpred_all); d_all = self.dpred_all[:n]
