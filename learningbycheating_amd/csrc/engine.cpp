@@ -76,6 +76,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
     if (const char* e = getenv("LBC_NO_FUSE_Z1")) fuse_z1_ = !(e[0] == '1');
     if (const char* e = getenv("LBC_DGRAD_WT")) dgrad_wt_ = (e[0] == '1');
+    if (const char* e = getenv("LBC_NO_SIDE_STREAM")) side_allowed_ = !(e[0] == '1');
     bf16_ = d.precision >= 1;
     act_bf16_ = d.precision == 2;
     if (bf16_) dgrad_wt_ = true;   // the bf16 tiles are [row][depth] only: every weight operand must be depth-contiguous
@@ -186,6 +187,35 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     wt_ = alloc((size_t)640 * 512 * 9);
     gD_ = alloc_act(max_act); gE_ = alloc_act(max_act); gF_ = alloc_act(max_act); gG_ = alloc_act(max_act);
     g0_ = alloc_act(NB * (H0 / 2) * (W0 / 2) * 64);
+}
+
+Net::~Net()
+{
+    if (side_) (void)hipStreamDestroy(side_);
+    if (ev_fork_) (void)hipEventDestroy(ev_fork_);
+    if (ev_join_) (void)hipEventDestroy(ev_join_);
+}
+
+int Net::fork(hipStream_t s)
+{
+    if (!side_on_) return LBC_OK;
+    if (hipEventRecord(ev_fork_, s) != hipSuccess || hipStreamWaitEvent(side_, ev_fork_, 0) != hipSuccess) {
+        lbc_set_error("net.backward: side-stream fork failed");
+        return LBC_ELAUNCH;
+    }
+    side_dirty_ = true;
+    return LBC_OK;
+}
+
+int Net::join(hipStream_t s)
+{
+    if (!side_on_ || !side_dirty_) return LBC_OK;
+    if (hipEventRecord(ev_join_, side_) != hipSuccess || hipStreamWaitEvent(s, ev_join_, 0) != hipSuccess) {
+        lbc_set_error("net.backward: side-stream join failed");
+        return LBC_ELAUNCH;
+    }
+    side_dirty_ = false;
+    return LBC_OK;
 }
 
 int Net::check_bound(bool need_grads) const
@@ -446,7 +476,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
 // ---------------------------------------------------------------------------------------
 // BatchNorm backward: reduce (sum g, sum g*xhat) -> dgamma/dbeta + coefficients -> dx
 int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
-                     float* dx, int Cout, hipStream_t s, const BN* mask_bn)
+                     float* dx, int Cout, hipStream_t s, const BN* mask_bn, bool join_before_apply)
 {
     ChanReduceArgs r;
     memset(&r, 0, sizeof(r));
@@ -473,6 +503,7 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
     ap.coefA = W(bn.cA); ap.coefB = W(bn.cB); ap.coefD = W(bn.cD);
     ap.mean = W(bn.mean); ap.invstd = W(bn.invstd);
     ap.dx = dx; ap.pixels = pixels; ap.C = bn.C; ap.Cout = Cout; ap.act_bf16 = act_bf16_;
+    if (join_before_apply) LBC_TRY(join(s));     // dx is still being read by a weight gradient on the side stream
     return lbc_bn_bwd_apply(ap, s);
 }
 
@@ -535,24 +566,30 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
     const int N = lastN_;
     const long long pix = (long long)N * b.c1.OH * b.c1.OW;
     const float* xin = (&b == &blocks_.front()) ? W(p0_) : W((&b - 1)->out);
+    // Weight gradients go to the side stream (wstream), next to the input gradient that consumes the same dY.  E and F are
+    // rewritten by the BatchNorm-backward apply passes / dgrads of the main stream: every apply that overwrites a buffer a
+    // pending weight gradient may still read joins first (join_before_apply), every weight gradient forks after its dY exists.
     // out = relu(bn2(y2) + identity): mask by out, keep masked gradient in D for the identity path
-    LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E, b.b2.C, s));        // E = dY2
+    LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E, b.b2.C, s, nullptr, true));   // E = dY2
+    LBC_TRY(fork(s));
     if (fuse_z1_) {
-        LBC_TRY(conv_wgrad_pre(b.c2, W(b.c1.y), &b.b1, E, N, s));
+        LBC_TRY(conv_wgrad_pre(b.c2, W(b.c1.y), &b.b1, E, N, wstream(s)));
         LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                               // F = dZ1
-        LBC_TRY(bn_backward(b.b1, F, W(b.c1.y), F, W(b.c1.y), pix, E, b.b1.C, s, &b.b1));   // E = dY1 (mask = bn1(y1) > 0)
+        LBC_TRY(bn_backward(b.b1, F, W(b.c1.y), F, W(b.c1.y), pix, E, b.b1.C, s, &b.b1, true));   // E = dY1 (mask = bn1(y1) > 0)
     } else {
-        LBC_TRY(conv_wgrad(b.c2, W(b.z1), E, N, s));
+        LBC_TRY(conv_wgrad(b.c2, W(b.z1), E, N, wstream(s)));
         LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                               // F = dZ1
-        LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E, b.b1.C, s));      // E = dY1
+        LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E, b.b1.C, s, nullptr, true));   // E = dY1
     }
-    LBC_TRY(conv_wgrad(b.c1, xin, E, N, s));
+    LBC_TRY(fork(s));
+    LBC_TRY(conv_wgrad(b.c1, xin, E, N, wstream(s)));
     if (!b.has_ds) {
         LBC_TRY(conv_dgrad(b.c1, E, D, Gbuf, N, s));                                  // G = dgrad + identity gradient
     } else {
         LBC_TRY(conv_dgrad(b.c1, E, nullptr, Gbuf, N, s));
-        LBC_TRY(bn_backward(b.bd, D, nullptr, nullptr, W(b.ds.y), pix, F, b.bd.C, s)); // F = dYd
-        LBC_TRY(conv_wgrad(b.ds, xin, F, N, s));
+        LBC_TRY(bn_backward(b.bd, D, nullptr, nullptr, W(b.ds.y), pix, F, b.bd.C, s)); // F = dYd (no pending reader of F)
+        LBC_TRY(fork(s));
+        LBC_TRY(conv_wgrad(b.ds, xin, F, N, wstream(s)));
         LBC_TRY(conv_dgrad(b.ds, F, Gbuf, Gbuf, N, s));                               // G += dgrad_1x1 (even pixels)
     }
     std::swap(D, Gbuf);
@@ -567,6 +604,15 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
     const int N = lastN_;
     float* E = W(gE_);
     float* F = W(gF_);
+    side_on_ = side_allowed_ && !lbc_prof_on();     // the profiler's per-launch events want kernels that run alone
+    if (side_on_ && !side_) {
+        if (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming) != hipSuccess) {
+            lbc_set_error("net.backward: cannot create the side stream");
+            return LBC_ELAUNCH;
+        }
+    }
 
     if (stage == -1 || stage == 0) {
         bwd_D_ = W(gD_); bwd_G_ = W(gG_);
@@ -656,6 +702,7 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
         const int first = stage_first_block_[li];
         const int lastb = li == 3 ? (int)blocks_.size() : stage_first_block_[li + 1];
         for (int bi = lastb - 1; bi >= first; --bi) LBC_TRY(block_backward(blocks_[bi], bwd_D_, bwd_G_, E, F, s));
+        LBC_TRY(join(s));     // the stage's gradients are complete on s (the caller all-reduces them behind an event on s)
     }
 
     if (stage == -1 || stage == 5) {

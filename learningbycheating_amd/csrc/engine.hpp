@@ -61,6 +61,7 @@ struct Deconv {   // BN -> ConvTranspose2d(k3,s2,p1,op1) -> ReLU
 class Net {
 public:
     explicit Net(const lbc_net_desc& d);
+    ~Net();
     const lbc_net_desc& desc() const { return d_; }
     std::vector<TensorInfo>& tensors() { return t_; }
     size_t workspace_bytes() const { return ws_floats_ * sizeof(float); }
@@ -98,7 +99,16 @@ private:
     int weight_prep(hipStream_t s);
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
-                    float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr);
+                    float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr, bool join_before_apply = false);
+    // Backward runs the weight gradients of the residual blocks on an internal side stream, next to the input gradients that
+    // consume the same dY (independent work; it fills the chip at small per-GPU batches).  fork: the side stream waits for
+    // everything enqueued on s so far; join: s waits for the side stream.  Inactive while the launch profiler is on.
+    int fork(hipStream_t s);
+    int join(hipStream_t s);
+    hipStream_t wstream(hipStream_t s) const { return side_on_ ? side_ : s; }
+    hipStream_t side_ = nullptr;
+    hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
+    bool side_allowed_ = true, side_on_ = false, side_dirty_ = false;
     int conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s);
     int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s);
     int block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s);
