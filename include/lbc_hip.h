@@ -121,7 +121,8 @@ int lbc_net_forward_u8(lbc_net* net, int N, int train, const unsigned char* imag
  * (either may be NULL) -> every bound parameter gradient (overwritten, not accumulated).
  * stage = -1 runs everything; stages 0..lbc_net_num_stages()-1 run in order (head+decoder,
  * layer4, layer3, layer2, layer1, stem) so gradient buckets can be all-reduced while the
- * remaining stages execute. */
+ * remaining stages execute.  The residual blocks' weight gradients run on an internal side stream next to their input
+ * gradients; every stage joins it before returning control of `stream` (LBC_NO_SIDE_STREAM=1 keeps everything on `stream`). */
 int lbc_net_num_stages(void);
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream);
 
