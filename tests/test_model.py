@@ -489,3 +489,38 @@ def test_training_scripts_chain_phase0_to_phase1(env, tmp_path, precision):
     layout = O.state_dict_layout("image", "resnet34")
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(shape)) for k, shape in layout]
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
+
+
+@gpu
+@pytest.mark.parametrize("precision", [0, 2])
+def test_side_stream_backward_is_bit_identical_to_single_stream(env, monkeypatch, precision):
+    """the residual blocks' weight gradients run on an internal side stream; every kernel is deterministic, so a missing
+    dependency (a buffer rewritten while a weight gradient still reads it) shows up as a bit difference against the
+    single-stream order (LBC_NO_SIDE_STREAM=1), repeated a few times"""
+    dev, _ = env
+    kind, backbone, h, w, n = "image", "resnet34", 160, 384, 8
+    sd = O.make_state_dict(kind, backbone, 12, h, w)
+    x, speed, cmd = _inputs(kind, n, h, w, 13)
+    g = torch.Generator().manual_seed(14)
+    d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g).to(dev), torch.randn((n, 5, 2), generator=g).to(dev)
+
+    def grads(single_stream):
+        if single_stream:
+            monkeypatch.setenv("LBC_NO_SIDE_STREAM", "1")
+        else:
+            monkeypatch.delenv("LBC_NO_SIDE_STREAM", raising=False)
+        eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
+        out = []
+        for _ in range(3):
+            eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
+            for st in range(eng.num_stages()):
+                eng.backward(d_sel, d_all, st)
+            torch.cuda.synchronize()
+            out.append(eng.grad_flat.clone())
+        return out
+
+    ref = grads(True)
+    got = grads(False)
+    for a, b in zip(ref, got):
+        assert torch.equal(a, b)
+    assert torch.equal(ref[0], ref[1]) and torch.equal(got[0], got[2])
