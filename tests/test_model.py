@@ -448,7 +448,7 @@ def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, mon
 
 
 @pytest.mark.parametrize("precision", [0, 2])
-@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), ("birdview", "resnet18", 64, 64, 2),
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 32, 64, 2), ("birdview", "resnet18", 32, 32, 2),
                                                  pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])
 def test_uint8_nhwc_frames_equal_float_nchw_input(env, kind, backbone, h, w, n, precision):
     """lbc_net_forward_u8: the dataset's uint8 NHWC frames give exactly the reference path's float (x/255, NCHW) result"""
