@@ -461,7 +461,7 @@ def test_uint8_nhwc_frames_equal_float_nchw_input(env, kind, backbone, h, w, n, 
     speed = torch.rand(n, generator=g) * 10
     cmd = torch.eye(4)[torch.randint(0, 4, (n,), generator=g)]
     eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
-    for train in (False, True):
+    for train in ((False, True) if precision == 2 else (False,)):     # (the exact-f32 MFMA is slow under the CPU emulator)
         ps1, pa1 = eng.forward(xf.to(dev), speed.to(dev), cmd.to(dev), train)
         ps2, pa2 = eng.forward(u8.to(dev), speed.to(dev), cmd.to(dev), train)
         assert torch.equal(pa1, pa2) and torch.equal(ps1, ps2)
