@@ -124,6 +124,9 @@ int lbc_net_forward_u8(lbc_net* net, int N, int train, const unsigned char* imag
  * remaining stages execute.  The residual blocks' weight gradients run on an internal side stream next to their input
  * gradients; every stage joins it before returning control of `stream` (LBC_NO_SIDE_STREAM=1 keeps everything on `stream`). */
 int lbc_net_num_stages(void);
+/* State lbc_net_backward() would differentiate: batch size and mode of the last forward, and a counter that every forward
+ * increments -- a caller that holds several forward results (autograd) can detect that the workspace has moved on. */
+int lbc_net_last_forward(const lbc_net* net, int* batch, int* train, long long* generation);
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream);
 
 /* Losses (forward value per sample + gradient wrt pred), reference training/train_image_phase1.py:35-70,
@@ -143,6 +146,89 @@ int lbc_phase2_weight(const lbc_camera* cam, const float* pred_sel, const float*
 typedef struct lbc_adam_chunk { float* p; const float* g; float* m; float* v; int n; int pad; } lbc_adam_chunk;
 int lbc_adam_step(const lbc_adam_chunk* chunks_dev, int nchunks, double lr, double beta1, double beta2,
                   double eps, double weight_decay, int step, lbc_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Single-operator entry points of the HBM-bound kernels: what the executor above launches between the
+ * convolutions, exported so that every kernel has its own parity test against torch CPU (tests/test_ops.py).
+ * act_bf16 = 1: the activation tensors (void*) are bf16 in HBM, arithmetic stays f32.
+ * ---------------------------------------------------------------------------------------- */
+
+/* nn.BatchNorm2d (reference resnet.py:31,34,104,137; image.py:38,41,44,56).
+ * lbc_bn_stats: per-workgroup partial (sum, sum^2) rows of x[pixels][C] -> partial[rows][2][C] (the convolution epilogues
+ *   produce the same rows for their outputs); *rows receives the row count (query with x == NULL allowed; <= 1024).
+ * lbc_bn_finalize_stats: partial rows -> scale = gamma*invstd, shift = beta - mean*scale, saved mean / invstd; train != 0
+ *   also updates running_mean / running_var (momentum, unbiased variance) and num_batches_tracked (all nullable);
+ *   train == 0 takes the statistics from running_mean / running_var.
+ * lbc_bn_apply_relu_add_fwd: y = relu?(x*scale + shift (+ resid [*rscale + rshift])). */
+int lbc_bn_stats(const void* x, long long pixels, int C, int act_bf16, float* partial, int* rows, lbc_stream_t stream);
+int lbc_bn_finalize_stats(const float* partial, int rows, int C, long long count, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, long long* num_batches_tracked, float momentum, float eps,
+                          int train, float* scale, float* shift, float* save_mean, float* save_invstd, lbc_stream_t stream);
+int lbc_bn_apply_relu_add_fwd(const void* x, void* y, long long pixels, int C, const float* scale, const float* shift,
+                              const void* resid, const float* rscale, const float* rshift, int relu, int act_bf16,
+                              lbc_stream_t stream);
+/* BatchNorm2d backward (autograd of the call sites above), fused with the backward of a following ReLU:
+ *   g = dz * (mask > 0)   (mask nullable; mask_scale/mask_shift nullable: mask := mask*mask_scale + mask_shift first)
+ *   dbeta = sum g, dgamma = sum g*xhat, dx = gamma*invstd*(g - dbeta/n - xhat*dgamma/n) over the first Cout channels.
+ * g_out (nullable, may alias dz) receives g.  workspace: lbc_bn_bwd_workspace(C) bytes. */
+size_t lbc_bn_bwd_workspace(int C);
+int lbc_bn_bwd(const void* x, const void* dz, const void* mask, const float* mask_scale, const float* mask_shift,
+               void* g_out, const float* gamma, const float* mean, const float* invstd, long long pixels, int C, int Cout,
+               float* dgamma, float* dbeta, void* dx, float* workspace, int act_bf16, lbc_stream_t stream);
+
+/* bn1 -> relu -> nn.MaxPool2d(3,2,1) of the ResNet stem (reference resnet.py:149-152, :106) and its backward.
+ * fwd: y[N,H,W,C] (pre-BN) -> p[N,H/2,W/2,C], idx = arg-max tap 0..8 per output element (u8, nullable).
+ * bwd: dp -> g[N,H,W,C] = gradient wrt the BatchNorm output (ReLU mask applied) + BatchNorm-backward partial rows
+ *   (sum g, sum g*xhat) in partial[rows][2][C]; *rows receives the row count (query with dp == NULL allowed). */
+int lbc_maxpool3x3s2_fwd(const void* y, const float* scale, const float* shift, void* p, unsigned char* idx, int N, int H, int W,
+                         int C, int act_bf16, lbc_stream_t stream);
+int lbc_maxpool3x3s2_bwd(const void* dp, const unsigned char* idx, const void* y, const float* scale, const float* shift,
+                         const float* mean, const float* invstd, void* g, float* partial, int* rows, int N, int H, int W, int C,
+                         int act_bf16, lbc_stream_t stream);
+
+/* Waypoint head: 4 x (BatchNorm2d(64) -> Conv2d(64,5,1) -> SpatialSoftmax) -> stack -> select_branch
+ * (reference image.py:54-60,82-84; common.py:29-35,136-152).  All per-branch parameter arrays are [4] pointers. */
+typedef struct lbc_head_desc {
+    const void* h;             /* decoder output [N][OH*OW][64], f32 or bf16 */
+    int N, OH, OW, act_bf16;
+    const float* mean[4];      /* BatchNorm statistics per branch [64]; training mode: the four entries are the same batch statistics */
+    const float* invstd[4];
+    const float* gamma[4];
+    const float* beta[4];
+    const float* w[4];         /* [5][64] */
+    const float* bias[4];      /* [5] */
+    const float* pos_x[4];     /* SpatialSoftmax buffers [OH*OW] */
+    const float* pos_y[4];
+    const float* cmd;          /* [N][4] one-hot */
+} lbc_head_desc;
+/* workspace (floats): N*40 (row statistics, fwd -> bwd) + N*20*65 + 8*20*65 + 3*64 + N*16*20*4 */
+size_t lbc_head_workspace(int N);
+int lbc_head_fwd(const lbc_head_desc* d, float* pred_all, float* pred_sel, float* workspace, lbc_stream_t stream);
+/* backward of the last lbc_head_fwd on the same workspace (training-mode statistics): d_all [N,4,5,2] / d_sel [N,5,2]
+ * (either nullable) -> dh (like h) and the parameter gradients dgamma/dbeta [4][64], dw [4][5*64], dbias [4][5]. */
+int lbc_head_bwd(const lbc_head_desc* d, const float* pred_all, const float* d_all, const float* d_sel, void* dh,
+                 float* const* dgamma, float* const* dbeta, float* const* dw, float* const* dbias, float* workspace,
+                 lbc_stream_t stream);
+
+/* Stem: input pass + 7x7/2 convolution 3|7 -> 64 (reference resnet.py:102; common.py:101-109 NormalizeV2 fused).
+ * lbc_nchw_to_input / lbc_u8nhwc_to_input: image -> xp[N][H+6][W+6][C] (3-pixel zero border; bf16 when xp_bf16),
+ *   optionally ImageNet-normalised (normalize = 1, C = 3).
+ * lbc_stem_fwd: xp, w[64][7][7][C] -> y[N][H/2][W/2][64] (+ statistics partial rows, nullable).
+ * lbc_stem_wgrad: xp, dy -> dw[64][7][7][C]; workspace lbc_stem_wgrad_workspace() bytes.  bf16: lbc_conv_desc.bf16 modes 0/1/2. */
+int lbc_nchw_to_input(const float* image_nchw, void* xp, int xp_bf16, int N, int C, int H, int W, int normalize, lbc_stream_t stream);
+int lbc_u8nhwc_to_input(const unsigned char* image_nhwc, void* xp, int xp_bf16, int N, int C, int H, int W, int normalize,
+                        lbc_stream_t stream);
+int lbc_stem_fwd(const void* xp, const float* w, void* y, float* stats, int* stats_rows, int N, int H, int W, int C, int bf16,
+                 lbc_stream_t stream);
+size_t lbc_stem_wgrad_workspace(int N, int H, int W, int C);
+int lbc_stem_wgrad(const void* xp, const void* dy, float* dw, void* workspace, int N, int H, int W, int C, int bf16,
+                   lbc_stream_t stream);
+
+/* Runtime options (A/B switches, tuning knobs, test hooks): names are the LBC_* environment variables that initialise the
+ * table at load time; -1 = unset.  Options read when a network is created (LBC_NO_FUSE_Z1,
+ * LBC_DGRAD_WT, LBC_NO_SIDE_STREAM) apply to networks created afterwards. */
+int lbc_config_set(const char* name, long long value);
+long long lbc_config_get(const char* name);
 
 /* Built-in launch profiler: HIP-event timing of every kernel launch on its own stream, booked per
  * kernel class together with the launch's algorithmic flops and HBM bytes.  report() writes one

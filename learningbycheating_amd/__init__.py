@@ -7,3 +7,11 @@ Per-step compute runs in hand-written HIP kernels for gfx950 (csrc/), reached th
 C ABI of include/lbc_hip.h; torch only provides device memory, streams and RCCL.
 """
 __version__ = "0.1.0"
+
+#: Declared accuracy of the precision modes (asserted by tests/test_model.py::test_bf16_mode_declared_accuracy on the MI355X
+#: and quoted next to `dtype` in bench.py's JSON line).  Waypoints are normalised coordinates in [-1, 1].
+#:   fp32: exact-f32 MFMA everywhere -- the north-star bar (|waypoint - reference PyTorch-CPU forward| <= 1e-3), asserted at 1e-4.
+#:   bf16: BASELINE.json config 3 (bf16 MFMA operands + bf16 activation storage, f32 master weights / accumulate / BN / loss /
+#:         Adam) on a trained-like (warm-started, calibrated) network: max |waypoint - fp32 executor| <= 1e-2.  The reference
+#:         under torch autocast(bf16) deviates 3-5e-3 from its own f32 forward (SURVEY.md 8c), so bf16 cannot meet 1e-3.
+WAYPOINT_TOLERANCE = {"fp32": 1e-3, "bf16": 1e-2, "bf16_mfma": 1e-2}

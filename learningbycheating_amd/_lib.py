@@ -26,6 +26,11 @@ class Camera(ctypes.Structure):
     _fields_ = [(n, c_float) for n in ("w", "h", "fov", "world_y", "fixed_offset", "pixels_per_meter", "crop_size")]
 
 
+class HeadDesc(ctypes.Structure):
+    _fields_ = ([("h", c_void_p), ("N", c_int), ("OH", c_int), ("OW", c_int), ("act_bf16", c_int)] +
+                [(n, c_void_p * 4) for n in ("mean", "invstd", "gamma", "beta", "w", "bias", "pos_x", "pos_y")] + [("cmd", c_void_p)])
+
+
 class AdamChunk(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int), ("pad", c_int)]
 
@@ -52,10 +57,30 @@ _SIGNATURES = {
     "lbc_net_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),
     "lbc_net_forward_u8": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),
     "lbc_net_num_stages": (c_int, []),
+    "lbc_net_last_forward": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong)]),
     "lbc_net_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
     "lbc_loss": (c_int, [c_int, ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "lbc_phase2_weight": (c_int, [ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "lbc_adam_step": (c_int, [c_void_p, c_int] + [ctypes.c_double] * 5 + [c_int, c_void_p]),
+    "lbc_bn_stats": (c_int, [c_void_p, ctypes.c_longlong, c_int, c_int, c_void_p, ctypes.POINTER(c_int), c_void_p]),
+    "lbc_bn_finalize_stats": (c_int, [c_void_p, c_int, c_int, ctypes.c_longlong] + [c_void_p] * 5 + [c_float, c_float, c_int] + [c_void_p] * 5),
+    "lbc_bn_apply_relu_add_fwd": (c_int, [c_void_p, c_void_p, ctypes.c_longlong, c_int] + [c_void_p] * 5 + [c_int, c_int, c_void_p]),
+    "lbc_bn_bwd_workspace": (c_size_t, [c_int]),
+    "lbc_bn_bwd": (c_int, [c_void_p] * 9 + [ctypes.c_longlong, c_int, c_int] + [c_void_p] * 4 + [c_int, c_void_p]),
+    "lbc_maxpool3x3s2_fwd": (c_int, [c_void_p] * 5 + [c_int] * 5 + [c_void_p]),
+    "lbc_maxpool3x3s2_bwd": (c_int, [c_void_p] * 9 + [ctypes.POINTER(c_int)] + [c_int] * 5 + [c_void_p]),
+    "lbc_head_workspace": (c_size_t, [c_int]),
+    "lbc_head_fwd": (c_int, [ctypes.POINTER(HeadDesc)] + [c_void_p] * 4),
+    "lbc_head_bwd": (c_int, [ctypes.POINTER(HeadDesc)] + [c_void_p] * 4 + [ctypes.POINTER(c_void_p)] * 4 + [c_void_p, c_void_p]),
+    "lbc_nchw_to_input": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "lbc_u8nhwc_to_input": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
+    "lbc_stem_fwd": (c_int, [c_void_p] * 4 + [ctypes.POINTER(c_int)] + [c_int] * 5 + [c_void_p]),
+    "lbc_stem_wgrad_workspace": (c_size_t, [c_int] * 4),
+    "lbc_stem_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "lbc_config_set": (c_int, [c_char_p, ctypes.c_longlong]),
+    "lbc_config_get": (ctypes.c_longlong, [c_char_p]),
+    "lbc_profile_enable": (c_int, [c_int]),
+    "lbc_profile_report": (c_int, [c_char_p, c_int]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -89,6 +114,15 @@ def _inject_for_tests(lib):
     global _lib
     _lib = _declare(lib) if lib is not None else None
     return _lib
+
+
+def config_set(name, value):
+    """runtime option of the library (names = the LBC_* environment variables); value -1 = unset"""
+    check(get().lbc_config_set(name.encode(), int(value)), "config_set")
+
+
+def config_get(name):
+    return int(get().lbc_config_get(name.encode()))
 
 
 def backend():

@@ -72,6 +72,7 @@ class _PolicyFunction(torch.autograd.Function):
         eng = module._engine_for(image, need_grad)   # (grad mode is always off inside Function.forward: decided by the caller)
         pred_sel, pred_all = eng.forward(image, velocity, command, module.training)
         ctx.module, ctx.eng, ctx.train = module, eng, module.training
+        ctx.generation = eng.generation            # the activations backward() needs live in the engine's ONE workspace
         return pred_sel, pred_all
 
     @staticmethod
@@ -81,6 +82,12 @@ class _PolicyFunction(torch.autograd.Function):
         if d_sel is None and d_all is None:
             return (None,) * (5 + len(ctx.module._param_names))
         eng = ctx.eng
+        if eng.generation != ctx.generation:
+            raise RuntimeError(
+                "backward through a stale forward: the executor keeps the activations of the LAST forward only (one workspace per "
+                "module and input size), and %d more forward(s) ran on this module since the one being differentiated. Call "
+                "backward() before the next forward of the same module (the reference's training loops do), or use a second "
+                "module instance for interleaved forwards." % (eng.generation - ctx.generation))
         eng.backward(None if d_sel is None else d_sel.contiguous().float(),
                      None if d_all is None else d_all.contiguous().float())
         grads = []

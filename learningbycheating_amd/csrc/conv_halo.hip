@@ -185,8 +185,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_k(IgemmArgs a)
 
 bool lbc_conv3x3_halo_eligible(const IgemmArgs& a, int mode)
 {
-    static const bool off = getenv("LBC_NO_HALO") && getenv("LBC_NO_HALO")[0] == '1';   // A/B switch
-    return !off && a.w_bf16 && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.ostep == 1 && a.oy0 == 0 &&
+    return !lbc_opt_on(kOptNoHalo) && a.w_bf16 && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.ostep == 1 && a.oy0 == 0 &&
            a.ox0 == 0 && a.C == 64 && a.K == 64 && a.H == a.OH && a.W == a.OW && a.M == a.N * a.H * a.W &&
            128 + 2 * a.W + 2 <= kHaloRowsMax && (mode == 0 || mode == 1);
 }
@@ -197,7 +196,7 @@ int lbc_conv3x3_halo_launch(const IgemmArgs& a, int mode, hipStream_t s)
     // weights stationary in registers, persistent workgroups, two per CU
     int nb = lbc_cdiv(a.M, 128);
     int cap = 512;
-    if (const char* e = getenv("LBC_HALO_BLOCKS")) { const int v = atoi(e); if (v >= 8) cap = v & ~7; }   // tests: force multi-tile workgroups
+    if (lbc_opt(kOptHaloBlocks) >= 8) cap = (int)lbc_opt(kOptHaloBlocks) & ~7;   // tests: force multi-tile workgroups
     if (nb > cap) nb = cap;
     if (mode == 0) hipLaunchKernelGGL((conv3x3_c64_k<0>), dim3((unsigned)nb), dim3(256), 0, s, a);
     else           hipLaunchKernelGGL((conv3x3_c64_k<1>), dim3((unsigned)nb), dim3(256), 0, s, a);

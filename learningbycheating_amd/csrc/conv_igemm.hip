@@ -497,7 +497,7 @@ int lbc_igemm_rows(const IgemmArgs& a, int cfg)
 
 int lbc_igemm_pick(long long M, int K)
 {
-    if (const char* e = getenv("LBC_FORCE_CFG")) { const int c = atoi(e); if (c >= 0 && c < 3 && K % kCfgBN[c] == 0) return c; }   // tests / tuning
+    { const long long c = lbc_opt(kOptForceCfg); if (c >= 0 && c < 3 && K % kCfgBN[c] == 0) return (int)c; }   // tests / tuning
     // Prefer the largest tile that still gives the 256 CUs >= 1.5 waves of workgroups.
     const long long want = 384;
     if (K % 128 == 0 && ((M + 127) / 128) * (K / 128) >= want) return 1;

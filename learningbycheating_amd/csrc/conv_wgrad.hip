@@ -457,7 +457,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict
 // and is neutral at batch 32.
 inline bool big_tile(const WgradArgs& a)
 {
-    static const long long min_m = getenv("LBC_WGRAD_BIGM") ? atoll(getenv("LBC_WGRAD_BIGM")) : 4096;   // tuning knob
+    const long long min_m = lbc_opt(kOptWgradBigM) >= 0 ? lbc_opt(kOptWgradBigM) : 4096;   // tuning knob
     return a.CP % 128 == 0 && a.CQ % 128 == 0 && (long long)a.N * a.OH * a.OW >= min_m;
 }
 
@@ -470,7 +470,7 @@ int lbc_wgrad_pick_split(const WgradArgs& a)
     const long long tiles = (long long)(a.CP / bp) * (a.CQ / bp) * a.KH * a.KW;
     const long long M = (long long)a.N * a.OH * a.OW;
     const long long chunks = (M + BR - 1) / BR;
-    static const long long target = getenv("LBC_WGRAD_BLOCKS") ? atoll(getenv("LBC_WGRAD_BLOCKS")) : 1024;   // tuning knob
+    const long long target = lbc_opt(kOptWgradBlocks) > 0 ? lbc_opt(kOptWgradBlocks) : 1024;   // tuning knob
     long long ns = (target + tiles - 1) / tiles;
     if (ns < 1) ns = 1;
     if (ns > 256) ns = 256;
@@ -500,7 +500,7 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     const int bt = big_tile(a) ? 128 : 64;
     const long long ngroups = (long long)a.nsplit * (a.CP / bt) * (a.CQ / bt);
     const dim3 grid((unsigned)(((ngroups + 7) / 8) * 8 * a.KH * a.KW));
-    static const int kb = getenv("LBC_WGRAD_KB") ? atoi(getenv("LBC_WGRAD_KB")) : -1;   // tuning knob (lane mapping, see the kernel)
+    const int kb = (int)lbc_opt(kOptWgradKb);   // tuning knob (lane mapping, see the kernel); -1 = default
 #define LBC_WG(AT, KB)                                                                                                               \
     do {                                                                                                                             \
         if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, AT, KB>), grid, dim3(256), 0, s, a, rows_per_split);        \

@@ -240,14 +240,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
 
 bool lbc_wgrad_tr_eligible(const WgradArgs& a)
 {
-    static const bool off = getenv("LBC_NO_WGRAD_TR") && getenv("LBC_NO_WGRAD_TR")[0] == '1';   // A/B switch
+    const bool off = lbc_opt_on(kOptNoWgradTr);   // A/B switch
     return !off && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.OH == a.H && a.OW == a.W && !a.p_scale &&
            a.W >= 8 && 64 + 2 * a.W + 2 + 64 <= kRing && a.CP % 64 == 0 && a.CQ % 64 == 0;
 }
 
 int lbc_wgrad_tr_pick_split(const WgradArgs& a)
 {
-    static const long long target = getenv("LBC_WGRAD_TR_BLOCKS") ? atoll(getenv("LBC_WGRAD_TR_BLOCKS")) : 512;   // tuning knob
+    const long long target = lbc_opt(kOptWgradTrBlocks) > 0 ? lbc_opt(kOptWgradTrBlocks) : 512;   // tuning knob
     const long long tiles = (long long)(a.CP / 64) * (a.CQ / 64);
     const long long M = (long long)a.N * a.H * a.W;
     const long long chunks = (M + 63) / 64;

@@ -74,9 +74,9 @@ Net::Net(const lbc_net_desc& d) : d_(d)
 {
     const size_t NB = (size_t)d.max_batch;
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
-    if (const char* e = getenv("LBC_NO_FUSE_Z1")) fuse_z1_ = !(e[0] == '1');
-    if (const char* e = getenv("LBC_DGRAD_WT")) dgrad_wt_ = (e[0] == '1');
-    if (const char* e = getenv("LBC_NO_SIDE_STREAM")) side_allowed_ = !(e[0] == '1');
+    fuse_z1_ = !lbc_opt_on(kOptNoFuseZ1);
+    dgrad_wt_ = lbc_opt_on(kOptDgradWt);
+    side_allowed_ = !lbc_opt_on(kOptNoSideStream);
     bf16_ = d.precision >= 1;
     act_bf16_ = d.precision == 2;
     if (bf16_) dgrad_wt_ = true;   // the bf16 tiles are [row][depth] only: every weight operand must be depth-contiguous
@@ -323,7 +323,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
     LBC_REQUIRE(N >= 1 && N <= d_.max_batch, "net.forward: batch %d outside [1,%d]", N, d_.max_batch);
     LBC_REQUIRE(image && velocity && command && pred_all, "net.forward: null argument");
     LBC_TRY(check_bound(false));
-    lastN_ = N; last_train_ = train;
+    lastN_ = N; last_train_ = train; ++generation_;
     const int H0 = d_.H, W0 = d_.W, Cin = d_.in_channels;
     const bool tr = train != 0;
     int rows = 0;
@@ -598,6 +598,18 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
 
 int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t s)
 {
+    const int rc = backward_impl(d_sel, d_all, stage, s);
+    if (rc != LBC_OK && side_dirty_) {
+        // an early return between fork() and join(): weight gradients may still be in flight on the side stream; let them
+        // finish before anything (a retry, the next forward) reuses the gradient ping-pong buffers or the split-K slabs
+        (void)hipStreamSynchronize(side_);
+        side_dirty_ = false;
+    }
+    return rc;
+}
+
+int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStream_t s)
+{
     LBC_REQUIRE(lastN_ > 0 && last_train_, "net.backward: needs a preceding training-mode forward");
     LBC_REQUIRE(stage >= -1 && stage < kNumStages, "net.backward: bad stage %d", stage);
     LBC_TRY(check_bound(true));
@@ -606,9 +618,18 @@ int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t
     float* F = W(gF_);
     side_on_ = side_allowed_ && !lbc_prof_on();     // the profiler's per-launch events want kernels that run alone
     if (side_on_ && !side_) {
-        if (hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming) != hipSuccess) {
+        // the side stream belongs to the device that owns the workspace, whatever device is current in the calling thread
+        int cur = 0, want = 0;
+        (void)hipGetDevice(&cur);
+        want = cur;
+        hipPointerAttribute_t attr;
+        if (hipPointerGetAttributes(&attr, ws_) == hipSuccess) want = attr.device;
+        if (want != cur) (void)hipSetDevice(want);
+        const bool ok = hipStreamCreateWithFlags(&side_, hipStreamNonBlocking) == hipSuccess &&
+                        hipEventCreateWithFlags(&ev_fork_, hipEventDisableTiming) == hipSuccess &&
+                        hipEventCreateWithFlags(&ev_join_, hipEventDisableTiming) == hipSuccess;
+        if (want != cur) (void)hipSetDevice(cur);
+        if (!ok) {
             lbc_set_error("net.backward: cannot create the side stream");
             return LBC_ELAUNCH;
         }
@@ -808,6 +829,14 @@ int lbc_net_forward_u8(lbc_net* net, int N, int train, const unsigned char* imag
     return net->impl.forward(N, train, image_nhwc, 1, velocity, command, pred_sel, pred_all, (hipStream_t)stream);
 }
 int lbc_net_num_stages(void) { return lbc::Net::kNumStages; }
+int lbc_net_last_forward(const lbc_net* net, int* batch, int* train, long long* generation)
+{
+    LBC_REQUIRE(net, "net_last_forward: null net");
+    if (batch) *batch = net->impl.last_batch();
+    if (train) *train = net->impl.last_train();
+    if (generation) *generation = net->impl.generation();
+    return LBC_OK;
+}
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream)
 {
     LBC_REQUIRE(net, "net_backward: null net");

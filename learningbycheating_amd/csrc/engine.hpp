@@ -74,6 +74,10 @@ public:
     // stage: -1 = everything; otherwise 0 = head+decoder, 1..4 = layer4..layer1, 5 = stem (call in order)
     int backward(const float* d_sel, const float* d_all, int stage, hipStream_t s);
     static const int kNumStages = 6;
+    // what backward() would differentiate: batch size and mode of the last forward, and how many forwards ran before it
+    int last_batch() const { return lastN_; }
+    int last_train() const { return last_train_; }
+    long long generation() const { return generation_; }
 
 private:
     int add_tensor(const std::string& name, int kind, std::initializer_list<int> shape);
@@ -112,6 +116,8 @@ private:
     int conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s);
     int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s);
     int block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s);
+    int backward_impl(const float* d_sel, const float* d_all, int stage, hipStream_t s);
+    long long generation_ = 0;
 
     lbc_net_desc d_;
     std::vector<TensorInfo> t_;

@@ -476,7 +476,7 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
     LbcProfScope prof("head_fwd", 2.0 * a.N * a.OH * a.OW * 64.0 * 20, 4.0 * a.N * (double)a.OH * a.OW * 64, s);
-    const bool no_mfma = getenv("LBC_HEAD_NO_MFMA") && getenv("LBC_HEAD_NO_MFMA")[0] == '1';   // A/B switch
+    const bool no_mfma = lbc_opt_on(kOptHeadNoMfma);   // A/B switch
     if (a.act_bf16 && !no_mfma) {
         HeadArgs b = a;
         b.nslice = 1;

@@ -28,6 +28,28 @@ int lbc_check_launch(const char* what);
 
 static inline int lbc_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Runtime options (A/B switches, tuning knobs, test hooks).  ONE table: initialised from the LBC_* environment variables when
+// the library is loaded and changed afterwards only through lbc_config_set() (include/lbc_hip.h) -- a launch path never reads
+// the environment, and every option can be toggled inside one process.  -1 = unset (the built-in policy applies).
+enum LbcOpt {
+    kOptForceCfg = 0,      // LBC_FORCE_CFG: tile policy of the generic convolution (0: 128x64, 1: 128x128, 2: 64x64)
+    kOptNoHalo,            // LBC_NO_HALO: 1 = never use the halo-staged layer-1 kernel
+    kOptHaloBlocks,        // LBC_HALO_BLOCKS: cap on its persistent workgroups (tests: force multi-tile workgroups)
+    kOptWgradBigM,         // LBC_WGRAD_BIGM
+    kOptWgradBlocks,       // LBC_WGRAD_BLOCKS
+    kOptWgradKb,           // LBC_WGRAD_KB
+    kOptNoWgradTr,         // LBC_NO_WGRAD_TR: 1 = never use the tap-fused weight gradient
+    kOptWgradTrBlocks,     // LBC_WGRAD_TR_BLOCKS
+    kOptHeadNoMfma,        // LBC_HEAD_NO_MFMA
+    kOptNoFuseZ1,          // LBC_NO_FUSE_Z1 (read when a network is created)
+    kOptDgradWt,           // LBC_DGRAD_WT (read when a network is created)
+    kOptNoSideStream,      // LBC_NO_SIDE_STREAM (read when a network is created)
+    kOptNoGemm256,         // LBC_NO_GEMM256: 1 = never use the 8-wave direct-to-LDS convolution (conv_glds.hip)
+    kOptCount
+};
+long long lbc_opt(LbcOpt o);
+static inline bool lbc_opt_on(LbcOpt o) { return lbc_opt(o) == 1; }
+
 // Built-in launch profiler (lbc_util.cpp): when enabled through lbc_profile_enable(1) every launcher
 // brackets its kernel with two HIP events on the launch stream and books the kernel's ALGORITHMIC
 // flops / HBM bytes under a class name; lbc_profile_report() sums them.  Disabled = zero overhead.

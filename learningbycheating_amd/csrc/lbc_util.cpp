@@ -26,6 +26,42 @@ int lbc_check_launch(const char* what)
 
 extern "C" const char* lbc_last_error(void) { return g_err; }
 
+// ---- runtime options -----------------------------------------------------------------
+#include <stdlib.h>
+#include <string.h>
+namespace {
+const char* const kOptNames[kOptCount] = {
+    "LBC_FORCE_CFG", "LBC_NO_HALO", "LBC_HALO_BLOCKS", "LBC_WGRAD_BIGM", "LBC_WGRAD_BLOCKS", "LBC_WGRAD_KB", "LBC_NO_WGRAD_TR",
+    "LBC_WGRAD_TR_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_FUSE_Z1", "LBC_DGRAD_WT", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256"};
+struct OptTable {
+    long long v[kOptCount];
+    OptTable()
+    {
+        for (int i = 0; i < kOptCount; ++i) {
+            const char* e = getenv(kOptNames[i]);
+            v[i] = (e && *e) ? atoll(e) : -1;
+        }
+    }
+};
+OptTable& opts() { static OptTable t; return t; }   // built on first use = library load time for every practical purpose
+}  // namespace
+long long lbc_opt(LbcOpt o) { return opts().v[o]; }
+extern "C" int lbc_config_set(const char* name, long long value)
+{
+    LBC_REQUIRE(name, "config_set: null name");
+    for (int i = 0; i < kOptCount; ++i)
+        if (!strcmp(name, kOptNames[i])) { opts().v[i] = value; return LBC_OK; }
+    lbc_set_error("config_set: unknown option %s", name);
+    return LBC_EINVAL;
+}
+extern "C" long long lbc_config_get(const char* name)
+{
+    if (name)
+        for (int i = 0; i < kOptCount; ++i)
+            if (!strcmp(name, kOptNames[i])) return opts().v[i];
+    return -1;
+}
+
 // ---- launch profiler -----------------------------------------------------------------
 #include <map>
 #include <string>

@@ -6,6 +6,13 @@ import torch
 from . import _lib
 
 
+GRAD_ALIGN = 64      # elements (256 bytes)
+
+
+def _pad(n):
+    return (n + GRAD_ALIGN - 1) // GRAD_ALIGN * GRAD_ALIGN
+
+
 def is_channels_last_4d(t):
     """True when a 4-D tensor's memory order is [d0][d2][d3][d1] (or the distinction is void)."""
     if t.dim() != 4:
@@ -40,6 +47,8 @@ class PolicyEngine:
             self.shapes.append(tuple(shape[k] for k in range(ndim.value)))
         self.workspace = torch.empty(lib.lbc_net_workspace_bytes(h), dtype=torch.uint8, device=device)
         self._bound_key = None
+        self.generation = 0          # forwards run on this engine's workspace so far (autograd checks it, see models/common.py)
+        self.last_batch = 0
         self.grad_flat = None
         self.grad_views = {}
         self._keep = None
@@ -75,15 +84,19 @@ class PolicyEngine:
             pnames = [n for n, k in zip(self.names, self.kinds) if k == 0]
             order = [n for n in (param_order or pnames) if n in set(pnames)]
             assert set(order) == set(pnames)
-            total = sum(tensors[n].numel() for n in order)
+            # every tensor starts on a GRAD_ALIGN-element (256-byte) boundary of the flat buffer: the fused Adam and the
+            # all-reduce buckets address it with 16-byte vector accesses (the 5-element head biases would otherwise
+            # misalign everything behind them); the pad elements stay zero and travel with their stage's bucket
+            total = sum(_pad(tensors[n].numel()) for n in order)
             if self.grad_flat is None or self.grad_flat.numel() != total:
                 self.grad_flat = torch.zeros(total, dtype=torch.float32, device=self.workspace.device)
-            self.grad_views, self.grad_offsets, off = {}, {}, 0
+            self.grad_views, self.grad_offsets, self.grad_spans, off = {}, {}, {}, 0
             for n in order:
                 t = tensors[n]
                 self.grad_views[n] = torch.as_strided(self.grad_flat, t.shape, t.stride(), off)
                 self.grad_offsets[n] = (off, t.numel())
-                off += t.numel()
+                self.grad_spans[n] = (off, _pad(t.numel()))
+                off += _pad(t.numel())
             gp = (ctypes.c_void_p * nt)(*[self.grad_views[n].data_ptr() if k == 0 else 0 for n, k in zip(self.names, self.kinds)])
         _lib.check(_lib.get().lbc_net_bind(self.handle, _lib.ptr(self.workspace), tp, gp), "net_bind")
         self._bound_key = key
@@ -92,21 +105,45 @@ class PolicyEngine:
     # ---- execution --------------------------------------------------------------------
     def forward(self, image, velocity, command, train):
         """image: float32 (N,C,H,W) in [0,1] (the reference signature) or uint8 (N,H,W,C) frames as the dataset stores them"""
+        d = self.desc
+        if image.dim() != 4:
+            raise RuntimeError("engine.forward: image must be 4-D, got %s" % (tuple(image.shape),))
         n = image.shape[0]
+        if not 1 <= n <= self.max_batch:
+            raise RuntimeError("engine.forward: batch %d outside [1, %d]" % (n, self.max_batch))
+        # the C ABI takes raw pointers: everything it will dereference is validated here (dtype, layout, extent, device)
+        if image.dtype == torch.uint8:
+            want = (n, d.H, d.W, d.in_channels)
+            fn = _lib.get().lbc_net_forward_u8
+        elif image.dtype == torch.float32:
+            want = (n, d.in_channels, d.H, d.W)
+            fn = _lib.get().lbc_net_forward
+        else:
+            raise RuntimeError("engine.forward: image must be float32 (N,C,H,W) or uint8 (N,H,W,C), got %s" % image.dtype)
+        if tuple(image.shape) != want or not image.is_contiguous():
+            raise RuntimeError("engine.forward: image must be a contiguous %s tensor of shape %s (the engine's plan), got %s with strides %s"
+                               % (image.dtype, want, tuple(image.shape), image.stride()))
+        for name, t, shape in (("velocity", velocity, (n,)), ("command", command, (n, 4))):
+            if t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous():
+                raise RuntimeError("engine.forward: %s must be a contiguous float32 tensor of shape %s, got %s %s"
+                                   % (name, shape, t.dtype, tuple(t.shape)))
+        for name, t in (("image", image), ("velocity", velocity), ("command", command)):
+            if t.device != self.workspace.device:
+                raise RuntimeError("engine.forward: %s lives on %s, the engine on %s" % (name, t.device, self.workspace.device))
         pred_sel = torch.empty((n, 5, 2), dtype=torch.float32, device=image.device)
         pred_all = torch.empty((n, 4, 5, 2), dtype=torch.float32, device=image.device)
-        if image.dtype == torch.uint8:
-            if image.dim() != 4 or not image.is_contiguous():
-                raise RuntimeError("engine.forward: uint8 frames must be a contiguous (N,H,W,C) tensor")
-            fn = _lib.get().lbc_net_forward_u8
-        else:
-            fn = _lib.get().lbc_net_forward
         _lib.check(fn(self.handle, n, int(train), _lib.ptr(image), _lib.ptr(velocity), _lib.ptr(command),
                       _lib.ptr(pred_sel), _lib.ptr(pred_all), _lib.stream_for(image)), "net_forward")
+        self.generation += 1
+        self.last_batch = n
         return pred_sel, pred_all
 
     def backward(self, d_sel, d_all, stage=-1):
         ref = d_sel if d_sel is not None else d_all
+        for name, t, shape in (("d_sel", d_sel, (self.last_batch, 5, 2)), ("d_all", d_all, (self.last_batch, 4, 5, 2))):
+            if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.workspace.device):
+                raise RuntimeError("engine.backward: %s must be a contiguous float32 %s tensor on %s (the last forward ran %d samples), got %s %s on %s"
+                                   % (name, shape, self.workspace.device, self.last_batch, t.dtype, tuple(t.shape), t.device))
         _lib.check(_lib.get().lbc_net_backward(self.handle, _lib.ptr(d_sel), _lib.ptr(d_all), stage, _lib.stream_for(ref)), "net_backward")
 
     @staticmethod

@@ -19,7 +19,11 @@ class FusedAdam:
         self.step_count = 0
         self.names = [n for n, _ in named_params if n in grads]
         params = dict(named_params)
-        total = sum(params[n].numel() for n in self.names)
+        # moments in the gradients' element order, every tensor starting on a 64-element (256-byte) boundary: adam_k moves
+        # 16 bytes per lane, so p, g, m and v of every chunk must be 16-byte aligned (the engine's flat gradient buffer pads
+        # the same way; the 5-element head biases would otherwise misalign everything behind them)
+        from .engine import _pad
+        total = sum(_pad(params[n].numel()) for n in self.names)
         dev = params[self.names[0]].device
         self.exp_avg = torch.zeros(total, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(total, dtype=torch.float32, device=dev)
@@ -28,12 +32,13 @@ class FusedAdam:
         for n in self.names:
             p, g = params[n].data, grads[n]
             assert p.stride() == g.stride() and p.dtype == torch.float32
+            assert p.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0, "adam: %s is not 16-byte aligned" % n
             self.offsets[n] = (off, p.numel())
             for c in range(0, p.numel(), CHUNK):
                 k = min(CHUNK, p.numel() - c)
                 rows.append((p.data_ptr() + 4 * c, g.data_ptr() + 4 * c, self.exp_avg.data_ptr() + 4 * (off + c),
                              self.exp_avg_sq.data_ptr() + 4 * (off + c), k))
-            off += p.numel()
+            off += _pad(p.numel())
         table = np.zeros(len(rows), dtype=[("p", "<u8"), ("g", "<u8"), ("m", "<u8"), ("v", "<u8"), ("n", "<i4"), ("pad", "<i4")])
         for i, r in enumerate(rows):
             table[i] = r + (0,)

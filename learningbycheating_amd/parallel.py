@@ -13,11 +13,12 @@ STAGE_PREFIXES = [("deconv.", "location_pred."), ("conv.layer4.",), ("conv.layer
                   ("conv.conv1.", "conv.bn1.")]
 
 
-def stage_ranges(grad_offsets):
-    """[(start, end)] element ranges of the flat gradient buffer, one per backward stage."""
+def stage_ranges(grad_spans):
+    """[(start, end)] element ranges of the flat gradient buffer, one per backward stage.  grad_spans: name -> (offset,
+    padded element count) as laid out by PolicyEngine.bind (every tensor on a 256-byte boundary; pads are zero)."""
     out = []
     for prefixes in STAGE_PREFIXES:
-        spans = [grad_offsets[n] for n in grad_offsets if n.startswith(prefixes)]
+        spans = [grad_spans[n] for n in grad_spans if n.startswith(prefixes)]
         lo = min(o for o, _ in spans)
         hi = max(o + c for o, c in spans)
         assert sum(c for _, c in spans) == hi - lo, "stage parameters must be contiguous in the flat gradient buffer"
@@ -26,9 +27,9 @@ def stage_ranges(grad_offsets):
 
 
 class StageAllReducer:
-    def __init__(self, grad_flat, grad_offsets, group=None, force=False):
+    def __init__(self, grad_flat, grad_spans, group=None, force=False):
         self.flat = grad_flat
-        self.ranges = stage_ranges(grad_offsets)
+        self.ranges = stage_ranges(grad_spans)
         self.group = group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         self.active = self.world > 1 or (force and dist.is_initialized())   # force: exercise the comm path on one rank (tests)

@@ -37,7 +37,7 @@ class NativeTrainer:
             self.teng = teacher.engine((batch, 7, 192, 192), device, max_batch=batch, with_grads=False)
         self.cam = camera or camera_struct()
         self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
-        self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_offsets, group)
+        self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group)
         self.loss = torch.zeros(batch, dtype=torch.float32, device=device)
         self.dpred_all = torch.zeros((batch, 4, 5, 2), dtype=torch.float32, device=device)
         self.dpred_sel = torch.zeros((batch, 5, 2), dtype=torch.float32, device=device)

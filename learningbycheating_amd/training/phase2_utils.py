@@ -27,6 +27,7 @@ class ReplayBuffer:
         self.speed = None
         self._weights = np.zeros(0, dtype=np.float64)
         self._rng = np.random.RandomState(seed)
+        self._perm, self._perm_pos = None, 0     # epoch shuffle while the weights are not normalised yet
 
     def __len__(self):
         return 0 if self.rgb is None else self.rgb.shape[0]
@@ -51,7 +52,9 @@ class ReplayBuffer:
         self.add_batch(torch.as_tensor(rgb_img)[None], torch.as_tensor(birdview_img)[None], torch.tensor([cmd]), torch.tensor([speed]), [weight])
 
     def init_new_weights(self):
+        """start of an epoch (reference train_image_phase2.py:168): fresh write-back array, fresh shuffle"""
         self._new_weights = self._weights.copy()
+        self._perm = None
 
     def update_weights(self, idxes, losses):
         idx = np.asarray(idxes)
@@ -63,11 +66,18 @@ class ReplayBuffer:
         self.normalized = True
 
     def sample_indices(self, batch_size, epoch_pos=None):
-        """weighted resampling once weights are normalised (phase2_utils.py:219-227), sequential shuffle before"""
+        """Indices of the next batch.  Once the weights are normalised: loss-weighted resampling, one draw per sample
+        (reference phase2_utils.py:219-227, weighted_random_choice).  Before that: the reference's
+        DataLoader(shuffle=True, drop_last=True) (train_image_phase2.py:170), i.e. consecutive slices of ONE permutation
+        per epoch, so every replay sample is visited (and gets its weight written back) exactly once."""
         if self._sampling and self.normalized:
             p = self._weights / self._weights.sum()
             return self._rng.choice(len(self), size=batch_size, p=p)
-        return self._rng.randint(0, len(self), size=batch_size)
+        if self._perm is None or self._perm_pos + batch_size > len(self._perm) or len(self._perm) != len(self):
+            self._perm, self._perm_pos = self._rng.permutation(len(self)), 0      # a new epoch (or the buffer changed)
+        out = self._perm[self._perm_pos:self._perm_pos + batch_size]
+        self._perm_pos += batch_size
+        return out
 
     def batch(self, idx):
         di = torch.as_tensor(idx, device=self.device)

@@ -147,6 +147,34 @@ def main():
     assert torch.allclose(ref_l, o_l, rtol=1e-5, atol=1e-6) and torch.allclose(cam_r.grad, cam_o.grad, rtol=1e-4, atol=1e-6)
     out["phase1_loss"] = {"cam": cam, "teacher": teac, "map": ref_map.detach().clone(), "loss": ref_l.detach().clone(),
                           "dcam": cam_r.grad.clone()}
+    # ---- phase-0: the reference's CoordConverter (cv2.projectPoints restated, see ref_shim) + LocationLoss --------------
+    defs0 = ref_shim.extract_training_defs("train_image_phase0.py", ["CoordConverter", "LocationLoss"])
+    conv0 = defs0["CoordConverter"](w=384, h=160, fov=90, world_y=1.4, fixed_offset=4.0, device="cpu")
+    crit0 = defs0["LocationLoss"](w=384, h=160, device="cpu")
+    tmap = torch.rand(6, 5, 2, generator=g) * 2 - 1          # teacher map-space waypoints, incl. ones that clip at the image border
+    img_ref = conv0(tmap)
+    assert torch.allclose(img_ref, O.phase0_project(tmap), rtol=1e-6, atol=1e-4), (img_ref - O.phase0_project(tmap)).abs().max()
+    pred0 = (torch.rand(6, 5, 2, generator=g) * 2 - 1).requires_grad_(True)
+    l0 = crit0(pred0, img_ref)
+    l0.mean().backward()
+    pred0o = pred0.detach().clone().requires_grad_(True)
+    l0o = O.phase0_loss(pred0o, O.phase0_project(tmap))
+    l0o.mean().backward()
+    assert torch.allclose(l0, l0o, rtol=1e-6, atol=1e-7) and torch.allclose(pred0.grad, pred0o.grad, rtol=1e-6, atol=1e-8)
+    out["phase0_loss"] = {"teacher_map": tmap, "image_xy": img_ref.clone(), "pred": pred0.detach().clone(), "loss": l0.detach().clone(),
+                          "dpred": pred0.grad.clone()}
+    # ---- bird-view behaviour cloning: LocationLoss(choice='l1') of train_birdview.py:33-54 (its ctor calls .cuda()) -------
+    with ref_shim._cuda_noop():
+        critb = ref_shim.extract_training_defs("train_birdview.py", ["LocationLoss"])["LocationLoss"](w=192, h=192, choice="l1")
+    gt = torch.rand(6, 5, 2, generator=g) * 192
+    predb = (torch.rand(6, 5, 2, generator=g) * 2 - 1).requires_grad_(True)
+    lb = critb(predb, gt)
+    lb.mean().backward()
+    predbo = predb.detach().clone().requires_grad_(True)
+    lbo = O.birdview_loss(predbo, gt)
+    lbo.mean().backward()
+    assert torch.allclose(lb, lbo, rtol=1e-6, atol=1e-7) and torch.allclose(predb.grad, predbo.grad, rtol=1e-6, atol=1e-8)
+    out["birdview_loss"] = {"gt": gt, "pred": predb.detach().clone(), "loss": lb.detach().clone(), "dpred": predb.grad.clone()}
     # ---- phase-2 resampling weight + batch_aug repeat vs the reference functions (training/phase2_utils.py) ----
     import ast
     src = open(ref_shim.REFERENCE_ROOT + "/training/phase2_utils.py").read()

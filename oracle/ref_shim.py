@@ -71,12 +71,29 @@ def load_one_hot():
     return one_hot
 
 
+class _Cv2ProjectPointsOnly:
+    """Stand-in for the ONE cv2 call on the path (train_image_phase0.py:61 cv2.projectPoints(xyz, tvec=0, rvec=0, A, None)).
+    opencv-python==4.0.0.21 (environment.yml:186) is not installed and cannot be fetched.  Published algorithm
+    (OpenCV calib3d docs, projectPoints): x' = X/Z, y' = Y/Z after [R|t] (identity here), no distortion terms when
+    distCoeffs is None, then u = fx*x' + cx, v = fy*y' + cy, computed in float64, returned as (N, 1, 2) plus a jacobian.
+    Everything else of the reference's CoordConverter (frame changes, metres, offset, clipping, reshapes) is the
+    reference's own code, executed unchanged around this call."""
+
+    @staticmethod
+    def projectPoints(xyz, rvec, tvec, A, dist):
+        assert dist is None and not np.any(rvec) and not np.any(tvec), "only the reference's call pattern is restated"
+        xyz = np.asarray(xyz, dtype=np.float64)
+        u = A[0, 0] * xyz[:, 0] / xyz[:, 2] + A[0, 2]
+        v = A[1, 1] * xyz[:, 1] / xyz[:, 2] + A[1, 2]
+        return np.stack([u, v], -1)[:, None, :], None
+
+
 def extract_training_defs(script, names):
     """AST-extract classes/functions from a non-importable training script
     (training/train_image_phase{0,1}.py import modules that do not exist here)."""
     src = open(REFERENCE_ROOT + "/training/" + script).read()
     tree = ast.parse(src)
-    ns = {"torch": torch, "np": np, "PIXELS_PER_METER": 5, "CROP_SIZE": 192, "N_STEP": 5}
+    ns = {"torch": torch, "np": np, "PIXELS_PER_METER": 5, "CROP_SIZE": 192, "N_STEP": 5, "cv2": _Cv2ProjectPointsOnly}
     for node in tree.body:
         if isinstance(node, (ast.ClassDef, ast.FunctionDef)) and node.name in names:
             code = compile(ast.Module([node], []), script, "exec")

@@ -30,3 +30,18 @@ def env(request):
         emu.activate()
         yield torch.device("cpu"), "emu-cpu"
         emu.deactivate()
+
+
+@pytest.fixture
+def lbc_config(env):
+    """set runtime options of the loaded library (lbc_config_set; names = the LBC_* variables) for one test, restored after"""
+    from learningbycheating_amd import _lib
+    saved = {}
+
+    def set_opt(name, value):
+        if name not in saved:
+            saved[name] = _lib.config_get(name)
+        _lib.config_set(name, value)
+    yield set_opt
+    for k, v in saved.items():
+        _lib.config_set(k, v)

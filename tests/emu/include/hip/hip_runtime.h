@@ -68,6 +68,10 @@ static inline const char* hipGetErrorString(hipError_t e) { return e == hipSucce
 static inline hipError_t hipGetLastError() { return hipSuccess; }
 static inline hipError_t hipPeekAtLastError() { return hipSuccess; }
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+static inline hipError_t hipSetDevice(int) { return hipSuccess; }
+struct hipPointerAttribute_t { int device; };
+static inline hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void*) { a->device = 0; return hipSuccess; }
 static inline hipError_t hipDeviceSynchronize() { return hipSuccess; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }

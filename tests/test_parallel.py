@@ -121,7 +121,7 @@ def _dp_worker(rank, world, port, q):
         return eng, d
 
     eng, d = shard_grads(rank, 1.0 / (n * world))
-    red = StageAllReducer(eng.grad_flat, eng.grad_offsets)
+    red = StageAllReducer(eng.grad_flat, eng.grad_spans)
     for st in range(6):
         eng.backward(None, d, st)
         red.launch(st)
