@@ -36,11 +36,12 @@ int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const void* w, const f
     a.OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
     a.LH = a.OH; a.LW = a.OW; a.ostep = 1;
     a.M = d->N * a.OH * a.OW;
-    const int cfg = lbc_igemm_pick(a.M, a.K);
+    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
+    // NB a row-count query must describe the launch it is for: pass the same pre_scale (NULL or not) as the real call
+    const int cfg = lbc_igemm_pick_for(a, 0);
     if (stats_rows) *stats_rows = lbc_igemm_rows(a, cfg);
     if (!y) return LBC_OK;   // query only
     a.x = x; a.w = w; a.y = y; a.bias = bias; a.resid = resid; a.stats = stats;
-    a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
     return lbc_igemm_launch(a, /*wmajor=*/1, /*mode=*/0, cfg, (hipStream_t)stream);
 }
 
@@ -63,7 +64,7 @@ static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const void* w
     if (d->S == 1) {
         a.LH = a.OH; a.LW = a.OW; a.ostep = 1; a.oy0 = 0; a.ox0 = 0;
         a.M = d->N * a.LH * a.LW;
-        const int cfg = lbc_igemm_pick(a.M, a.K);
+        const int cfg = wmajor ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K);
         rows = lbc_igemm_rows(a, cfg);
         if (stats_rows) *stats_rows = rows;
         if (!dx) return LBC_OK;

@@ -1,0 +1,324 @@
+// 3x3 / 1x1 stride-1 convolution (forward and input gradient) for bf16 tensors + bf16 weight copies on gfx950, as an
+// implicit GEMM on 256 x 256 / 256 x 128 / 128 x 256 output tiles with 8 waves per workgroup and LDS-DMA staging
+// (global_load_lds_dwordx4): the wide residual layers (layer 2-4) of the ResNets at training batch sizes.
+// reference arithmetic: BasicBlock conv1 / conv2, bird_view/models/resnet.py:15-22,38-54, and their autograd.
+//
+// Why a third kernel next to conv_igemm.hip (128 x 128, 4 waves, register staging) -- measured on that kernel at batch 256:
+// MFMA busy 0.21-0.24; a 64-channel depth chunk of a 128 x 128 tile stages 32 KB through VGPRs and ds_write_b128
+// (~80 B/clk/CU) for 16 MFMAs per wave, every chunk ends in a barrier that waits for the chunk's global loads, and the
+// four waves of a workgroup run in lockstep, so the matrix pipe idles while fragments are read.  Here
+//   * a tile is 4x (2x) larger: half the staged bytes per MFMA, and 8 waves = two per SIMD;
+//   * operands go HBM/L2 -> LDS by DMA: no staging registers, no ds_write issue, and the loads stay in flight across
+//     barriers (counted s_waitcnt vmcnt, raw s_barrier);
+//   * the two waves of a SIMD run half a phase apart (the second group of four waves passes one extra barrier up
+//     front): while one wave issues its 8 MFMAs (256 cycles) the other reads its next fragments and issues DMA pieces;
+//   * LDS rows are 128 bytes (64 bf16) with the 16-byte segment index XOR-ed with (row >> 1) & 7 -- applied to the
+//     SOURCE address of the DMA (the LDS image of a DMA is lane-linear) and to the fragment read -- which makes every
+//     ds_read_b128 lane group hit 16 distinct 16-byte slots.
+// Zero padding: taps that fall outside the image DMA from a 256-byte zero page instead (an LDS-DMA cannot be masked).
+// A depth step (K-tile) = one filter tap x 64 channels, channel slab outer / taps inner so that the nine shifted reads of
+// a slab hit in L2.  No BatchNorm-on-load prologue (a DMA cannot transform): launches that need one keep conv_igemm.hip.
+//
+// Synchronisation of one K-tile (P phases of 8 MFMAs; group g = wave >> 2; buffers ring of NBUF K-tiles):
+//   phase p:  [load segment]  fragment ds_reads of tile t from its buffer; (p <= 1) DMA pieces of tile t + NBUF - 1;
+//                             (p == P-1) s_waitcnt vmcnt(n): this wave's pieces of tile t + 1 have landed;
+//                             s_waitcnt lgkmcnt(0): this wave's reads are retired;   s_barrier
+//             [MFMA segment]  8 MFMAs;   s_barrier
+//   RAW: group 0 reads tile t+1 right after the barrier that ends its phase P-1 MFMAs, which is the barrier group 1
+//        crosses between its phase P-1 load and MFMA segments -- every wave has waited for its tile t+1 pieces before it.
+//   WAR: a buffer is refilled from phase 0 of the tile after its last reader; those reads were retired (lgkmcnt(0))
+//        before the barrier the refilling wave has just crossed.
+#include "lbc_common.hpp"
+#include "lbc_act.hpp"
+
+namespace {
+
+// s_waitcnt immediate, gfx9 layout: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14]
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | ((lgkm & 15) << 8); }
+#define LBC_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(waitcnt_imm((n), 15))
+#define LBC_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0))
+
+typedef __attribute__((address_space(1))) const void* gas_ptr;
+typedef __attribute__((address_space(3))) void* las_ptr;
+// 16 bytes per lane from a per-lane global address to (wave-uniform LDS base) + 16 * lane
+__device__ __forceinline__ void lds_dma16(const void* g, void* lds_wave_base)
+{
+    __builtin_amdgcn_global_load_lds((gas_ptr)g, (las_ptr)lds_wave_base, 16, 0, 0);
+}
+
+template <int BM, int BN, int WM, int WN, int NBUF, int MODE>
+__global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* zero_page)
+{
+    constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    static_assert(WM * WN == 8 && NT == 2 && (MT == 2 || MT == 4), "conv_glds: wave tiling");
+    constexpr int P = MT;                                       // phases per K-tile, (MT/2 * 2) x 1 x 4 = 8 MFMAs each
+    constexpr int TILE_A = BM * 128, TILE_B = BN * 128, BUF = TILE_A + TILE_B;   // bytes per K-tile: rows of 64 bf16
+    constexpr int NA = BM / 64, NB = BN / 64, NL = NA + NB;     // 1-KiB DMA pieces (8 rows) per wave per K-tile
+    static_assert(NBUF == 2 || NBUF == 3, "conv_glds: ring depth");
+    static_assert(NBUF * BUF <= 160 * 1024, "conv_glds: LDS");
+    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];   // the ONLY LDS object (a second one costs vmcnt(0) per read)
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int grp = wave >> 2;                                  // waves w and w + 4 share a SIMD: opposite groups
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int W = a.W, H = a.H, C = a.C, T = a.KH * a.KW, KW = a.KW, PAD = a.P;
+
+    // XCD-aware tile order (see conv_igemm.hip): contiguous tile ranges per XCD, column tiles of the same rows adjacent
+    const int ntn = a.K / BN;
+    int tile_id;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int mtile = tile_id / ntn;
+    const int m0 = mtile * BM;
+    const int n0 = (tile_id - mtile * ntn) * BN;
+
+    const __bf16* xin = static_cast<const __bf16*>(a.x);
+    const __bf16* win = static_cast<const __bf16*>(a.w);
+    const __bf16* zero = static_cast<const __bf16*>(zero_page);
+
+    // ---- DMA roles: piece (wave * NA + j) of the A tile = rows 8 * piece .. + 7, lane -> (row = lane >> 3, segment = lane & 7)
+    int aoff[NA], amask[NA], aseg[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int row = (wave * NA + j) * 8 + (lane >> 3);
+        const int m = m0 + row;
+        int bits = 0;
+        if (m < a.M) {
+            const int x = m % W;
+            const int y = (m / W) % H;
+            for (int t = 0; t < T; ++t) {
+                const int r = t / KW, s = t - r * KW;
+                const int dy = MODE == 0 ? r - PAD : PAD - r;
+                const int dx = MODE == 0 ? s - PAD : PAD - s;
+                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
+            }
+        }
+        amask[j] = bits;
+        aoff[j] = (m < a.M ? m : 0) * C;
+        aseg[j] = (((lane & 7) ^ ((row >> 1) & 7))) * 8;        // swizzle on the SOURCE: LDS slot (row, s) holds segment s ^ f(row)
+    }
+    int boff[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (wave * NB + j) * 8 + (lane >> 3);
+        boff[j] = (n0 + row) * (T * C) + (((lane & 7) ^ ((row >> 1) & 7))) * 8;
+    }
+    // ---- fragment roles: row l31 of a 32-row block, depth half kh; 16-byte segment (2g + kh) ^ f(row), f(row) = (l31 >> 1) & 7
+    const int swz = (l31 >> 1) & 7;
+    int koff[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) koff[g] = ((g * 2 + kh) ^ swz) << 4;
+    const int aBase = (wm * WTM + l31) * 128;
+    const int bBase = TILE_A + (wn * WTN + l31) * 128;
+
+    const int cpt = C / 64;
+    const int nit = T * cpt;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // the DMA stream walks K-tiles in order: (channel slab ci, tap ti), taps inner
+    int is_ci = 0, is_ti = 0, is_buf = 0;
+    auto issue_a = [&]() {
+        const int r = is_ti / KW, s = is_ti - r * KW;
+        const int shift = (MODE == 0 ? (r - PAD) * W + (s - PAD) : (PAD - r) * W + (PAD - s)) * C + is_ci * 64;
+        char* base = smem + is_buf * BUF;
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bool ok = (amask[j] >> is_ti) & 1;
+            const __bf16* src = ok ? xin + (aoff[j] + shift + aseg[j]) : zero + (lane & 7) * 8;
+            lds_dma16(src, base + (wave * NA + j) * 1024);
+        }
+    };
+    auto issue_b = [&]() {
+        const int koffs = is_ti * C + is_ci * 64;
+        char* base = smem + is_buf * BUF + TILE_A;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) lds_dma16(win + (boff[j] + koffs), base + (wave * NB + j) * 1024);
+    };
+    auto issue_next = [&]() {
+        if (++is_ti == T) { is_ti = 0; ++is_ci; }
+        if (++is_buf == NBUF) is_buf = 0;
+    };
+
+    // ---- prologue: NBUF - 1 tiles in flight, tile 0 landed and visible
+    issue_a(); issue_b(); issue_next();
+    if (NBUF == 3) {
+        if (nit > 1) { issue_a(); issue_b(); issue_next(); LBC_WAIT_VM(NL); }
+        else LBC_WAIT_VM(0);
+    } else {
+        LBC_WAIT_VM(0);
+    }
+    __builtin_amdgcn_s_barrier();
+    if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs half a phase behind group 0
+
+    int buf = 0;
+    for (int t = 0; t < nit; ++t) {
+        const char* bb = smem + buf * BUF;
+        const bool more = t + (NBUF - 1) < nit;        // a K-tile is left to prefetch
+        bf16x8 af[2][4], bfr[4];
+#pragma unroll
+        for (int p = 0; p < P; ++p) {
+            // phase -> (pair of 32-row blocks, 32-column block): (0,0) (0,1) [(1,1) (1,0)]
+            const int ih = p >> 1;
+            const int jn = (p == 1 || p == 2) ? 1 : 0;
+            // ---- load segment
+            if (p == 0 || p == 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g)
+                        af[i][g] = *reinterpret_cast<const bf16x8*>(bb + aBase + (ih * 2 + i) * 4096 + koff[g]);
+            }
+            if (p != 2) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) bfr[g] = *reinterpret_cast<const bf16x8*>(bb + bBase + jn * 4096 + koff[g]);
+            }
+            if (more) {
+                if (p == 0) issue_b();
+                if (p == 1) { issue_a(); issue_next(); }
+            }
+            if (p == P - 1) {
+                // this wave's pieces of tile t + 1 have landed; with a 3-deep ring the NL pieces of tile t + 2 (issued in this
+                // K-tile's phases 0 and 1, P = 2) may stay in flight
+                if (NBUF == 3 && more) LBC_WAIT_VM(NL);
+                else LBC_WAIT_VM(0);
+            }
+            LBC_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            // ---- MFMA segment
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+                    acc[ih * 2 + i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][g], bfr[g], acc[ih * 2 + i][jn], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+            __builtin_amdgcn_s_barrier();
+        }
+        if (++buf == NBUF) buf = 0;
+    }
+    if (grp == 0) __builtin_amdgcn_s_barrier();        // every wave passes the same number of barriers
+
+    // ---- epilogue (as conv_igemm.hip): affine / bias / residual / ReLU, bf16 store, per-channel (sum, sum^2) partial row
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    __bf16* yout = static_cast<__bf16*>(a.y);
+    const __bf16* resid = static_cast<const __bf16*>(a.resid);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        float rv[16][NT];
+        if (resid) {        // fetched per 32-row block before its stores: inside the store loop every 2-byte load is waited for alone
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const size_t ob = (size_t)(m < a.M ? m : 0) * (size_t)a.K;
+#pragma unroll
+                for (int nj = 0; nj < NT; ++nj) rv[r][nj] = (float)resid[ob + (size_t)(n0 + wn * WTN + nj * 32 + l31)];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            if (m < a.M) {
+                const size_t ob = (size_t)m * (size_t)a.K;
+#pragma unroll
+                for (int nj = 0; nj < NT; ++nj) {
+                    const int col = n0 + wn * WTN + nj * 32 + l31;
+                    float v = acc[mi][nj][r];
+                    if (a.post_scale) v = v * a.post_scale[col] + a.post_shift[col];
+                    if (a.bias) v += a.bias[col];
+                    if (resid) v += rv[r][nj];
+                    if (a.relu) v = fmaxf(v, 0.f);
+                    yout[ob + col] = (__bf16)v;
+                    s1[nj] += v;
+                    s2[nj] += v * v;
+                }
+            }
+        }
+    }
+    if (a.stats) {
+        float* red = reinterpret_cast<float*>(smem);   // [WM][2][BN]; every wave has left the main loop (last barrier above)
+#pragma unroll
+        for (int nj = 0; nj < NT; ++nj) {
+            s1[nj] += __shfl_xor(s1[nj], 32);
+            s2[nj] += __shfl_xor(s2[nj], 32);
+        }
+        if (kh == 0) {
+#pragma unroll
+            for (int nj = 0; nj < NT; ++nj) {
+                const int c = wn * WTN + nj * 32 + l31;
+                red[(wm * 2 + 0) * BN + c] = s1[nj];
+                red[(wm * 2 + 1) * BN + c] = s2[nj];
+            }
+        }
+        __syncthreads();
+        if (tid < BN) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+            dst[n0 + tid] = t1;
+            dst[a.K + n0 + tid] = t2;
+        }
+    }
+}
+
+struct GldsCfg { int bm, bn; };
+const GldsCfg kGldsCfg[3] = {{256, 256}, {256, 128}, {128, 256}};   // cfg ids kLbcCfgGlds + 0 / 1 / 2
+
+}  // namespace
+
+// Tile configuration for a launch, or -1 when the launch keeps conv_igemm.hip / conv_halo.hip.
+int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
+{
+    if (lbc_opt_on(kOptNoGemm256)) return -1;
+    if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || a.S != 1 || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
+    if (a.KH != a.KW || (a.KH != 3 && a.KH != 1) || a.P != (a.KH - 1) / 2) return -1;
+    if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || a.C % 64 || (mode != 0 && mode != 1)) return -1;
+    // one workgroup per CU: take a tile shape only when it fills at least three quarters of the 256 CUs
+    const long long fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 192;
+    if (a.K % 256 == 0) {
+        if ((long long)lbc_cdiv(a.M, 256) * (a.K / 256) >= fill) return kLbcCfgGlds + 0;
+        if ((long long)lbc_cdiv(a.M, 128) * (a.K / 256) >= fill) return kLbcCfgGlds + 2;
+        return -1;
+    }
+    if (a.K % 128 == 0 && (long long)lbc_cdiv(a.M, 256) * (a.K / 128) >= fill) return kLbcCfgGlds + 1;
+    return -1;
+}
+
+int lbc_conv_glds_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kGldsCfg[cfg - kLbcCfgGlds].bm); }
+
+int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
+{
+    LBC_REQUIRE(cfg >= kLbcCfgGlds && cfg < kLbcCfgGlds + 3, "conv_glds: bad cfg %d", cfg);
+    const GldsCfg c = kGldsCfg[cfg - kLbcCfgGlds];
+    LBC_REQUIRE(a.K % c.bn == 0 && a.C % 64 == 0 && a.KH * a.KW <= 9, "conv_glds: shape not tileable");
+    LBC_REQUIRE((long long)a.K * a.KH * a.KW * a.C < (1ll << 31), "conv_glds: weight tensor too large");
+    const void* zero = nullptr;
+    int rc = lbc_zero_page(&zero);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
+#define LBC_GL(BMv, BNv, WMv, WNv, NBv)                                                                                       \
+    do {                                                                                                                     \
+        if (mode == 0) hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 0>), grid, dim3(512), 0, s, a, zero);        \
+        else           hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 1>), grid, dim3(512), 0, s, a, zero);        \
+    } while (0)
+    if (cfg == kLbcCfgGlds + 0) LBC_GL(256, 256, 2, 4, 2);
+    else if (cfg == kLbcCfgGlds + 1) LBC_GL(256, 128, 4, 2, 3);
+    else LBC_GL(128, 256, 2, 4, 3);
+#undef LBC_GL
+    return lbc_check_launch("conv_glds");
+}

@@ -491,8 +491,18 @@ int lbc_weight_prep(const WeightPrepArgs& a, hipStream_t s)
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg)
 {
+    if (cfg >= kLbcCfgGlds) return lbc_conv_glds_rows(a, cfg);
     if (lbc_conv3x3_halo_eligible(a, 0)) return lbc_cdiv(a.M, 128);   // that kernel always works on 128-pixel tiles
     return lbc_cdiv(a.M, kCfgBM[cfg]);
+}
+
+int lbc_igemm_pick_for(const IgemmArgs& a, int mode)
+{
+    if (lbc_opt(kOptForceCfg) < 0 && !lbc_conv3x3_halo_eligible(a, mode)) {     // a forced tile policy pins conv_igemm.hip
+        const int g = lbc_conv_glds_pick(a, mode);
+        if (g >= 0) return g;
+    }
+    return lbc_igemm_pick(a.M, a.K);
 }
 
 int lbc_igemm_pick(long long M, int K)
@@ -507,12 +517,12 @@ int lbc_igemm_pick(long long M, int K)
 
 int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s)
 {
-    LBC_REQUIRE(cfg >= 0 && cfg < 3, "igemm: bad cfg %d", cfg);
+    LBC_REQUIRE(cfg >= 0 && cfg < kLbcCfgGlds + 3, "igemm: bad cfg %d", cfg);
     LBC_REQUIRE(a.C % (a.bf16 ? 64 : 32) == 0, "igemm: gathered channels %d not a multiple of %d", a.C, a.bf16 ? 64 : 32);
     LBC_REQUIRE(!a.bf16 || wmajor, "igemm: the bf16 path needs depth-contiguous weights (transpose first)");
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "igemm: bf16 activations need bf16 = 1");
     LBC_REQUIRE(!a.w_bf16 || a.act_bf16, "igemm: bf16 weight copies are used with bf16 activations only");
-    LBC_REQUIRE(a.K % kCfgBN[cfg] == 0, "igemm: output channels %d not a multiple of tile %d", a.K, kCfgBN[cfg]);
+    LBC_REQUIRE(cfg >= kLbcCfgGlds || a.K % kCfgBN[cfg] == 0, "igemm: output channels %d not a multiple of the tile", a.K);
     LBC_REQUIRE(a.KH * a.KW <= 16, "igemm: too many taps");
     LBC_REQUIRE(a.S == 1 || a.S == 2, "igemm: stride %d unsupported", a.S);
     LBC_REQUIRE(a.M > 0, "igemm: empty launch");
@@ -530,9 +540,18 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     const double nph = a.nphase == 4 ? 4.0 : 1.0;
     // bytes: the gathered tensor (a quarter of it per phase of a stride-2 transposed launch), the output (+ residual), the weights of the taps used
     const double in_elems = (double)a.N * a.H * a.W * a.C * ((mode == 1 && a.S == 2) ? nph / 4.0 : 1.0);
-    LbcProfScope prof(mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed", 2.0 * a.M * nph * a.K * (double)a.C * taps,
+    // profile class = kernel family + GEMM orientation
+    const bool halo = cfg < kLbcCfgGlds && wmajor && lbc_conv3x3_halo_eligible(a, mode);
+    const char* pname = cfg >= kLbcCfgGlds ? (mode == 0 ? "conv_glds_gather" : "conv_glds_transposed")
+                        : halo ? (mode == 0 ? "conv_halo_gather" : "conv_halo_transposed")
+                               : (mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed");
+    LbcProfScope prof(pname, 2.0 * a.M * nph * a.K * (double)a.C * taps,
                       (a.act_bf16 ? 2.0 : 4.0) * (in_elems + nph * (double)a.M * a.K * (a.resid ? 2 : 1)) +
                           (a.w_bf16 ? 2.0 : 4.0) * taps * nph * a.C * a.K, s);
+    if (cfg >= kLbcCfgGlds) {
+        LBC_REQUIRE(wmajor && lbc_conv_glds_pick(a, mode) >= 0, "igemm: launch not eligible for the 8-wave LDS-DMA kernel");
+        return lbc_conv_glds_launch(a, mode, cfg, s);
+    }
     if (wmajor && lbc_conv3x3_halo_eligible(a, mode)) return lbc_conv3x3_halo_launch(a, mode, s);
     switch (cfg) {
         case 0: return launch_cfg<128, 64>(a, wmajor, mode, s);

@@ -488,7 +488,7 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     const long long M = (long long)a.N * a.OH * a.OW;
     LBC_REQUIRE(M > 0 && M * a.CP < (1ll << 31) && (long long)a.N * a.H * a.W * a.CQ < (1ll << 31), "wgrad: bad tensor size");
     if (lbc_wgrad_tr_eligible(a)) {
-        LbcProfScope prof("conv_wgrad", 2.0 * M * a.CP * (double)a.CQ * 9, 2.0 * ((double)M * a.CP + (double)M * a.CQ) + 4.0 * (double)a.nsplit * a.CP * 9 * a.CQ, s);
+        LbcProfScope prof("conv_wgrad_tr", 2.0 * M * a.CP * (double)a.CQ * 9, 2.0 * ((double)M * a.CP + (double)M * a.CQ) + 4.0 * (double)a.nsplit * a.CP * 9 * a.CQ, s);
         return lbc_wgrad_tr_launch(a, s);
     }
     const int br = a.bf16 ? 64 : BR;

@@ -244,7 +244,7 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     a.M = N * c.OH * c.OW; a.LH = c.OH; a.LW = c.OW; a.ostep = 1;
     a.bf16 = bf16_; a.act_bf16 = act_bf16_;
     if (act_bf16_) { a.w = W(c.wn); a.w_bf16 = 1; }
-    const int cfg = lbc_igemm_pick(a.M, a.K);
+    const int cfg = lbc_igemm_pick_for(a, 0);
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? W(partial_) : nullptr;
     return lbc_igemm_launch(a, 1, 0, cfg, s);
@@ -550,7 +550,7 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     if (c.s == 1) {
         a.LH = c.H; a.LW = c.W; a.ostep = 1;
         a.M = N * c.H * c.W;
-        return lbc_igemm_launch(a, wmajor, 1, lbc_igemm_pick(a.M, a.K), s);
+        return lbc_igemm_launch(a, wmajor, 1, wmajor ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K), s);
     }
     a.LH = c.H / 2; a.LW = c.W / 2; a.ostep = 2;
     a.M = N * a.LH * a.LW;

@@ -45,6 +45,7 @@ enum LbcOpt {
     kOptDgradWt,           // LBC_DGRAD_WT (read when a network is created)
     kOptNoSideStream,      // LBC_NO_SIDE_STREAM (read when a network is created)
     kOptNoGemm256,         // LBC_NO_GEMM256: 1 = never use the 8-wave direct-to-LDS convolution (conv_glds.hip)
+    kOptGemm256MinTiles,   // LBC_GEMM256_MIN_TILES: minimum tile count for that kernel (default 192; tests set 1)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
@@ -122,7 +123,15 @@ struct WeightPrepArgs {
 int lbc_weight_prep(const WeightPrepArgs& a, hipStream_t s);
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg);   // number of M tiles (= stats rows) of a launch
-int lbc_igemm_pick(long long M, int K);
+int lbc_igemm_pick(long long M, int K);            // tile configuration 0..2 of conv_igemm.hip from the GEMM extents alone
+// tile configuration for a fully described launch: conv_glds.hip's (kLbcCfgGlds + 0..2) when eligible, else lbc_igemm_pick
+int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
+constexpr int kLbcCfgGlds = 3;
+int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256} or -1
+int lbc_conv_glds_rows(const IgemmArgs& a, int cfg);
+int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
+// 256 zero bytes in device memory (per device, allocated on first use): source of the zero padding of LDS-DMA staging
+int lbc_zero_page(const void** p);
 int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s);
 int lbc_weight_transpose(const float* w, float* wt, int A, int T, int B, hipStream_t s);   // w[A][T][B] -> wt[B][T][A]
 // 3x3 / stride-1 / pad-1, C = K = 64 launches on bf16 tensors + bf16 weight copies take the halo-staged,

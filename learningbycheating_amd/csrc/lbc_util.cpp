@@ -32,7 +32,7 @@ extern "C" const char* lbc_last_error(void) { return g_err; }
 namespace {
 const char* const kOptNames[kOptCount] = {
     "LBC_FORCE_CFG", "LBC_NO_HALO", "LBC_HALO_BLOCKS", "LBC_WGRAD_BIGM", "LBC_WGRAD_BLOCKS", "LBC_WGRAD_KB", "LBC_NO_WGRAD_TR",
-    "LBC_WGRAD_TR_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_FUSE_Z1", "LBC_DGRAD_WT", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256"};
+    "LBC_WGRAD_TR_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_FUSE_Z1", "LBC_DGRAD_WT", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256", "LBC_GEMM256_MIN_TILES"};
 struct OptTable {
     long long v[kOptCount];
     OptTable()
@@ -60,6 +60,22 @@ extern "C" long long lbc_config_get(const char* name)
         for (int i = 0; i < kOptCount; ++i)
             if (!strcmp(name, kOptNames[i])) return opts().v[i];
     return -1;
+}
+
+// ---- zero page ---------------------------------------------------------------------------
+int lbc_zero_page(const void** p)
+{
+    static void* pages[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { lbc_set_error("zero_page: bad device"); return LBC_ELAUNCH; }
+    if (!pages[dev]) {
+        // first use per device (a warm-up call, outside any stream capture): a synchronous 256-byte allocation, never freed
+        void* q = nullptr;
+        if (hipMalloc(&q, 256) != hipSuccess || hipMemset(q, 0, 256) != hipSuccess) { lbc_set_error("zero_page: allocation failed"); return LBC_ELAUNCH; }
+        pages[dev] = q;
+    }
+    *p = pages[dev];
+    return LBC_OK;
 }
 
 // ---- launch profiler -----------------------------------------------------------------

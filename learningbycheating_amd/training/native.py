@@ -55,6 +55,11 @@ class NativeTrainer:
     def step(self, x, speed, command, birdview=None, target=None, update=True):
         """x: student input (N,C,H,W) fp32; command one-hot (N,4); returns per-sample loss (device tensor)."""
         n = x.shape[0]
+        # the executor takes raw pointers to dense tensors; a permuted / sliced view is packed first (the reference's
+        # nn.Module accepts any strides)
+        x, speed, command = x.contiguous(), speed.contiguous(), command.contiguous()
+        if birdview is not None:
+            birdview = birdview.contiguous()
         if self.phase in (0, 1):
             if self.side is not None and self.overlap_teacher:
                 main = torch.cuda.current_stream(self.device)

@@ -3,9 +3,12 @@ of ImagePolicyModelSS at a given batch.  Prints ms and TFLOP/s per (layer, op, m
 operands with f32 tensors, 2 = bf16 operands and bf16 tensors, 3 = 2 + bf16 weight copies (fwd / dgrad).  Usage: python scripts/bench_ops.py [batch] [modes] [ops]
 """
 import ctypes
+import os
 import sys
 
 import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from learningbycheating_amd import _lib
 

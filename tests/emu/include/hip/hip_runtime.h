@@ -77,6 +77,7 @@ static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) {
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memmove(d, s, n); return hipSuccess; }
 static inline hipError_t hipMalloc(void** p, size_t n) { *p = malloc(n ? n : 1); return *p ? hipSuccess : hipErrorUnknown; }
 static inline hipError_t hipFree(void* p) { free(p); return hipSuccess; }
+static inline hipError_t hipMemset(void* p, int v, size_t n) { memset(p, v, n); return hipSuccess; }
 static inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 #define hipEventDisableTiming 0x2
 #define hipStreamNonBlocking 0x1
@@ -251,5 +252,14 @@ static inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 static inline double rsqrt(double x) { return 1.0 / sqrt(x); }
 static inline float __fdividef(float a, float b) { return a / b; }
 #define __builtin_amdgcn_s_setprio(x) ((void)0)
+// counted waits have nothing to wait for here (every emulated load completes at once); the raw workgroup barrier is the
+// fiber rendezvous.  NB: the emulator therefore checks indexing and arithmetic of a software pipeline, never its races.
+#define __builtin_amdgcn_s_waitcnt(x) ((void)0)
+#define __builtin_amdgcn_s_barrier() emu::sync_block()
+// global_load_lds_dwordx4 (LDS-DMA): lane l's 16 bytes land at the wave-uniform LDS base + 16 * l
+static inline void emu_global_load_lds(const void* g, void* lds_wave_base, unsigned size) {
+    memcpy(static_cast<char*>(lds_wave_base) + (size_t)emu::lane_id() * size, g, size);
+}
+#define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
 #define __builtin_amdgcn_readfirstlane(v) emu_wave_read((v), 0)

@@ -1,6 +1,8 @@
 """Per-kernel parity of the convolution family against torch CPU (conv2d / conv_transpose2d + autograd).
 Small shapes run the kernel sources under the CPU emulator (tests/emu); the gpu-marked cases run the
 real gfx950 library at the layer shapes of SURVEY.md appendix B.1 through the C ABI."""
+import ctypes
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -17,7 +19,10 @@ REAL = [pytest.param(c, marks=gpu) for c in [
     (8, 20, 48, 128, 128, 3, 1, 1),                                      # layer2
     (2, 20, 48, 128, 256, 3, 2, 1), (8, 10, 24, 256, 256, 3, 1, 1),      # layer3
     (2, 10, 24, 256, 512, 3, 2, 1), (32, 5, 12, 512, 512, 3, 1, 1), (2, 10, 24, 256, 512, 1, 2, 0),   # layer4
-    (3, 6, 6, 512, 512, 3, 1, 1)]]                                       # bird-view layer4 (6x6)
+    (3, 6, 6, 512, 512, 3, 1, 1),                                        # bird-view layer4 (6x6)
+    # BASELINE config 2's batch (64): long reductions, many split-K slabs, 128-row tiles
+    (64, 40, 96, 64, 64, 3, 1, 1), (64, 20, 48, 128, 128, 3, 1, 1), (64, 10, 24, 256, 256, 3, 1, 1), (64, 5, 12, 512, 512, 3, 1, 1),
+    (64, 40, 96, 64, 128, 3, 2, 1), (64, 20, 48, 128, 256, 1, 2, 0)]]
 
 
 def make(cfg, seed=0):
@@ -115,7 +120,8 @@ def test_conv_wgrad_fused_bn_on_load_and_accumulate(env):
 
 
 DEC_SMALL = [(2, 3, 4, 64, 64), (1, 5, 12, 128, 64)]
-DEC_REAL = [pytest.param(c, marks=gpu) for c in [(4, 5, 12, 640, 256), (4, 10, 24, 256, 128), (2, 20, 48, 128, 64), (2, 6, 6, 640, 256)]]
+DEC_REAL = [pytest.param(c, marks=gpu) for c in [(4, 5, 12, 640, 256), (4, 10, 24, 256, 128), (2, 20, 48, 128, 64), (2, 6, 6, 640, 256),
+                                                  (64, 5, 12, 640, 256), (64, 10, 24, 256, 128), (64, 20, 48, 128, 64)]]   # + BASELINE config 2's batch
 
 
 @pytest.mark.parametrize("cfg", DEC_SMALL + DEC_REAL)
@@ -503,3 +509,64 @@ def test_deconv_f32_large_tile_configs(env, cfg, cfgid, force_cfg):
     u.backward(dy)
     dx, dw = bwd(dy)
     assert relerr(dx, xn.grad) < 1e-5 and relerr(dw, w.grad) < 2e-5
+
+
+# ---- 8-wave LDS-DMA convolution (conv_glds.hip): bf16 tensors + bf16 weight copies, 256x256 / 256x128 / 128x256 tiles ------
+# (N, H, W, C, K, k, tiles-threshold that selects the configuration: K % 256 -> 256x256 unless its tile count is below the
+#  threshold, then 128x256; K = 128 -> 256x128)
+def _glds_cases():
+    out = []
+    for (N, H, W, C, K, k) in [(2, 9, 17, 64, 256, 3), (1, 12, 13, 128, 256, 3), (3, 7, 9, 64, 128, 3), (1, 10, 30, 64, 256, 1), (2, 16, 17, 128, 128, 3)]:
+        M = N * H * W
+        t256 = -(-M // 256) * (K // 256) if K % 256 == 0 else 0
+        out.append((N, H, W, C, K, k, 1))                       # largest eligible tile
+        if K % 256 == 0:
+            out.append((N, H, W, C, K, k, t256 + 1))            # 256x256 refused -> 128x256
+    return out
+
+
+GLDS_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, 3, 192), (64, 10, 24, 256, 256, 3, 192), (256, 5, 12, 512, 512, 3, 192),
+                                                   (64, 24, 24, 128, 128, 3, 192), (4, 20, 48, 128, 256, 3, 1), (5, 10, 24, 256, 512, 3, 9)]]
+
+
+@pytest.mark.parametrize("case", _glds_cases() + GLDS_REAL)
+def test_conv_glds_fwd_dgrad(env, case, lbc_config):
+    """forward with the epilogue variants (statistics; eval-mode BatchNorm fold + residual + ReLU) and the input gradient
+    (flipped taps, identity gradient added) against f32 convolutions of the bf16-rounded operands; ragged M tails, image
+    borders inside a tile, several images per tile, 1 .. 18 depth steps"""
+    dev, _ = env
+    from learningbycheating_amd import _lib
+    N, H, W, C, K, k, thr = case
+    lbc_config("LBC_GEMM256_MIN_TILES", thr)
+    p = (k - 1) // 2
+    x, w = make((N, H, W, C, K, k, 1, p), 90 + C + K)
+    x = rbf(x)
+    ref = F.conv2d(x, rbf(w), None, 1, p)
+    # 1. plain forward + statistics.  The kernel must actually be the one under test: its partial-row count is M / BM
+    rows = ctypes.c_int(0)
+    d = _lib.ConvDesc(N, H, W, C, K, k, k, 1, p, 0, 3, 0)
+    _lib.check(_lib.get().lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
+    M = N * H * W
+    assert rows.value in (-(-M // 256), -(-M // 128)) and (thr > 1 or rows.value == -(-M // 256))
+    y, st = Conv(dev).fwd(x, w, 1, p, stats=True, bf16=3)
+    assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(st[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), rtol=1e-3)
+    # 2. residual + ReLU epilogue
+    g = torch.Generator().manual_seed(91)
+    r = rbf(torch.randn(ref.shape, generator=g))
+    y2, _ = Conv(dev).fwd(x, w, 1, p, resid=r, relu=1, bf16=3)
+    assert relerr(y2, F.relu(ref + r)) < 1e-4 + OUT_TOL[2]
+    # 3. input gradient (the transposed mode) with the identity gradient in the epilogue
+    if C % 128 == 0:
+        xg = x.clone().requires_grad_(True)
+        yy = F.conv2d(xg, rbf(w), None, 1, p)
+        dy = rbf(torch.randn(yy.shape, generator=g))
+        yy.backward(dy)
+        rr = rbf(torch.randn(x.shape, generator=g))
+        dx = Conv(dev).dgrad(dy, w, H, W, 1, p, resid=rr, bf16=3, transposed=True)
+        assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
+    # 4. A/B: the generic kernel on the same launch gives the same result up to summation order
+    lbc_config("LBC_NO_GEMM256", 1)
+    y3, _ = Conv(dev).fwd(x, w, 1, p, bf16=3)
+    assert relerr(y, y3) < 2.0 ** -7
