@@ -1,5 +1,5 @@
 // 3x3 / 1x1 stride-1 convolution (forward and input gradient) for bf16 tensors + bf16 weight copies on gfx950, as an
-// implicit GEMM on 256 x 256 / 256 x 128 / 128 x 256 output tiles with 8 waves per workgroup and LDS-DMA staging
+// implicit GEMM on 256 x 256 / 512 x 128 / 128 x 256 / 256 x 128 output tiles with 8 waves per workgroup and LDS-DMA staging
 // (global_load_lds_dwordx4): the wide residual layers (layer 2-4) of the ResNets at training batch sizes.
 // reference arithmetic: BasicBlock conv1 / conv2, bird_view/models/resnet.py:15-22,38-54, and their autograd.
 //
@@ -130,22 +130,26 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
 
     // the DMA stream walks K-tiles in order: (channel slab ci, tap ti), taps inner
     int is_ci = 0, is_ti = 0, is_buf = 0;
-    auto issue_a = [&]() {
+    // pieces 0 .. NB-1 = the weight tile, NB .. NL-1 = the activation tile; a K-tile's pieces are issued in two halves (the load
+    // segments of phases 0 and 1)
+    constexpr int NH = (NL + 1) / 2;
+    auto issue = [&](const int q0, const int q1) {
         const int r = is_ti / KW, s = is_ti - r * KW;
         const int shift = (MODE == 0 ? (r - PAD) * W + (s - PAD) : (PAD - r) * W + (PAD - s)) * C + is_ci * 64;
+        const int koffs = is_ti * C + is_ci * 64;
         char* base = smem + is_buf * BUF;
 #pragma unroll
-        for (int j = 0; j < NA; ++j) {
-            const bool ok = (amask[j] >> is_ti) & 1;
-            const __bf16* src = ok ? xin + (aoff[j] + shift + aseg[j]) : zero + (lane & 7) * 8;
-            lds_dma16(src, base + (wave * NA + j) * 1024);
+        for (int q = 0; q < NL; ++q) {
+            if (q < q0 || q >= q1) continue;
+            if (q < NB) {
+                lds_dma16(win + (boff[q] + koffs), base + TILE_A + (wave * NB + q) * 1024);
+            } else {
+                const int j = q - NB;
+                const bool ok = (amask[j] >> is_ti) & 1;
+                const __bf16* src = ok ? xin + (aoff[j] + shift + aseg[j]) : zero + (lane & 7) * 8;
+                lds_dma16(src, base + (wave * NA + j) * 1024);
+            }
         }
-    };
-    auto issue_b = [&]() {
-        const int koffs = is_ti * C + is_ci * 64;
-        char* base = smem + is_buf * BUF + TILE_A;
-#pragma unroll
-        for (int j = 0; j < NB; ++j) lds_dma16(win + (boff[j] + koffs), base + (wave * NB + j) * 1024);
     };
     auto issue_next = [&]() {
         if (++is_ti == T) { is_ti = 0; ++is_ci; }
@@ -153,9 +157,9 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
     };
 
     // ---- prologue: NBUF - 1 tiles in flight, tile 0 landed and visible
-    issue_a(); issue_b(); issue_next();
+    issue(0, NL); issue_next();
     if (NBUF == 3) {
-        if (nit > 1) { issue_a(); issue_b(); issue_next(); LBC_WAIT_VM(NL); }
+        if (nit > 1) { issue(0, NL); issue_next(); LBC_WAIT_VM(NL); }
         else LBC_WAIT_VM(0);
     } else {
         LBC_WAIT_VM(0);
@@ -186,8 +190,8 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
                 for (int g = 0; g < 4; ++g) bfr[g] = *reinterpret_cast<const bf16x8*>(bb + bBase + jn * 4096 + koff[g]);
             }
             if (more) {
-                if (p == 0) issue_b();
-                if (p == 1) { issue_a(); issue_next(); }
+                if (p == 0) issue(0, NH);
+                if (p == 1) { issue(NH, NL); issue_next(); }
             }
             if (p == P - 1) {
                 // this wave's pieces of tile t + 1 have landed; with a 3-deep ring the NL pieces of tile t + 2 (issued in this
@@ -276,8 +280,9 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
     }
 }
 
-struct GldsCfg { int bm, bn; };
-const GldsCfg kGldsCfg[3] = {{256, 256}, {256, 128}, {128, 256}};   // cfg ids kLbcCfgGlds + 0 / 1 / 2
+struct GldsCfg { int bm, bn; double eff; };
+// cfg ids kLbcCfgGlds + 0 .. 3; eff = measured relative MFMA efficiency of a full round of tiles (MI355X, batch 256)
+const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128, 256, 0.95}, {512, 128, 1.0}};
 
 }  // namespace
 
@@ -288,22 +293,29 @@ int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
     if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || a.S != 1 || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
     if (a.KH != a.KW || (a.KH != 3 && a.KH != 1) || a.P != (a.KH - 1) / 2) return -1;
     if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || a.C % 64 || (mode != 0 && mode != 1)) return -1;
-    // one workgroup per CU: take a tile shape only when it fills at least three quarters of the 256 CUs
+    // One workgroup per CU: a tile shape qualifies when it fills at least three quarters of the 256 CUs; among the shapes
+    // that do, the one with the best (round quantisation x per-shape efficiency) wins.
     const long long fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 192;
-    if (a.K % 256 == 0) {
-        if ((long long)lbc_cdiv(a.M, 256) * (a.K / 256) >= fill) return kLbcCfgGlds + 0;
-        if ((long long)lbc_cdiv(a.M, 128) * (a.K / 256) >= fill) return kLbcCfgGlds + 2;
-        return -1;
+    const long long forced = lbc_opt(kOptGemm256Cfg);       // tests / tuning: pin one shape
+    int best = -1;
+    double best_score = 0.0;
+    for (int i = 0; i < kLbcGldsCfgs; ++i) {
+        const GldsCfg& c = kGldsCfg[i];
+        if (a.K % c.bn) continue;
+        if (forced >= 0 && forced != i) continue;
+        const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn);
+        if (tiles < fill) continue;
+        const double score = c.eff * (double)tiles / (double)(((tiles + 255) / 256) * 256);
+        if (score > best_score) { best_score = score; best = i; }
     }
-    if (a.K % 128 == 0 && (long long)lbc_cdiv(a.M, 256) * (a.K / 128) >= fill) return kLbcCfgGlds + 1;
-    return -1;
+    return best < 0 ? -1 : kLbcCfgGlds + best;
 }
 
 int lbc_conv_glds_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kGldsCfg[cfg - kLbcCfgGlds].bm); }
 
 int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
 {
-    LBC_REQUIRE(cfg >= kLbcCfgGlds && cfg < kLbcCfgGlds + 3, "conv_glds: bad cfg %d", cfg);
+    LBC_REQUIRE(cfg >= kLbcCfgGlds && cfg < kLbcCfgGlds + kLbcGldsCfgs, "conv_glds: bad cfg %d", cfg);
     const GldsCfg c = kGldsCfg[cfg - kLbcCfgGlds];
     LBC_REQUIRE(a.K % c.bn == 0 && a.C % 64 == 0 && a.KH * a.KW <= 9, "conv_glds: shape not tileable");
     LBC_REQUIRE((long long)a.K * a.KH * a.KW * a.C < (1ll << 31), "conv_glds: weight tensor too large");
@@ -318,7 +330,8 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     } while (0)
     if (cfg == kLbcCfgGlds + 0) LBC_GL(256, 256, 2, 4, 2);
     else if (cfg == kLbcCfgGlds + 1) LBC_GL(256, 128, 4, 2, 3);
-    else LBC_GL(128, 256, 2, 4, 3);
+    else if (cfg == kLbcCfgGlds + 2) LBC_GL(128, 256, 2, 4, 3);
+    else LBC_GL(512, 128, 4, 2, 2);
 #undef LBC_GL
     return lbc_check_launch("conv_glds");
 }

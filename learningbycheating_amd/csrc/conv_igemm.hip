@@ -517,7 +517,7 @@ int lbc_igemm_pick(long long M, int K)
 
 int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s)
 {
-    LBC_REQUIRE(cfg >= 0 && cfg < kLbcCfgGlds + 3, "igemm: bad cfg %d", cfg);
+    LBC_REQUIRE(cfg >= 0 && cfg < kLbcCfgGlds + kLbcGldsCfgs, "igemm: bad cfg %d", cfg);
     LBC_REQUIRE(a.C % (a.bf16 ? 64 : 32) == 0, "igemm: gathered channels %d not a multiple of %d", a.C, a.bf16 ? 64 : 32);
     LBC_REQUIRE(!a.bf16 || wmajor, "igemm: the bf16 path needs depth-contiguous weights (transpose first)");
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "igemm: bf16 activations need bf16 = 1");

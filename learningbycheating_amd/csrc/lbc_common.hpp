@@ -46,6 +46,7 @@ enum LbcOpt {
     kOptNoSideStream,      // LBC_NO_SIDE_STREAM (read when a network is created)
     kOptNoGemm256,         // LBC_NO_GEMM256: 1 = never use the 8-wave direct-to-LDS convolution (conv_glds.hip)
     kOptGemm256MinTiles,   // LBC_GEMM256_MIN_TILES: minimum tile count for that kernel (default 192; tests set 1)
+    kOptGemm256Cfg,        // LBC_GEMM256_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
@@ -127,7 +128,8 @@ int lbc_igemm_pick(long long M, int K);            // tile configuration 0..2 of
 // tile configuration for a fully described launch: conv_glds.hip's (kLbcCfgGlds + 0..2) when eligible, else lbc_igemm_pick
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
-int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256} or -1
+constexpr int kLbcGldsCfgs = 4;
+int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128} or -1
 int lbc_conv_glds_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 // 256 zero bytes in device memory (per device, allocated on first use): source of the zero padding of LDS-DMA staging

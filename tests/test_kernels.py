@@ -511,33 +511,36 @@ def test_deconv_f32_large_tile_configs(env, cfg, cfgid, force_cfg):
     assert relerr(dx, xn.grad) < 1e-5 and relerr(dw, w.grad) < 2e-5
 
 
-# ---- 8-wave LDS-DMA convolution (conv_glds.hip): bf16 tensors + bf16 weight copies, 256x256 / 256x128 / 128x256 tiles ------
-# (N, H, W, C, K, k, tiles-threshold that selects the configuration: K % 256 -> 256x256 unless its tile count is below the
-#  threshold, then 128x256; K = 128 -> 256x128)
+# ---- 8-wave LDS-DMA convolution (conv_glds.hip): bf16 tensors + bf16 weight copies --------------------------------------------
+GLDS_BM = {0: 256, 1: 256, 2: 128, 3: 512}      # tile rows of LBC_GEMM256_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128
+
+
 def _glds_cases():
     out = []
-    for (N, H, W, C, K, k) in [(2, 9, 17, 64, 256, 3), (1, 12, 13, 128, 256, 3), (3, 7, 9, 64, 128, 3), (1, 10, 30, 64, 256, 1), (2, 16, 17, 128, 128, 3)]:
-        M = N * H * W
-        t256 = -(-M // 256) * (K // 256) if K % 256 == 0 else 0
-        out.append((N, H, W, C, K, k, 1))                       # largest eligible tile
-        if K % 256 == 0:
-            out.append((N, H, W, C, K, k, t256 + 1))            # 256x256 refused -> 128x256
+    for (N, H, W, C, K, k) in [(2, 9, 17, 64, 256, 3), (1, 12, 13, 128, 256, 3), (3, 7, 9, 64, 128, 3), (1, 10, 30, 64, 256, 1), (2, 16, 17, 128, 128, 3),
+                               (5, 9, 13, 128, 128, 3)]:
+        for cfgid in ((0, 2) if K % 256 == 0 else (1, 3)):
+            out.append((N, H, W, C, K, k, cfgid))
     return out
 
 
-GLDS_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, 3, 192), (64, 10, 24, 256, 256, 3, 192), (256, 5, 12, 512, 512, 3, 192),
-                                                   (64, 24, 24, 128, 128, 3, 192), (4, 20, 48, 128, 256, 3, 1), (5, 10, 24, 256, 512, 3, 9)]]
+# (cfg -1: the shape the cost model picks at the default tile-count threshold)
+GLDS_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, 3, -1), (64, 10, 24, 256, 256, 3, -1), (256, 5, 12, 512, 512, 3, -1),
+                                                   (64, 24, 24, 128, 128, 3, -1), (4, 20, 48, 128, 256, 3, 0), (5, 10, 24, 256, 512, 3, 2),
+                                                   (7, 20, 48, 128, 128, 3, 1), (7, 20, 48, 128, 128, 3, 3)]]
 
 
 @pytest.mark.parametrize("case", _glds_cases() + GLDS_REAL)
 def test_conv_glds_fwd_dgrad(env, case, lbc_config):
-    """forward with the epilogue variants (statistics; eval-mode BatchNorm fold + residual + ReLU) and the input gradient
-    (flipped taps, identity gradient added) against f32 convolutions of the bf16-rounded operands; ragged M tails, image
+    """forward with the epilogue variants (statistics; residual + ReLU) and the input gradient (flipped taps, identity
+    gradient added) against f32 convolutions of the bf16-rounded operands, for every tile shape; ragged M tails, image
     borders inside a tile, several images per tile, 1 .. 18 depth steps"""
     dev, _ = env
     from learningbycheating_amd import _lib
-    N, H, W, C, K, k, thr = case
-    lbc_config("LBC_GEMM256_MIN_TILES", thr)
+    N, H, W, C, K, k, cfgid = case
+    if cfgid >= 0:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+        lbc_config("LBC_GEMM256_CFG", cfgid)
     p = (k - 1) // 2
     x, w = make((N, H, W, C, K, k, 1, p), 90 + C + K)
     x = rbf(x)
@@ -547,7 +550,7 @@ def test_conv_glds_fwd_dgrad(env, case, lbc_config):
     d = _lib.ConvDesc(N, H, W, C, K, k, k, 1, p, 0, 3, 0)
     _lib.check(_lib.get().lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
     M = N * H * W
-    assert rows.value in (-(-M // 256), -(-M // 128)) and (thr > 1 or rows.value == -(-M // 256))
+    assert rows.value in ([-(-M // GLDS_BM[cfgid])] if cfgid >= 0 else [-(-M // b) for b in (128, 256, 512)]), (rows.value, M)
     y, st = Conv(dev).fwd(x, w, 1, p, stats=True, bf16=3)
     assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
     assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
