@@ -224,6 +224,28 @@ size_t lbc_stem_wgrad_workspace(int N, int H, int W, int C);
 int lbc_stem_wgrad(const void* xp, const void* dy, float* dw, void* workspace, int N, int H, int W, int C, int bf16,
                    lbc_stream_t stream);
 
+/* Device-side input pipeline on the dataset's uint8 frames (what the reference does per sample in CPU dataloader workers).
+ * lbc_birdview_crop_u8: the fixed crop of the stored 320 x 320 x 7 bird-view (reference image_lmdb.py:150-163: rows
+ *   [58:250], cols [64:256]); generic window copy src[N][SH][SW][C] -> dst[N][H][W][C].
+ * lbc_augment_rgb_u8: the "super_hard" colour augmentation recipe (reference bird_view/augmenter.py:227-279) on a batch
+ *   of RGB frames [N][H][W][3], in place; per-image parameters (operator order, magnitudes, seed) come from the host
+ *   (learningbycheating_amd/bird_view/augmenter.py), per-pixel randomness from a counter-based hash.  scratch: N*H*W*3
+ *   floats (needed when any image's sequence contains the blur). */
+typedef struct lbc_aug_params {
+    int order[8];                /* 0 blur, 1 gaussian noise, 2 coarse dropout, 3 dropout, 4 add, 5 multiply, 6 contrast */
+    int n_ops, blur_pos;         /* blur_pos = index of the blur in order[], n_ops if absent */
+    unsigned seed;
+    float blur_sigma;
+    float noise_scale; int noise_per_channel;
+    float coarse_p; int coarse_h, coarse_w, coarse_per_channel;
+    float dropout_p; int dropout_per_channel;
+    float add[3], multiply[3], contrast[3];
+} lbc_aug_params;
+int lbc_birdview_crop_u8(const unsigned char* src, unsigned char* dst, int N, int SH, int SW, int C, int y0, int x0, int H, int W,
+                         lbc_stream_t stream);
+int lbc_augment_rgb_u8(unsigned char* images, const lbc_aug_params* params_dev, float* scratch, int N, int H, int W, int any_blur,
+                       lbc_stream_t stream);
+
 /* Runtime options (A/B switches, tuning knobs, test hooks): names are the LBC_* environment variables that initialise the
  * table at load time; -1 = unset.  Options read when a network is created (LBC_NO_FUSE_Z1,
  * LBC_DGRAD_WT, LBC_NO_SIDE_STREAM) apply to networks created afterwards. */

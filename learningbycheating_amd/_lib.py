@@ -31,6 +31,13 @@ class HeadDesc(ctypes.Structure):
                 [(n, c_void_p * 4) for n in ("mean", "invstd", "gamma", "beta", "w", "bias", "pos_x", "pos_y")] + [("cmd", c_void_p)])
 
 
+class AugParams(ctypes.Structure):
+    _fields_ = [("order", c_int * 8), ("n_ops", c_int), ("blur_pos", c_int), ("seed", ctypes.c_uint), ("blur_sigma", c_float),
+                ("noise_scale", c_float), ("noise_pc", c_int), ("coarse_p", c_float), ("coarse_h", c_int), ("coarse_w", c_int),
+                ("coarse_pc", c_int), ("dropout_p", c_float), ("dropout_pc", c_int), ("add", c_float * 3), ("multiply", c_float * 3),
+                ("contrast", c_float * 3)]
+
+
 class AdamChunk(ctypes.Structure):
     _fields_ = [("p", c_void_p), ("g", c_void_p), ("m", c_void_p), ("v", c_void_p), ("n", c_int), ("pad", c_int)]
 
@@ -77,6 +84,8 @@ _SIGNATURES = {
     "lbc_stem_fwd": (c_int, [c_void_p] * 4 + [ctypes.POINTER(c_int)] + [c_int] * 5 + [c_void_p]),
     "lbc_stem_wgrad_workspace": (c_size_t, [c_int] * 4),
     "lbc_stem_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
+    "lbc_birdview_crop_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "lbc_augment_rgb_u8": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "lbc_config_set": (c_int, [c_char_p, ctypes.c_longlong]),
     "lbc_config_get": (ctypes.c_longlong, [c_char_p]),
     "lbc_profile_enable": (c_int, [c_int]),

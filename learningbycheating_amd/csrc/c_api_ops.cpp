@@ -242,4 +242,18 @@ int lbc_stem_wgrad(const void* xp, const void* dy, float* dw, void* workspace, i
     return lbc_splitk_reduce(sw.partial, sw.nsplit, (long long)64 * 49 * C, dw, 0.f, (hipStream_t)stream);
 }
 
+// ---- device-side input pipeline ------------------------------------------------------------------------------
+int lbc_birdview_crop_u8(const unsigned char* src, unsigned char* dst, int N, int SH, int SW, int C, int y0, int x0, int H, int W,
+                         lbc_stream_t stream)
+{
+    return lbc_crop_u8(src, dst, N, SH, SW, C, y0, x0, H, W, (hipStream_t)stream);
+}
+
+int lbc_augment_rgb_u8(unsigned char* images, const lbc_aug_params* params_dev, float* scratch, int N, int H, int W, int any_blur,
+                       lbc_stream_t stream)
+{
+    static_assert(sizeof(lbc_aug_params) == sizeof(AugParams), "augmentation parameter layout");
+    return lbc_augment_u8(images, reinterpret_cast<const AugParams*>(params_dev), scratch, N, H, W, any_blur, (hipStream_t)stream);
+}
+
 }  // extern "C"

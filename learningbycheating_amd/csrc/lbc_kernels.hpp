@@ -182,6 +182,22 @@ struct HeadBwdFinalizeArgs {
 int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s);
 int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s);
 
+// ---- device-side input pipeline (data.hip) ----------------------------------------------------------------
+enum { kAugBlur = 0, kAugNoise = 1, kAugCoarseDropout = 2, kAugDropout = 3, kAugAdd = 4, kAugMultiply = 5, kAugContrast = 6 };
+struct AugParams {               // one per image; layout = lbc_aug_params of include/lbc_hip.h
+    int order[8];                // operator ids in application order (n_ops valid entries)
+    int n_ops;
+    int blur_pos;                // index of kAugBlur in order[], or n_ops when the sequence has no blur
+    unsigned seed;               // per-image stream of the per-pixel hash
+    float blur_sigma;
+    float noise_scale; int noise_pc;
+    float cd_p; int cd_h, cd_w, cd_pc;
+    float do_p; int do_pc;
+    float add_v[3], mul_v[3], con_a[3];
+};
+int lbc_crop_u8(const unsigned char* src, unsigned char* dst, int N, int SH, int SW, int C, int y0, int x0, int H, int W, hipStream_t s);
+int lbc_augment_u8(unsigned char* img, const AugParams* params_dev, float* tmp, int N, int H, int W, int any_blur, hipStream_t s);
+
 // ---- losses (phase 0 / phase 1 / bird-view) -------------------------------------------
 struct LossArgs {
     const float* pred;           // student output, normalised [-1,1]

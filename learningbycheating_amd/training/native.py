@@ -52,8 +52,12 @@ class NativeTrainer:
         _lib.check(_lib.get().lbc_loss(kind, ctypes.byref(self.cam), _lib.ptr(pred), _lib.ptr(target), n, rows,
                                        1.0 / (n * self.world), _lib.ptr(self.loss), _lib.ptr(dpred), _lib.stream_for(pred)), "loss")
 
-    def step(self, x, speed, command, birdview=None, target=None, update=True):
-        """x: student input (N,C,H,W) fp32; command one-hot (N,4); returns per-sample loss (device tensor)."""
+    def step(self, x, speed, command, birdview=None, target=None, update=True, train_mode=True):
+        """x: student input, float32 (N,C,H,W) in [0,1] or the dataset's uint8 (N,H,W,C) frames; command one-hot (N,4);
+        returns the per-sample loss (device tensor).  update=False: forward + loss only.  train_mode=False: the student runs
+        in eval mode (running statistics, no buffer update) -- the reference's validation pass (train_image_phase1.py:162-165,256)."""
+        if not train_mode and update:
+            raise ValueError("an eval-mode step cannot update (backward through running-statistics BatchNorm is not implemented)")
         n = x.shape[0]
         # the executor takes raw pointers to dense tensors; a permuted / sliced view is packed first (the reference's
         # nn.Module accepts any strides)
@@ -70,7 +74,7 @@ class NativeTrainer:
             else:
                 t_sel, t_all = self.teng.forward(birdview, speed, command, False)
             self.last_teacher = (t_sel, t_all)
-        p_sel, p_all = self.eng.forward(x, speed, command, True)
+        p_sel, p_all = self.eng.forward(x, speed, command, bool(train_mode))
         if self.phase in (0, 1) and self.side is not None and self.overlap_teacher:
             torch.cuda.current_stream(self.device).wait_stream(self.side)      # the loss reads the teacher's waypoints
         d_sel = d_all = None

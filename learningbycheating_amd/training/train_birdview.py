@@ -11,7 +11,7 @@ import torch.distributed as dist
 
 from ..bird_view.models.birdview import BirdViewPolicyModelSS
 from ..bird_view.utils import bz_utils as bzu
-from ..bird_view.utils.datasets.synthetic import SyntheticFrames, loader
+from .data import make_loaders
 from ..bird_view.utils.train_utils import one_hot
 from ..parallel import broadcast_module
 from .native import NativeTrainer
@@ -27,7 +27,7 @@ def train_or_eval(trainer, data, is_train, config, is_first_epoch):
     tick = time.time()
     for i, (rgb_image, birdview, location, command, speed) in enumerate(data):
         command = one_hot(command).to(config["device"])
-        loss = trainer.step(birdview, speed, command, target=location.float().contiguous(), update=is_train and not is_first_epoch)
+        loss = trainer.step(birdview, speed, command, target=location.float().contiguous(), update=is_train and not is_first_epoch, train_mode=is_train)
         if (i % int(config["log_iterations"]) == 0) or (not is_train) or is_first_epoch:
             bzu.log.scalar(is_train=is_train, loss_mean=loss.mean().item())
         now = time.time()
@@ -50,11 +50,14 @@ def train(config):
             net.load_state_dict(torch.load(str(ckpts[-1]), map_location=device))
     broadcast_module(net)
     bs = config["data_args"]["batch_size"]
-    frames = SyntheticFrames(config["synthetic"], device, seed=0, rank=rank, world=world)
+    data_train, data_val = make_loaders(config, device, rank, world)
     trainer = NativeTrainer(net, None, bs, (7, 192, 192), device, phase="birdview", lr=config["optimizer_args"]["lr"], world_size=world)
     for epoch in range(int(config["max_epoch"]) + 1):
         net.train()
-        train_or_eval(trainer, loader(frames, bs, config["iters_per_epoch"]), True, config, epoch == 0)
+        train_or_eval(trainer, data_train, True, config, epoch == 0)
+        net.eval()                              # reference train_birdview.py:175-176: validation pass after every epoch
+        train_or_eval(trainer, data_val, False, config, epoch == 0)
+        net.train()
         if epoch in SAVE_EPOCHS and rank == 0:
             torch.save(net.state_dict(), str(Path(config["log_dir"]) / ("model-%d.th" % epoch)))
         rec = bzu.log.end_epoch()
@@ -83,8 +86,6 @@ def main(argv=None):
     parser.add_argument("--precision", choices=["fp32", "bf16", "bf16_mfma"], default="fp32",
                         help="fp32 = the reference arithmetic; bf16 = bf16 MFMA operands + bf16 activation storage, f32 master weights")
     parsed = parser.parse_args(argv)
-    if parsed.dataset_dir is not None:
-        raise SystemExit("the LMDB reader needs the lmdb/cv2 packages (not in this image); use --synthetic N")
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("training needs a ROCm GPU")

@@ -15,7 +15,7 @@ import torch.distributed as dist
 from ..bird_view.models.birdview import BirdViewPolicyModelSS
 from ..bird_view.models.image import ImagePolicyModelSS
 from ..bird_view.utils import bz_utils as bzu
-from ..bird_view.utils.datasets.synthetic import SyntheticFrames, loader
+from .data import make_loaders
 from ..bird_view.utils.train_utils import one_hot
 from ..parallel import broadcast_module
 from .native import NativeTrainer, camera_struct
@@ -33,7 +33,7 @@ def train_or_eval(trainer, data, is_train, config, is_first_epoch):
     tick = time.time()
     for i, (rgb_image, birdview, location, command, speed) in enumerate(data):
         command = one_hot(command).to(config["device"])
-        loss = trainer.step(rgb_image, speed, command, birdview=birdview, update=is_train and not is_first_epoch)
+        loss = trainer.step(rgb_image, speed, command, birdview=birdview, update=is_train and not is_first_epoch, train_mode=is_train)
         if (i % int(config["log_iterations"]) == 0) or (not is_train) or is_first_epoch:
             bzu.log.scalar(is_train=is_train, loss_mean=loss.mean().item())
         now = time.time()
@@ -59,12 +59,15 @@ def train(config):
     broadcast_module(net)
     broadcast_module(teacher_net)
     bs = config["data_args"]["batch_size"]
-    frames = SyntheticFrames(config["synthetic"], device, seed=0, rank=rank, world=world)
+    data_train, data_val = make_loaders(config, device, rank, world)
     cam = camera_struct(**{k: float(v) for k, v in config["camera_args"].items()})
     trainer = NativeTrainer(net, teacher_net, bs, (3, 160, 384), device, phase=0, lr=config["optimizer_args"]["lr"], world_size=world, camera=cam)
     for epoch in range(int(config["max_epoch"]) + 1):
         net.train()
-        train_or_eval(trainer, loader(frames, bs, config["iters_per_epoch"]), True, config, epoch == 0)
+        train_or_eval(trainer, data_train, True, config, epoch == 0)
+        net.eval()                              # reference train_image_phase0.py:236-237: validation pass after every epoch
+        train_or_eval(trainer, data_val, False, config, epoch == 0)
+        net.train()
         if epoch in SAVE_EPOCHS and rank == 0:
             torch.save(net.state_dict(), str(Path(config["log_dir"]) / ("model-%d.th" % epoch)))
         rec = bzu.log.end_epoch()
@@ -90,8 +93,6 @@ def main(argv=None):
     parser.add_argument("--precision", choices=["fp32", "bf16", "bf16_mfma"], default="fp32",
                         help="fp32 = the reference arithmetic; bf16 = bf16 MFMA operands + bf16 activation storage, f32 master weights")
     parsed = parser.parse_args(argv)
-    if parsed.dataset_dir is not None:
-        raise SystemExit("the LMDB reader needs the lmdb/cv2/imgaug packages (not in this image); use --synthetic N")
     if parsed.pretrained:
         raise SystemExit("--pretrained downloads ImageNet weights (reference resnet.py:175-178); no network here")
     world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))

@@ -20,7 +20,7 @@ import torch.distributed as dist
 from ..bird_view.models.birdview import BirdViewPolicyModelSS
 from ..bird_view.models.image import ImagePolicyModelSS
 from ..bird_view.utils import bz_utils as bzu
-from ..bird_view.utils.datasets.synthetic import SyntheticFrames, loader
+from .data import make_loaders
 from ..bird_view.utils.train_utils import one_hot
 from ..parallel import broadcast_module
 from .native import NativeTrainer, camera_struct
@@ -63,7 +63,7 @@ def train_or_eval(trainer, data, is_train, config, is_first_epoch):
         command = one_hot(command).to(device)
         if is_train and config["speed_noise"] > 0:
             speed = torch.clamp(speed + torch.randn_like(speed) * config["speed_noise"], 0, 10)
-        loss = trainer.step(rgb_image, speed, command, birdview=birdview, update=is_train and not is_first_epoch)
+        loss = trainer.step(rgb_image, speed, command, birdview=birdview, update=is_train and not is_first_epoch, train_mode=is_train)
         should_log = (i % int(config["log_iterations"]) == 0) or (not is_train) or is_first_epoch
         if should_log:
             lm = loss.mean().item()          # device->host sync only when logging, as the reference (:207-221)
@@ -96,14 +96,17 @@ def train(config):
     broadcast_module(net)
     broadcast_module(teacher_net)
 
-    bs = config["data_args"]["batch_size"]
-    frames = SyntheticFrames(config["synthetic"], device, seed=0, rank=rank, world=world)
+    bs = config["data_args"]["batch_size"] * int(config["data_args"].get("batch_aug", 1) or 1)
+    data_train, data_val = make_loaders(config, device, rank, world)
     cam = camera_struct(**{k: float(v) for k, v in config["agent_args"]["camera_args"].items()})
     trainer = NativeTrainer(net, teacher_net, bs, (3, 160, 384), device, phase=1, lr=config["optimizer_args"]["lr"],
                             world_size=world, camera=cam)
     for epoch in range(int(config["max_epoch"]) + 1):
         net.train()
-        train_or_eval(trainer, loader(frames, bs, config["iters_per_epoch"]), True, config, epoch == 0)
+        train_or_eval(trainer, data_train, True, config, epoch == 0)
+        net.eval()                              # reference train_image_phase1.py:255-256: a validation pass after every epoch
+        train_or_eval(trainer, data_val, False, config, epoch == 0)
+        net.train()
         if epoch in SAVE_EPOCHS and rank == 0:
             torch.save(net.state_dict(), str(Path(config["log_dir"]) / ("model-%d.th" % epoch)))
         rec = bzu.log.end_epoch()
@@ -127,15 +130,11 @@ def main(argv=None):
     parser.add_argument("--speed_noise", type=float, default=0.0)
     parser.add_argument("--augment", choices=["medium", "medium_harder", "super_hard", "None", "custom"], default="super_hard")
     parser.add_argument("--lr", type=float, default=1e-4)
-    parser.add_argument("--synthetic", type=int, default=2048, help="number of device-resident synthetic frames")
+    parser.add_argument("--synthetic", type=int, default=2048, help="number of device-resident synthetic frames (used when no --dataset_dir is given)")
     parser.add_argument("--iters_per_epoch", type=int, default=1000)
     parser.add_argument("--precision", choices=["fp32", "bf16", "bf16_mfma"], default="fp32",
                         help="fp32 = the reference arithmetic; bf16 = bf16 MFMA operands + bf16 activation storage, f32 master weights")
     parsed = parser.parse_args(argv)
-    if parsed.dataset_dir is not None:
-        raise SystemExit("the LMDB reader needs the lmdb/cv2/imgaug packages (not in this image); use --synthetic N")
-    if parsed.batch_aug != 1:
-        raise SystemExit("--batch_aug > 1 belongs to the imgaug loader (reference train_image_phase1.py:183-189); not available with --synthetic")
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))

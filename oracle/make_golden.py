@@ -13,6 +13,7 @@ import json
 import os
 import sys
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -175,6 +176,23 @@ def main():
     lbo.mean().backward()
     assert torch.allclose(lb, lbo, rtol=1e-6, atol=1e-7) and torch.allclose(predb.grad, predbo.grad, rtol=1e-6, atol=1e-8)
     out["birdview_loss"] = {"gt": gt, "pred": predb.detach().clone(), "loss": lb.detach().clone(), "dpred": predb.grad.clone()}
+    # ---- dataset geometry: world_to_pixel of bird_view/utils/datasets/image_lmdb.py:22-30 (the module itself needs lmdb/cv2) ----
+    import ast as _ast
+    src = open(ref_shim.REFERENCE_ROOT + "/bird_view/utils/datasets/image_lmdb.py").read()
+    ns_w = {"np": np, "PIXELS_PER_METER": 5}
+    for node in _ast.parse(src).body:
+        if isinstance(node, _ast.FunctionDef) and node.name == "world_to_pixel":
+            exec(compile(_ast.Module([node], []), "image_lmdb.py", "exec"), ns_w)
+    rs = np.random.RandomState(9)
+    wargs, wout = [], []
+    for _ in range(16):
+        ox, oy = rs.uniform(-200, 200, 2)
+        ang = rs.uniform(-np.pi, np.pi)
+        x, y = ox + rs.uniform(-30, 30), oy + rs.uniform(-30, 30)
+        a = (x, y, ox, oy, np.cos(ang), np.sin(ang))
+        wargs.append(torch.tensor(a, dtype=torch.float64))
+        wout.append(torch.from_numpy(np.asarray(ns_w["world_to_pixel"](*a), dtype=np.float64)))
+    out["world_to_pixel"] = {"args": wargs, "out": wout}
     # ---- phase-2 resampling weight + batch_aug repeat vs the reference functions (training/phase2_utils.py) ----
     import ast
     src = open(ref_shim.REFERENCE_ROOT + "/training/phase2_utils.py").read()

@@ -1,0 +1,264 @@
+"""Data side of the hot path: the LMDB on-disk format, the dataset's sample contract, the
+device-side bird-view crop and the GPU colour augmentation.  Unmarked cases run the kernels under the CPU emulator."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from learningbycheating_amd import _lib
+from learningbycheating_amd.bird_view import augmenter as A
+from learningbycheating_amd.bird_view.utils.datasets import image_lmdb as D
+from learningbycheating_amd.bird_view.utils.datasets.lmdb_format import LmdbReader, write_lmdb
+
+gpu = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+# ---- LMDB format ---------------------------------------------------------------------------------------------------
+def test_lmdb_round_trip_inline_overflow_and_branch_pages(tmp_path):
+    rng = np.random.RandomState(0)
+    items = {"len": b"12"}
+    for i in range(12):                                   # the reference's keys: two of them far larger than a page
+        items["rgb_%04d" % i] = rng.randint(0, 256, 160 * 384 * 3, dtype=np.uint8).tobytes()
+        items["birdview_%04d" % i] = rng.randint(0, 256, 320 * 320 * 7, dtype=np.uint8).tobytes()
+        items["measurements_%04d" % i] = rng.randn(17).astype(np.float32).tobytes()
+        items["control_%04d" % i] = rng.randn(3).astype(np.float32).tobytes()
+    info = write_lmdb(str(tmp_path / "ep"), items)
+    assert info["overflow_pages"] == 12 * (-(-(16 + 184320) // 4096) + -(-(16 + 716800) // 4096))
+    r = LmdbReader(str(tmp_path / "ep"))
+    assert r.entries == len(items) and r.keys() == sorted(k.encode() for k in items)
+    for k, v in items.items():
+        assert bytes(r.get(k)) == v, k
+    assert r.get("rgb_0012") is None and r.get("") is None and r.get("zzz") is None and r.get(b"a") is None
+    assert int(bytes(r.get("len"))) == 12
+    r.close()
+    # three tree levels: enough small keys for more than one branch page
+    many = {"k%07d" % i: ("v%d" % i).encode() * (1 + i % 5) for i in range(60000)}
+    info = write_lmdb(str(tmp_path / "big"), many)
+    assert info["depth"] == 3 and info["branch_pages"] > 1
+    r = LmdbReader(str(tmp_path / "big"))
+    for i in list(range(0, 60000, 997)) + [0, 59999]:
+        k = "k%07d" % i
+        assert bytes(r.get(k)) == many[k]
+    assert r.get("k0060000") is None and len(r.keys()) == 60000
+
+
+def test_lmdb_meta_page_layout(tmp_path):
+    """byte-level checks of what an LMDB 0.9 reader parses first (mdb.c MDB_meta): magic, version, page size, root, entries"""
+    import struct
+    write_lmdb(str(tmp_path / "e"), {"a": b"1", "b": b"22"})
+    raw = open(tmp_path / "e" / "data.mdb", "rb").read()
+    for pg in (0, 1):
+        off = pg * 4096
+        pgno, pad, flags = struct.unpack_from("<QHH", raw, off)
+        assert pgno == pg and flags == 0x08
+        magic, version = struct.unpack_from("<II", raw, off + 16)
+        assert magic == 0xBEEFC0DE and version == 1
+        assert struct.unpack_from("<I", raw, off + 16 + 24)[0] == 4096                 # free DB md_pad = page size
+        depth, = struct.unpack_from("<H", raw, off + 16 + 24 + 48 + 6)
+        entries, root = struct.unpack_from("<QQ", raw, off + 16 + 24 + 48 + 32)
+        assert depth == 1 and entries == 2 and root == 2
+    assert struct.unpack_from("<Q", raw, 4096 + 16 + 24 + 96 + 8)[0] == 1              # meta 1 carries the newer txnid
+    flags, lower, upper = struct.unpack_from("<HHH", raw, 2 * 4096 + 10)
+    assert flags == 0x02 and lower == 16 + 4                                         # a leaf with two node pointers
+
+
+# ---- dataset -------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def dataset_dir(tmp_path_factory):
+    root = tmp_path_factory.mktemp("lbc_data")
+    D.write_synthetic_dataset(str(root), episodes=2, frames=40, seed=3)
+    return str(root)
+
+
+def test_world_to_pixel_matches_reference_fixture():
+    """fixture = the reference's own function (AST-extracted from bird_view/utils/datasets/image_lmdb.py:22-30 by oracle/make_golden.py)"""
+    g = torch.load(os.path.join(GOLD, "reference_outputs.pt"))["world_to_pixel"]
+    for args, want in zip(g["args"], g["out"]):
+        got = D.world_to_pixel(*[float(a) for a in args])
+        assert np.allclose(got, want.numpy(), rtol=1e-6, atol=1e-5)
+
+
+def test_image_dataset_sample_contract(dataset_dir):
+    ds = D.ImageDataset(os.path.join(dataset_dir, "train"))
+    assert len(ds) == 2 * (40 - 25)                                # every episode loses gap * n_step frames (image_lmdb.py:113)
+    rgb, bv, loc, cmd, speed = ds[7]
+    assert rgb.shape == (3, 160, 384) and rgb.dtype == torch.float32 and 0 <= rgb.min() and rgb.max() <= 1
+    assert bv.shape == (7, 192, 192) and set(np.unique(bv.numpy()).tolist()) <= {0.0, 1.0}
+    assert loc.shape == (5, 2) and loc.dtype == np.float64 and 1 <= cmd <= 4 and 0 < speed <= 10.5
+    # the sample is the stored bytes: rgb / 255 in CHW, the bird-view window rows 58:250, cols 64:256
+    r_u8, b_u8, loc2, cmd2, speed2 = ds.raw(7)
+    assert torch.equal(rgb, torch.from_numpy(r_u8.copy()).permute(2, 0, 1).float() / 255)
+    assert torch.equal(bv, torch.from_numpy(b_u8[58:250, 64:256].copy()).permute(2, 0, 1).float() / 255)
+    # waypoints: the ego vehicle drives forward, so future positions lie ahead (above the ego pixel row 260 - 58 - 10 = 192 of
+    # the crop ... in crop coordinates y decreases with distance) and get further away step by step
+    assert np.all(np.diff(loc2[:, 1]) < 0) and np.all(np.abs(loc2[:, 0] - 96) < 40)
+    env = ds.envs[ds.file_map[7]]
+    m = np.frombuffer(env.get("measurements_%04d" % ds.idx_map[7]), np.float32)
+    assert abs(speed2 - np.linalg.norm(m[5:8])) < 1e-6 and cmd2 == m[11]
+
+
+def test_device_loader_batches_crop_and_batch_aug(env, dataset_dir):
+    dev, _ = env
+    ds = D.ImageDataset(os.path.join(dataset_dir, "train"))
+    ld = D.DeviceLoader(ds, batch_size=3, samples=2, device=dev, seed=5)
+    ref_rng = np.random.RandomState(5 * 9973)
+    n = 0
+    for rgb, bv, loc, cmd, speed in ld:
+        idx = ref_rng.randint(len(ds), size=3)
+        assert rgb.shape == (3, 160, 384, 3) and rgb.dtype == torch.uint8 and bv.shape == (3, 192, 192, 7) and bv.dtype == torch.uint8
+        assert loc.shape == (3, 5, 2) and cmd.shape == (3,) and not cmd.is_cuda and speed.shape == (3,)
+        for i, j in enumerate(idx):
+            r_u8, b_u8, l, c, s = ds.raw(int(j))
+            assert torch.equal(rgb[i].cpu(), torch.from_numpy(r_u8.copy()))
+            assert torch.equal(bv[i].cpu(), torch.from_numpy(b_u8[58:250, 64:256].copy()))           # the device-side crop
+            assert torch.allclose(loc[i].cpu(), torch.from_numpy(l).float()) and float(cmd[i]) == float(c)
+        n += 1
+    assert n == 2
+    ld = D.DeviceLoader(ds, batch_size=2, samples=1, device=dev, batch_aug=3, seed=6)
+    rgb, bv, loc, cmd, speed = next(iter(ld))
+    assert rgb.shape[0] == 6 and torch.equal(rgb[0], rgb[2]) and torch.equal(bv[3], bv[5]) and not torch.equal(rgb[0], rgb[3])
+    assert torch.equal(cmd[:3], cmd[:1].expand(3))
+
+
+# ---- augmentation: numpy twin of csrc/data.hip ---------------------------------------------------------------------
+def _h32(x):
+    x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF
+    x ^= x >> 16; x = (x * 0x7feb352d) & 0xFFFFFFFF; x ^= x >> 15; x = (x * 0x846ca68b) & 0xFFFFFFFF; x ^= x >> 16
+    return x
+
+
+def _hash3(seed, a, b):
+    return _h32(np.uint64(seed) ^ _h32((np.asarray(a, np.uint64) * 0x9E3779B9 + _h32(np.asarray(b, np.uint64) + 0x85EBCA6B)) & 0xFFFFFFFF))
+
+
+def _u01(h):
+    return (h >> 8).astype(np.float32) * np.float32(1.0 / 16777216.0)
+
+
+def _clip(v):
+    return np.clip(np.rint(v), 0, 255).astype(np.float32)
+
+
+def numpy_augment(img, p):
+    """img (H,W,3) uint8, p = one lbc_aug_params: the operator sequence of csrc/data.hip in numpy"""
+    H, W, _ = img.shape
+    v = img.astype(np.float32)
+    pix = np.arange(H * W, dtype=np.uint64).reshape(H, W)
+    yy, xx = np.divmod(np.arange(H * W).reshape(H, W), W)
+    for k in range(p.n_ops):
+        op = p.order[k]
+        if op == A.BLUR:
+            if p.blur_sigma <= 1e-3:
+                continue
+            rad = min(int(4.0 * p.blur_sigma + 0.5), 16)
+            d = np.arange(-rad, rad + 1)
+            w = np.exp(-(d * d).astype(np.float32) * np.float32(0.5 / (p.blur_sigma * p.blur_sigma))).astype(np.float32)
+            w /= w.sum()
+
+            def refl(i, n):
+                i = np.where(i < 0, -i - 1, i)
+                i = np.where(i >= n, 2 * n - 1 - i, i)
+                return np.clip(i, 0, n - 1)
+            tmp = sum(w[j] * v[:, refl(np.arange(W) + d[j], W)] for j in range(len(d)))
+            v = _clip(sum(w[j] * tmp[refl(np.arange(H) + d[j], H)] for j in range(len(d))))
+        elif op == A.NOISE:
+            for c in range(3):
+                cc = c if p.noise_pc else 0
+                u1 = _u01(_hash3(p.seed, 0x100 + cc, pix)) + np.float32(0.5 / 16777216.0)
+                u2 = _u01(_hash3(p.seed, 0x110 + cc, pix))
+                z = np.sqrt(-2.0 * np.log(u1)) * np.cos(np.float32(6.28318530718) * u2)
+                v[..., c] = _clip(v[..., c] + np.float32(p.noise_scale) * z.astype(np.float32))
+        elif op == A.COARSE_DROPOUT:
+            cell = (yy * p.coarse_h // H) * p.coarse_w + xx * p.coarse_w // W
+            for c in range(3):
+                cc = c if p.coarse_pc else 0
+                v[..., c] = np.where(_u01(_hash3(p.seed, 0x200 + cc, cell)) < np.float32(p.coarse_p), 0, v[..., c])
+        elif op == A.DROPOUT:
+            for c in range(3):
+                cc = c if p.dropout_pc else 0
+                v[..., c] = np.where(_u01(_hash3(p.seed, 0x300 + cc, pix)) < np.float32(p.dropout_p), 0, v[..., c])
+        elif op == A.ADD:
+            v = _clip(v + np.array(list(p.add), np.float32))
+        elif op == A.MULTIPLY:
+            v = _clip(v * np.array(list(p.multiply), np.float32))
+        elif op == A.CONTRAST:
+            v = _clip(np.float32(128.0) + np.array(list(p.contrast), np.float32) * (v - np.float32(128.0)))
+    return v.astype(np.uint8)
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 36), pytest.param((16, 160, 384), marks=gpu)])
+def test_augmentation_kernels_match_the_numpy_twin(env, shape):
+    dev, _ = env
+    N, H, W = shape
+    rng = np.random.RandomState(11)
+    imgs = rng.randint(0, 256, (N, H, W, 3), dtype=np.uint8)
+    # a late-training recipe (every operator fires, large magnitudes) so that all code paths run
+    recipe = A.super_hard(40_000_000)
+    assert recipe.frequency == 1.0 and recipe.color == 1.0
+    recipe.color = 0.5
+    params, any_blur = recipe.sample(N, np.random.RandomState(12), H, W)
+    assert any_blur and all(params[i].n_ops == 7 for i in range(N))
+    got = A.BatchAugmenter(recipe).augment_batch(torch.from_numpy(imgs.copy()).to(dev), params=(params, any_blur)).cpu().numpy()
+    worst, nbad = 0, 0
+    for i in range(N):
+        want = numpy_augment(imgs[i], params[i])
+        diff = np.abs(got[i].astype(np.int32) - want.astype(np.int32))
+        # the blur's float summation order and the device's logf / cosf differ from numpy's by an ulp: a value at x.5 before
+        # rounding may land on the other side (+-1), and a +-1 that then passes through Multiply / Contrast grows by their factor
+        worst = max(worst, int(diff.max()))
+        nbad += int((diff > 0).sum())
+    assert worst <= 4 and nbad <= 0.02 * imgs.size, (worst, nbad)
+    # the operators did something, on every image
+    assert all(np.mean(got[i] != imgs[i]) > 0.5 for i in range(N))
+
+
+def test_augmentation_single_operators_are_exact(env):
+    dev, _ = env
+    rng = np.random.RandomState(13)
+    img = rng.randint(0, 256, (2, 12, 20, 3), dtype=np.uint8)
+    for op in (A.COARSE_DROPOUT, A.DROPOUT, A.ADD, A.MULTIPLY, A.CONTRAST):
+        arr = (_lib.AugParams * 2)()
+        for i in range(2):
+            p = arr[i]
+            p.n_ops, p.blur_pos, p.seed = 1, 1, 1000 + i
+            p.order[0] = op
+            p.coarse_p, p.coarse_h, p.coarse_w, p.coarse_pc = 0.3, 4, 5, i
+            p.dropout_p, p.dropout_pc = 0.25, i
+            for c in range(3):
+                p.add[c], p.multiply[c], p.contrast[c] = (-40.0, 13.0, 90.0)[c], (0.4, 1.0, 2.7)[c], (0.5, 1.5, 1.0)[c]
+        got = A.BatchAugmenter(None).augment_batch(torch.from_numpy(img.copy()).to(dev), params=(arr, False)).cpu().numpy()
+        for i in range(2):
+            assert np.array_equal(got[i], numpy_augment(img[i], arr[i])), op
+    # hand-checked values: Add / Multiply / Contrast saturate and round to nearest
+    one = np.array([[[[200, 100, 7]]]], dtype=np.uint8)
+    arr = (_lib.AugParams * 1)()
+    arr[0].n_ops, arr[0].blur_pos = 3, 3
+    arr[0].order[0], arr[0].order[1], arr[0].order[2] = A.ADD, A.MULTIPLY, A.CONTRAST
+    for c in range(3):
+        arr[0].add[c], arr[0].multiply[c], arr[0].contrast[c] = 60.0, 0.5, 2.0
+    got = A.BatchAugmenter(None).augment_batch(torch.from_numpy(one.copy()).to(dev), params=(arr, False)).cpu().numpy()
+    # (200+60 -> 255, 100+60 = 160, 67) * 0.5 -> (127.5 -> 128, 80, 33.5 -> 34) ; 128 + 2 (v - 128) -> (128, 32, 0)
+    assert got.reshape(-1).tolist() == [128, 32, 0]
+
+
+def test_augmentation_schedule_follows_the_reference_formulas():
+    """bird_view/augmenter.py:227-246 at two counters (hand-evaluated)"""
+    r0 = A.super_hard(0)
+    assert abs(r0.frequency - 0.05) < 1e-12 and r0.color == 0.0 and r0.ops[A.BLUR] == (0.0, 0.5) and r0.ops[A.ADD] == (-10.0, 10.0)
+    it = 3_200_000 / 32.0                                  # iteration 100000
+    r = A.super_hard(3_200_000)
+    assert r.frequency == 1.0 and abs(r.color - 1.0) < 1e-12 and abs(r.ops[A.BLUR][1] - 1.0) < 1e-12 and abs(r.ops[A.ADD][1] - 20.0) < 1e-12
+    assert abs(r.ops[A.MULTIPLY][1] - (1 + 2.5 * it / 200000.0)) < 1e-12 and abs(r.ops[A.MULTIPLY][0] - (1 - 0.91 * it / 500000.0)) < 1e-12
+    d = 0.198667 + (0.03856658 - 0.198667) / (1 + (it / 196416.6) ** 1.863486)
+    assert abs(r.ops[A.DROPOUT][1] - d) < 1e-12 and r.ops[A.COARSE_DROPOUT]["size_percent"] == (0.08, 0.2)
+    # sampling statistics: operators fire with probability `frequency`, in random order
+    rng = np.random.RandomState(0)
+    rec = A.super_hard(32 * 20000)                         # frequency 0.45
+    params, _ = rec.sample(4000, rng)
+    assert abs(np.mean([params[i].n_ops for i in range(4000)]) - 7 * rec.frequency) < 0.1
+    full, _ = A.super_hard(40_000_000).sample(400, rng)    # frequency 1: all seven fire, random_order shuffles them
+    assert all(sorted(full[i].order[k] for k in range(7)) == list(range(7)) for i in range(400))
+    assert len({full[i].order[0] for i in range(400)}) == 7 and len({full[i].blur_pos for i in range(400)}) == 7

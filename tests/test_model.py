@@ -775,3 +775,42 @@ def test_flat_gradient_and_adam_state_are_16_byte_aligned(env):
     for off, n in eng.grad_offsets.values():
         used[off:off + n] = True
     assert opt.exp_avg.cpu()[~used].abs().max().item() == 0.0
+
+
+@gpu
+def test_training_scripts_birdview_phase2_and_lmdb_dataset(env, tmp_path):
+    """the secondary scripts end to end with the reference's flag names: train_birdview (BASELINE config 4), phase 1 fed from
+    an LMDB dataset in the reference's on-disk format with GPU augmentation and --batch_aug, train_image_phase2 (config 5);
+    .th files in the reference's state_dict layout, validation pass logged"""
+    import json
+    from learningbycheating_amd.bird_view.utils.datasets.image_lmdb import write_synthetic_dataset
+    from learningbycheating_amd.training import train_birdview, train_image_phase0, train_image_phase1, train_image_phase2
+    data = write_synthetic_dataset(str(tmp_path / "data"), episodes=2, frames=48, seed=1)
+    common = ["--batch_size", "4", "--iters_per_epoch", "3", "--max_epoch", "1", "--log_iterations", "1"]
+    db = tmp_path / "bv"
+    train_birdview.main(["--log_dir", str(db), "--dataset_dir", data] + common)
+    sd = torch.load(str(db / "model-1.th"), map_location="cpu")
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(s)) for k, s in O.state_dict_layout("birdview", "resnet18")]
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    log = [json.loads(l) for l in open(db / "log.jsonl")]
+    assert all("val_loss_mean" in r and "train_loss_mean" in r for r in log), "every epoch logs a training and a validation pass"
+    # phase 0 on the LMDB dataset (teacher = the checkpoint just written), then phase 1 with augmentation + batch_aug
+    d0, d1 = tmp_path / "p0", tmp_path / "p1"
+    train_image_phase0.main(["--log_dir", str(d0), "--dataset_dir", data, "--teacher_path", str(db / "model-1.th"), "--lr", "1e-3",
+                             "--augment", "super_hard"] + [("12" if c == "3" else c) for c in common])
+    train_image_phase1.main(["--log_dir", str(d1), "--dataset_dir", data, "--ckpt", str(d0 / "model-1.th"), "--teacher_path", str(db / "model-1.th"),
+                             "--augment", "super_hard", "--batch_aug", "2"] + common)
+    sd1 = torch.load(str(d1 / "model-1.th"), map_location="cpu")
+    assert [(k, tuple(v.shape)) for k, v in sd1.items()] == [(k, tuple(s)) for k, s in O.state_dict_layout("image", "resnet34")]
+    assert all(torch.isfinite(v.float()).all() for v in sd1.values())
+    cfg = json.loads((d1 / "config.json").read_text())
+    assert cfg["data_args"]["batch_aug"] == 2 and cfg["data_args"]["dataset_dir"] == data
+    # phase 2: two short episodes on a synthetic replay buffer, model-1.th saved (SAVE_EPISODES)
+    d2 = tmp_path / "p2"
+    train_image_phase2.main(["--log_dir", str(d2), "--ckpt", str(d1 / "model-1.th"), "--teacher_path", str(db / "model-1.th"), "--batch_size", "4",
+                             "--synthetic", "16", "--max_episode", "2", "--epoch_per_episode", "1", "--log_iterations", "1"])
+    assert (d2 / "config.json").exists()
+    saved = sorted(p.name for p in d2.glob("model-*.th"))
+    assert saved, "phase 2 saved no checkpoint"
+    sd2 = torch.load(str(d2 / saved[0]), map_location="cpu")
+    assert list(sd2.keys()) == list(sd1.keys())
