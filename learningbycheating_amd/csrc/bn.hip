@@ -298,6 +298,12 @@ __global__ __launch_bounds__(256) void concat_velocity_k(const void* tv, const f
     }
 }
 
+__global__ __launch_bounds__(256) void copy_f32_k(const float* __restrict__ src, float* __restrict__ dst, long long n)
+{
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) dst[i] = src[i];
+}
+
 int grid_for(long long total4)
 {
     long long b = (total4 + 255) / 256;
@@ -307,6 +313,13 @@ int grid_for(long long total4)
 }
 
 }  // namespace
+
+int lbc_copy_f32(const float* src, float* dst, long long n, hipStream_t s)
+{
+    LBC_REQUIRE(src && dst && n > 0, "copy_f32: bad arguments");
+    hipLaunchKernelGGL(copy_f32_k, dim3((unsigned)grid_for(n)), dim3(256), 0, s, src, dst, n);
+    return lbc_check_launch("copy_f32");
+}
 
 int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s)
 {

@@ -328,10 +328,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
     const bool tr = train != 0;
     int rows = 0;
 
-    if (hipMemcpyAsync(W(cmd_), command, sizeof(float) * 4 * N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        lbc_set_error("net.forward: command copy failed");
-        return LBC_ELAUNCH;
-    }
+    LBC_TRY(lbc_copy_f32(command, W(cmd_), 4 * N, s));    // (kernels, not memcpy nodes: a captured forward is kernel nodes only)
     // image.py:71 / common.py:108-109: (x - mean) / std, fused into the NCHW -> padded NHWC repack
     NormConst nc;
     memset(&nc, 0, sizeof(nc));
@@ -466,11 +463,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
     ha.N = N; ha.OH = HH_; ha.OW = HW_; ha.act_bf16 = act_bf16_;
     ha.scratch = W(head_partial_);       // max_batch * 20 * 65 floats >= N * 16 * 20 * 4
     LBC_TRY(lbc_head_fwd(ha, s));
-    if (hipMemcpyAsync(pred_all, W(pred_all_), sizeof(float) * 40 * N, hipMemcpyDeviceToDevice, s) != hipSuccess) {
-        lbc_set_error("net.forward: output copy failed");
-        return LBC_ELAUNCH;
-    }
-    return LBC_OK;
+    return lbc_copy_f32(W(pred_all_), pred_all, 40 * N, s);
 }
 
 // ---------------------------------------------------------------------------------------

@@ -88,6 +88,7 @@ struct BnBwdApplyArgs {
 };
 int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
 
+int lbc_copy_f32(const float* src, float* dst, long long n, hipStream_t s);     // small device-to-device copies as a kernel
 int lbc_concat_velocity(const void* t, const float* vel, void* h, int N, int hw, int Ct, int Cv, int act_bf16, hipStream_t s);
 
 // ---- stem: input preparation, 7x7/2 convolution, BN+ReLU+maxpool -------------------

