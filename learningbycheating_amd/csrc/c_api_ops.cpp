@@ -5,6 +5,7 @@
 #include "lbc_hip.h"
 #include "lbc_kernels.hpp"
 #include <string.h>
+#include <algorithm>
 
 namespace {
 size_t up64(size_t n) { return (n + 63) / 64 * 64; }
@@ -227,7 +228,12 @@ int lbc_stem_fwd(const void* xp, const float* w, void* y, float* stats, int* sta
     return lbc_stem_fwd(st, (hipStream_t)stream);
 }
 
-size_t lbc_stem_wgrad_workspace(int N, int H, int W, int C) { return (size_t)lbc_stem_wgrad_split(N, H, W) * 64 * 49 * C * sizeof(float); }
+size_t lbc_stem_wgrad_workspace(int N, int H, int W, int C)
+{
+    // the larger of the two kernels' slab counts (the precision is not known here)
+    const int ns = std::max(lbc_stem_wgrad_split(N, H, W, C, 0), lbc_stem_wgrad_split(N, H, W, C, 1));
+    return (size_t)ns * 64 * 49 * C * sizeof(float);
+}
 
 int lbc_stem_wgrad(const void* xp, const void* dy, float* dw, void* workspace, int N, int H, int W, int C, int bf16,
                    lbc_stream_t stream)
@@ -237,7 +243,7 @@ int lbc_stem_wgrad(const void* xp, const void* dy, float* dw, void* workspace, i
     memset(&sw, 0, sizeof(sw));
     sw.xp = xp; sw.xp_bf16 = bf16 != 0; sw.dy = dy; sw.partial = static_cast<float*>(workspace);
     sw.N = N; sw.H = H; sw.W = W; sw.Cin = C; sw.act_bf16 = bf16 == 2; sw.bf16 = bf16 != 0;
-    sw.nsplit = lbc_stem_wgrad_split(N, H, W);
+    sw.nsplit = lbc_stem_wgrad_split(N, H, W, C, bf16 != 0);
     LBC_TRY(lbc_stem_wgrad(sw, (hipStream_t)stream));
     return lbc_splitk_reduce(sw.partial, sw.nsplit, (long long)64 * 49 * C, dw, 0.f, (hipStream_t)stream);
 }

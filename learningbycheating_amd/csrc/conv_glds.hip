@@ -47,7 +47,7 @@ __device__ __forceinline__ void lds_dma16(const void* g, void* lds_wave_base)
 }
 
 template <int BM, int BN, int WM, int WN, int NBUF, int MODE>
-__global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* zero_page)
+__global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* zero_page, const int diag)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
         for (int q = 0; q < NL; ++q) {
             if (q < q0 || q >= q1) continue;
             if (q < NB) {
-                lds_dma16(win + (boff[q] + koffs), base + TILE_A + (wave * NB + q) * 1024);
+                lds_dma16(diag == 2 ? zero + (lane & 7) * 8 : win + (boff[q] + koffs), base + TILE_A + (wave * NB + q) * 1024);
             } else {
                 const int j = q - NB;
-                const bool ok = (amask[j] >> is_ti) & 1;
+                const bool ok = ((amask[j] >> is_ti) & 1) && diag < 2;
                 const __bf16* src = ok ? xin + (aoff[j] + shift + aseg[j]) : zero + (lane & 7) * 8;
                 lds_dma16(src, base + (wave * NA + j) * 1024);
             }
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
     int buf = 0;
     for (int t = 0; t < nit; ++t) {
         const char* bb = smem + buf * BUF;
-        const bool more = t + (NBUF - 1) < nit;        // a K-tile is left to prefetch
+        const bool more = t + (NBUF - 1) < nit && diag != 1;   // a K-tile is left to prefetch (diag 1: timing run without the DMA stream)
         bf16x8 af[2][4], bfr[4];
 #pragma unroll
         for (int p = 0; p < P; ++p) {
@@ -280,6 +280,280 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Second generation of the same GEMM (default; LBC_GLDS_V1=1 keeps the kernel above for A/B runs).  Measured on the kernel
+// above at batch 256 (LBC_GLDS_DIAG runs): with the DMA stream removed a 256 x 256 launch still needs 68 of 77 us, the
+// 2-byte output stores cost 12 us and the barrier-separated fragment reads 14 us -- the matrix pipe waits on the phase
+// structure (two barriers per 8 MFMAs), not on memory.  Here
+//   * a K-tile is one filter tap x 32 channels (64-byte LDS rows, 16-byte slot XOR-ed with (row >> 2) & 3), four K-tiles
+//     in the ring: tile t + 3 is issued while tile t computes, so a DMA piece has two tile periods to land;
+//   * ONE barrier per K-tile (16 MFMAs per wave).  A wave's fragment reads for the next depth step are issued between the
+//     MFMAs of the current one (two register sets), so the barrier finds every wave with its next fragments in registers;
+//   * the output tile goes through LDS: bf16 rows, then 16-byte coalesced stores (was 128 two-byte stores per lane).
+// Synchronisation of K-tile t (buffer t & 3):
+//   first half :  reads (t, step 1) | 8 MFMAs (t, step 0);  s_waitcnt vmcnt: own pieces of tile t + 1 landed;  lgkmcnt(0);  s_barrier
+//   second half:  DMA pieces of tile t + 3 -> buffer (t - 1) & 3;  reads (t + 1, step 0) | 8 MFMAs (t, step 1)
+//   RAW: tile t + 1 is read only after the barrier of tile t, which every wave enters after its pieces of t + 1 have landed.
+//   WAR: buffer (t - 1) & 3 is refilled after the barrier of tile t; its last reads (tile t - 1, step 1) were retired by the
+//        lgkmcnt(0) in front of the barrier of tile t - 1.
+#define LBC_SG(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+template <int BM, int BN, int WM, int WN, int MODE, int DIAG = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
+__global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* zero_page)
+{
+    constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    static_assert(WM * WN == 8 && NT == 2 && (MT == 2 || MT == 4), "conv_glds2: wave tiling");
+    constexpr int NBUF = 4;
+    constexpr int TILE_A = BM * 64, TILE_B = BN * 64, BUF = TILE_A + TILE_B;     // bytes per K-tile: rows of 32 bf16
+    constexpr int NA = BM / 128, NB = BN / 128, NL = NA + NB;   // 1-KiB DMA pieces (16 rows) per wave per K-tile
+    static_assert(BM % 128 == 0 && BN % 128 == 0, "conv_glds2: tile extents");
+    constexpr int OROW = BN * 2 + 16;                           // staged output row: BN bf16 + 16 bytes (rows 4 apart on distinct banks)
+    constexpr int STAGE = BM * OROW;
+    constexpr int RED = WM * 2 * BN * 4;
+    constexpr int SMEM = NBUF * BUF > STAGE + RED ? NBUF * BUF : STAGE + RED;
+    static_assert(SMEM <= 160 * 1024, "conv_glds2: LDS");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int W = a.W, H = a.H, C = a.C, T = a.KH * a.KW, KW = a.KW, PAD = a.P;
+
+    const int ntn = a.K / BN;
+    int tile_id;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int mtile = tile_id / ntn;
+    const int m0 = mtile * BM;
+    const int n0 = (tile_id - mtile * ntn) * BN;
+
+    const __bf16* xin = static_cast<const __bf16*>(a.x);
+    const __bf16* win = static_cast<const __bf16*>(a.w);
+    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 3) * 8;
+
+    // ---- DMA roles: piece (wave * NA + j) of the A tile = rows 16 * piece .. + 15, lane -> (row = lane >> 2, segment = lane & 3)
+    int aoff[NA], amask[NA];
+#pragma unroll
+    for (int j = 0; j < NA; ++j) {
+        const int row = (wave * NA + j) * 16 + (lane >> 2);
+        const int m = m0 + row;
+        int bits = 0;
+        if (m < a.M) {
+            const int x = m % W;
+            const int y = (m / W) % H;
+            for (int t = 0; t < T; ++t) {
+                const int r = t / KW, s = t - r * KW;
+                const int dy = MODE == 0 ? r - PAD : PAD - r;
+                const int dx = MODE == 0 ? s - PAD : PAD - s;
+                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
+            }
+        }
+        amask[j] = bits;
+        // swizzle on the SOURCE: LDS slot (row, s) holds segment s ^ ((row >> 2) & 3)
+        aoff[j] = (m < a.M ? m : 0) * C + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+    }
+    int boff[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const int row = (wave * NB + j) * 16 + (lane >> 2);
+        boff[j] = (n0 + row) * (T * C) + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+    }
+    // ---- fragment roles: row l31 of a 32-row block, depth step g (16 channels), half kh: slot (2g + kh) ^ ((l31 >> 2) & 3)
+    const int swz = (l31 >> 2) & 3;
+    const int koff0 = ((0 + kh) ^ swz) << 4, koff1 = ((2 + kh) ^ swz) << 4;
+    const int aBase = (wm * WTM + l31) * 64;
+    const int bBase = TILE_A + (wn * WTN + l31) * 64;
+
+    const int cpt = C / 32;
+    const int nit = T * cpt;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // the DMA stream walks K-tiles in order: (32-channel slab, tap), taps inner (the nine shifted reads of a slab hit in L2)
+    int is_ti = 0, is_s = 0, is_buf = 0;
+    int is_shift = (MODE == 0 ? -(PAD * W + PAD) : PAD * W + PAD) * C;     // element offset of tap (0, 0), slab 0
+    int is_koffs = 0;
+    auto issue = [&]() {
+        char* base = smem + is_buf * BUF;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) lds_dma16(DIAG == 2 ? zero : win + (boff[j] + is_koffs), base + TILE_A + (wave * NB + j) * 1024);
+#pragma unroll
+        for (int j = 0; j < NA; ++j) {
+            const bool ok = ((amask[j] >> is_ti) & 1) && DIAG != 2;
+            const __bf16* src = ok ? xin + (aoff[j] + is_shift) : zero;
+            lds_dma16(src, base + (wave * NA + j) * 1024);
+        }
+        // next K-tile: tap (r, s) -> (r, s + 1) -> (r + 1, 0) -> next 32-channel slab, tap (0, 0).  (Walking the two 32-channel
+        // halves of a 128-byte line back to back instead was measured 4-6 % slower at batch 256.)
+        const int step = MODE == 0 ? C : -C;
+        ++is_ti; ++is_s;
+        is_shift += step; is_koffs += C;
+        if (is_s == KW) { is_s = 0; is_shift += step * (W - KW); }
+        if (is_ti == T) {
+            is_ti = 0;
+            is_shift += 32 - step * (W * a.KH);
+            is_koffs += 32 - T * C;
+        }
+        is_buf = (is_buf + 1) & (NBUF - 1);
+    };
+
+    bf16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
+#define LBC_RD(bufp, KOFF, FA, FB)                                                                                   \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *reinterpret_cast<const bf16x8*>((bufp) + aBase + i * 2048 + (KOFF)); \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) FB[j] = *reinterpret_cast<const bf16x8*>((bufp) + bBase + j * 2048 + (KOFF)); \
+    } while (0)
+#define LBC_MM(FA, FB)                                                                                               \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                               \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[i][j], 0, 0, 0);               \
+    } while (0)
+
+    // ---- prologue: up to three K-tiles in flight, tile 0 landed and visible, its first fragments in registers
+    issue();
+    if (nit > 1) issue();
+    if (nit > 2) issue();
+    if (nit > 2) LBC_WAIT_VM(2 * NL);
+    else if (nit > 1) LBC_WAIT_VM(NL);
+    else LBC_WAIT_VM(0);
+    __builtin_amdgcn_s_barrier();
+    LBC_RD(smem, koff0, fa0, fb0);
+
+    // ---- steady state: tiles 0 .. nit - 4 (each issues tile t + 3): straight-line body, no conditionals, the DMA address
+    //      arithmetic and the fragment reads spread between the MFMAs
+    int t = 0;
+    for (; t + 3 < nit; ++t) {
+        const char* bb = smem + (t & (NBUF - 1)) * BUF;
+        const char* bn = smem + ((t + 1) & (NBUF - 1)) * BUF;
+        LBC_RD(bb, koff1, fa1, fb1);
+        LBC_MM(fa0, fb0);
+#pragma unroll
+        for (int k = 0; k < MT + NT; ++k) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); }
+        LBC_SG(0x008, MT * NT - (MT + NT));
+        __builtin_amdgcn_sched_barrier(0);        // the MFMAs above stay above: nothing is scheduled across the barrier
+        LBC_WAIT_VM(NL);                          // own pieces of tile t + 1 landed (those of tile t + 2 stay in flight)
+        LBC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        LBC_RD(bn, koff0, fa0, fb0);
+        LBC_MM(fa1, fb1);
+        if (DIAG != 1) issue();
+#pragma unroll
+        for (int k = 0; k < MT * NT; ++k) {
+            LBC_SG(0x008, 1);
+            if (k < MT + NT) LBC_SG(0x100, 1);
+            LBC_SG(0x036, 10);                    // VALU | SALU | VMEM: the address arithmetic and DMA pieces of tile t + 3
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    // ---- the last (up to) three tiles: nothing left to issue
+    for (; t < nit; ++t) {
+        const char* bb = smem + (t & (NBUF - 1)) * BUF;
+        const char* bn = smem + ((t + 1) & (NBUF - 1)) * BUF;
+        LBC_RD(bb, koff1, fa1, fb1);
+        LBC_MM(fa0, fb0);
+#pragma unroll
+        for (int k = 0; k < MT + NT; ++k) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); }
+        LBC_SG(0x008, MT * NT - (MT + NT));
+        if (t + 2 < nit) LBC_WAIT_VM(NL);
+        else LBC_WAIT_VM(0);
+        LBC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        if (t + 1 < nit) LBC_RD(bn, koff0, fa0, fb0);
+        LBC_MM(fa1, fb1);
+    }
+#undef LBC_RD
+#undef LBC_MM
+
+    // ---- epilogue: affine / bias / residual / ReLU on the accumulators, per-channel (sum, sum^2), bf16 tile staged in LDS
+    LBC_WAIT_LGKM0();
+    __builtin_amdgcn_s_barrier();                      // every wave has left the main loop: the ring is free
+    float s1[NT], s2[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
+    const __bf16* resid = static_cast<const __bf16*>(a.resid);
+#pragma unroll
+    for (int mi = 0; mi < MT; ++mi) {
+        float rv[16][NT];
+        if (resid) {        // fetched per 32-row block before its use: inside the loop every 2-byte load is waited for alone
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const size_t ob = (size_t)(m < a.M ? m : 0) * (size_t)a.K;
+#pragma unroll
+                for (int nj = 0; nj < NT; ++nj) rv[r][nj] = (float)resid[ob + (size_t)(n0 + wn * WTN + nj * 32 + l31)];
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const bool live = m0 + row < a.M;
+#pragma unroll
+            for (int nj = 0; nj < NT; ++nj) {
+                const int cl = wn * WTN + nj * 32 + l31;
+                const int col = n0 + cl;
+                float v = acc[mi][nj][r];
+                if (a.post_scale) v = v * a.post_scale[col] + a.post_shift[col];
+                if (a.bias) v += a.bias[col];
+                if (resid) v += rv[r][nj];
+                if (a.relu) v = fmaxf(v, 0.f);
+                *reinterpret_cast<__bf16*>(smem + row * OROW + cl * 2) = (__bf16)v;
+                if (live) { s1[nj] += v; s2[nj] += v * v; }
+            }
+        }
+    }
+    float* red = reinterpret_cast<float*>(smem + STAGE);   // [WM][2][BN]
+    if (a.stats) {
+#pragma unroll
+        for (int nj = 0; nj < NT; ++nj) {
+            s1[nj] += __shfl_xor(s1[nj], 32);
+            s2[nj] += __shfl_xor(s2[nj], 32);
+        }
+        if (kh == 0) {
+#pragma unroll
+            for (int nj = 0; nj < NT; ++nj) {
+                const int c = wn * WTN + nj * 32 + l31;
+                red[(wm * 2 + 0) * BN + c] = s1[nj];
+                red[(wm * 2 + 1) * BN + c] = s2[nj];
+            }
+        }
+    }
+    __syncthreads();
+    {
+        __bf16* yout = static_cast<__bf16*>(a.y);
+        constexpr int SEG = BN / 8;                     // 16-byte segments per output row
+#pragma unroll 4
+        for (int idx = tid; idx < BM * SEG; idx += 512) {
+            const int row = idx / SEG, sg = idx - row * SEG;
+            const int m = m0 + row;
+            if (m < a.M)
+                *reinterpret_cast<bf16x8*>(yout + (size_t)m * (size_t)a.K + (size_t)(n0 + sg * 8)) =
+                    *reinterpret_cast<const bf16x8*>(smem + row * OROW + sg * 16);
+        }
+    }
+    if (a.stats && tid < BN) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+        float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+        dst[n0 + tid] = t1;
+        dst[a.K + n0 + tid] = t2;
+    }
+}
+#undef LBC_SG
+
 struct GldsCfg { int bm, bn; double eff; };
 // cfg ids kLbcCfgGlds + 0 .. 3; eff = measured relative MFMA efficiency of a full round of tiles (MI355X, batch 256)
 const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128, 256, 0.95}, {512, 128, 1.0}};
@@ -323,10 +597,33 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     int rc = lbc_zero_page(&zero);
     if (rc) return rc;
     const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
+    // LBC_GLDS_DIAG (timing experiments only, results are wrong): 1 = no DMA stream in the main loop, 2 = every DMA piece from the
+    // zero page, 3 = the activation pieces from the zero page
+    const int diag = lbc_opt(kOptGldsDiag) > 0 ? (int)lbc_opt(kOptGldsDiag) : 0;
+    if (!lbc_opt_on(kOptGldsV1)) {
+        LBC_REQUIRE(a.C % 32 == 0, "conv_glds: channel count");
+#define LBC_GL2(BMv, BNv, WMv, WNv)                                                                                          \
+    do {                                                                                                                     \
+        if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0>), grid, dim3(512), 0, s, a, zero);            \
+        else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1>), grid, dim3(512), 0, s, a, zero);            \
+    } while (0)
+        const long long dg = lbc_opt(kOptGldsDiag);
+        if (dg > 0 && cfg == kLbcCfgGlds + 0 && mode == 0) {        // 1 = no DMA stream in the steady state, 2 = every piece from the zero page
+            if (dg == 1) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 1>), grid, dim3(512), 0, s, a, zero);
+            else         hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 2>), grid, dim3(512), 0, s, a, zero);
+            return lbc_check_launch("conv_glds2");
+        }
+        if (cfg == kLbcCfgGlds + 0) LBC_GL2(256, 256, 2, 4);
+        else if (cfg == kLbcCfgGlds + 1) LBC_GL2(256, 128, 4, 2);
+        else if (cfg == kLbcCfgGlds + 2) LBC_GL2(128, 256, 2, 4);
+        else LBC_GL2(512, 128, 4, 2);
+#undef LBC_GL2
+        return lbc_check_launch("conv_glds2");
+    }
 #define LBC_GL(BMv, BNv, WMv, WNv, NBv)                                                                                       \
     do {                                                                                                                     \
-        if (mode == 0) hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 0>), grid, dim3(512), 0, s, a, zero);        \
-        else           hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 1>), grid, dim3(512), 0, s, a, zero);        \
+        if (mode == 0) hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 0>), grid, dim3(512), 0, s, a, zero, diag);        \
+        else           hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 1>), grid, dim3(512), 0, s, a, zero, diag);        \
     } while (0)
     if (cfg == kLbcCfgGlds + 0) LBC_GL(256, 256, 2, 4, 2);
     else if (cfg == kLbcCfgGlds + 1) LBC_GL(256, 128, 4, 2, 3);

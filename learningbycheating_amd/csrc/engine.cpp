@@ -74,7 +74,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
 {
     const size_t NB = (size_t)d.max_batch;
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
-    fuse_z1_ = !lbc_opt_on(kOptNoFuseZ1);
+    fuse_z1_ = (int)lbc_opt(kOptNoFuseZ1);
     dgrad_wt_ = lbc_opt_on(kOptDgradWt);
     side_allowed_ = !lbc_opt_on(kOptNoSideStream);
     bf16_ = d.precision >= 1;
@@ -112,7 +112,11 @@ Net::Net(const lbc_net_desc& d) : d_(d)
                 b.ds = make_conv(pre + ".downsample.0.weight", inpl, planes, h, w, 1, stride, 0);
                 b.bd = make_bn(pre + ".downsample.1", planes);
             }
-            b.z1 = fuse_z1_ ? 0 : alloc_act(NB * oh * ow * planes);
+            // z1 = relu(bn1(y1)): applied on load by its three consumers (never written), unless conv2 would then lose the LDS-DMA
+            // kernel (conv_glds.hip cannot transform what it stages): there one bn_apply pass (read + write 2 bytes per element)
+            // costs less than the register-staged convolution does (batch 256: layer 2 144 -> 95 + 29 us, layer 3 120 -> 72 + 14 us)
+            b.fuse_z1 = fuse_z1_ < 0 ? !conv_takes_glds(b.c2, (int)NB) : fuse_z1_ == 0;
+            b.z1 = b.fuse_z1 ? 0 : alloc_act(NB * oh * ow * planes);
             b.out = alloc_act(NB * oh * ow * planes);
             blocks_.push_back(b);
             inpl = planes; h = oh; w = ow;
@@ -181,7 +185,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     }
     for (int i = 0; i < 3; ++i)
         wg = std::max(wg, wg_need((int)NB, dec_[i].H, dec_[i].W, dec_[i].Cin, 2 * dec_[i].H, 2 * dec_[i].W, dec_[i].Cout, 3, 2, 1));
-    wg = std::max(wg, (size_t)lbc_stem_wgrad_split((int)NB, H0, W0) * 64 * 49 * Cin);
+    wg = std::max(wg, (size_t)lbc_stem_wgrad_split((int)NB, H0, W0, Cin, bf16_) * 64 * 49 * Cin);
     wg_partial_ = alloc(wg);
 
     wt_ = alloc((size_t)640 * 512 * 9);
@@ -248,6 +252,18 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? W(partial_) : nullptr;
     return lbc_igemm_launch(a, 1, 0, cfg, s);
+}
+
+// would a training forward of this convolution at batch N take conv_glds.hip when its input needs no transform on load?
+bool Net::conv_takes_glds(const Conv& c, int N) const
+{
+    if (!act_bf16_) return false;
+    IgemmArgs a;
+    memset(&a, 0, sizeof(a));
+    a.N = N; a.H = c.H; a.W = c.W; a.C = c.Cin; a.OH = c.OH; a.OW = c.OW; a.K = c.Cout;
+    a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p; a.M = N * c.OH * c.OW; a.LH = c.OH; a.LW = c.OW; a.ostep = 1;
+    a.bf16 = 1; a.act_bf16 = 1; a.w_bf16 = 1;
+    return lbc_conv_glds_pick(a, 0) >= 0;
 }
 
 int Net::weight_prep(hipStream_t s)
@@ -373,7 +389,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         LBC_TRY(conv_fwd(b.c1, x, N, tr, &rows, s));
         LBC_TRY(bn_finalize(b.b1, rows, pix, train, s));
         BnApplyArgs ap;
-        if (fuse_z1_) {
+        if (b.fuse_z1) {
             LBC_TRY(conv_fwd(b.c2, W(b.c1.y), N, tr, &rows, s, &b.b1));
         } else {
             memset(&ap, 0, sizeof(ap));
@@ -565,7 +581,7 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
     // out = relu(bn2(y2) + identity): mask by out, keep masked gradient in D for the identity path
     LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E, b.b2.C, s, nullptr, true));   // E = dY2
     LBC_TRY(fork(s));
-    if (fuse_z1_) {
+    if (b.fuse_z1) {
         LBC_TRY(conv_wgrad_pre(b.c2, W(b.c1.y), &b.b1, E, N, wstream(s)));
         LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                               // F = dZ1
         LBC_TRY(bn_backward(b.b1, F, W(b.c1.y), F, W(b.c1.y), pix, E, b.b1.C, s, &b.b1, true));   // E = dY1 (mask = bn1(y1) > 0)
@@ -753,7 +769,7 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
         StemWgradArgs sw;
         sw.xp = W(xp_); sw.xp_bf16 = bf16_; sw.dy = W(g0_); sw.partial = W(wg_partial_);
         sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels; sw.act_bf16 = act_bf16_; sw.bf16 = bf16_;
-        sw.nsplit = lbc_stem_wgrad_split(N, H0, W0);
+        sw.nsplit = lbc_stem_wgrad_split(N, H0, W0, d_.in_channels, bf16_);
         LBC_TRY(lbc_stem_wgrad(sw, s));
         LBC_TRY(lbc_splitk_reduce(sw.partial, sw.nsplit, (long long)64 * 49 * d_.in_channels, G(stem_w_), 0.f, s));
     }

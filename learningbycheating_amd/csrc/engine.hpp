@@ -47,6 +47,7 @@ struct Block {
     Conv c1, c2, ds;
     BN b1, b2, bd;
     bool has_ds = false;
+    bool fuse_z1 = true;     // conv2 / wgrad2 / bn1-backward read y1 with bn1(+ReLU) applied on load; z1 is never written
     size_t z1 = 0, out = 0;
 };
 
@@ -99,8 +100,9 @@ private:
     size_t wt_ = 0;
     bool bf16_ = false;      // precision >= 1: bf16 MFMA operands in the convolution family
     bool act_bf16_ = false;  // precision 2: activations and activation gradients are stored as bf16 in HBM
-    bool fuse_z1_ = true;    // conv2 / wgrad2 / bn1-backward read y1 with bn1(+ReLU) applied on load; z1 is never written
+    int fuse_z1_ = -1;       // LBC_NO_FUSE_Z1: 1 = every block writes z1, 0 = no block does, -1 = per block (Net::Net)
     int weight_prep(hipStream_t s);
+    bool conv_takes_glds(const Conv& c, int N) const;
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
                     float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr, bool join_before_apply = false);

@@ -41,12 +41,14 @@ enum LbcOpt {
     kOptNoWgradTr,         // LBC_NO_WGRAD_TR: 1 = never use the tap-fused weight gradient
     kOptWgradTrBlocks,     // LBC_WGRAD_TR_BLOCKS
     kOptHeadNoMfma,        // LBC_HEAD_NO_MFMA
-    kOptNoFuseZ1,          // LBC_NO_FUSE_Z1 (read when a network is created)
+    kOptNoFuseZ1,          // LBC_NO_FUSE_Z1 (read when a network is created): 1 = every block writes z1 = relu(bn1(y1)), 0 = none does
     kOptDgradWt,           // LBC_DGRAD_WT (read when a network is created)
     kOptNoSideStream,      // LBC_NO_SIDE_STREAM (read when a network is created)
     kOptNoGemm256,         // LBC_NO_GEMM256: 1 = never use the 8-wave direct-to-LDS convolution (conv_glds.hip)
     kOptGemm256MinTiles,   // LBC_GEMM256_MIN_TILES: minimum tile count for that kernel (default 192; tests set 1)
     kOptGemm256Cfg,        // LBC_GEMM256_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128)
+    kOptGldsDiag,          // LBC_GLDS_DIAG: timing experiments on conv_glds.hip (wrong results): see lbc_conv_glds_launch
+    kOptGldsV1,            // LBC_GLDS_V1: 1 = the first-generation (phase-barrier) kernel of conv_glds.hip
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

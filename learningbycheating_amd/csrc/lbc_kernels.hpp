@@ -115,7 +115,7 @@ struct StemWgradArgs {
     int act_bf16;
     int bf16;                    // 1: bf16 MFMA operands (f32 accumulation)
 };
-int lbc_stem_wgrad_split(int N, int H, int W);
+int lbc_stem_wgrad_split(int N, int H, int W, int Cin, int bf16);   // partial slabs of the kernel a (Cin, bf16) launch takes
 int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s);
 
 struct PoolFwdArgs {

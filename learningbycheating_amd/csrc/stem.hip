@@ -598,6 +598,150 @@ __global__ __launch_bounds__(256) void stem_wgrad_bf16_k(StemWgradArgs a, int ro
     }
 }
 
+// bf16 weight gradient of the RGB stem, ALL SEVEN filter rows per workgroup.  The kernel above gives every filter row its own
+// workgroup, so the seven workgroups of a pixel range each stage the same 64 x 64 dy tile (7 x 503 MB through L2 at batch 256,
+// two MFMAs per staged tile and wave: 664 us for 74 GFLOP).  Here a 64-pixel chunk stages dy once and the seven 21-column image
+// tiles next to it (one [24 columns][64 pixels] LDS tile per filter row; columns 21..23 and the fragment rows past them are
+// never-used padding: a garbage B column only reaches an output column that is not stored), 14 MFMAs per wave and chunk.  The two
+// wave pairs split the 64-pixel depth of a chunk and write separate partial slabs (slab = 2 * workgroup + depth half).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void stem_wgrad_rows_k(StemWgradArgs a, int rows_per_split)
+{
+    constexpr int CIN = 3, L = 21, QR = 24, BRH = 64, LD = BRH + 8, KB = 2;
+    constexpr bool ABF = Act<T>::kBf16;
+    using preg_t = typename std::conditional<ABF, bf16x4, f32x4>::type;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    __shared__ __attribute__((aligned(16))) __bf16 sP[2][64 * LD];
+    __shared__ __attribute__((aligned(16))) __bf16 sQ[2][(7 * QR + 8) * LD];      // + 8 rows: the last tile's fragment reads stay inside
+
+    const __bf16* xpad = static_cast<const __bf16*>(a.xp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int pt = wave & 1;                       // which 32 output channels
+    const int ks = wave >> 1;                      // which half of the chunk's pixels
+    const int OH = a.H / 2, OW = a.W / 2;
+    const int Hp = a.H + 6, Wp = a.W + 6;
+    const int M = a.N * OH * OW;
+    const int split = blockIdx.x;
+    const int mbeg = split * rows_per_split;
+    const int mend = mbeg + rows_per_split < M ? mbeg + rows_per_split : M;
+    const int nchunk = mend > mbeg ? (mend - mbeg + BRH - 1) / BRH : 0;
+    const T* dy = static_cast<const T*>(a.dy);
+
+    int pcg, ppg;
+    wgrad_tile_coord<16, KB>(tid, pcg, ppg);       // P: 16 channel groups x 16 pixel groups = 256 micro-tiles of 4 x 4
+    // Q: 7 rows x 6 column groups x 16 pixel groups = 672 micro-tiles; thread t takes t, t + 256, t + 512.  Within 16 lanes the
+    // pixel group takes 8 values and the column group 2: the 8-byte column writes of a lane group hit 16 distinct bank pairs.
+    int qr[3], qcg[3], qpg[3], qn[3], qy[3], qx[3];
+    bool qjob[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int job = tid + 256 * k;
+        qjob[k] = job < 7 * 96;
+        const int r = job / 96, u = job - r * 96;
+        const int lo = u & 15, hi = u >> 4;
+        qr[k] = qjob[k] ? r : 0;
+        qpg[k] = (lo & 7) + 8 * (hi & 1);
+        qcg[k] = (lo >> 3) + 2 * (hi >> 1);
+        const int m = mbeg + 4 * qpg[k];
+        qn[k] = m / (OH * OW);
+        const int rem = m - qn[k] * OH * OW;
+        qy[k] = rem / OW; qx[k] = rem - qy[k] * OW;
+    }
+
+    f32x16 acc[7];
+#pragma unroll
+    for (int r = 0; r < 7; ++r)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
+
+    preg_t rp[4];
+    unsigned rq[3][4][2];
+    bool pok[4], qok[3][4];
+    for (int ch = -1; ch < nchunk; ++ch) {
+        const bool more = ch + 1 < nchunk;
+        if (more) {
+            const int mc = mbeg + (ch + 1) * BRH;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int m = mc + 4 * ppg + i;
+                pok[i] = m < mend;
+                rp[i] = *reinterpret_cast<const preg_t*>(dy + (size_t)(pok[i] ? m : 0) * 64 + (size_t)(pcg * 4));
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                int n = qn[k], y = qy[k], x = qx[k];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int m = mc + 4 * qpg[k] + i;
+                    qok[k][i] = (m < mend) && qjob[k];
+                    const long long base = qok[k][i] ? (long long)((n * Hp + 2 * y + qr[k]) * Wp + 2 * x) * CIN + qcg[k] * 4 : 0;
+                    rq[k][i][0] = *reinterpret_cast<const unsigned*>(xpad + base);          // every offset is even
+                    rq[k][i][1] = *reinterpret_cast<const unsigned*>(xpad + base + 2);
+                    if (++x >= OW) { x = 0; if (++y >= OH) { y = 0; ++n; } }
+                }
+                qx[k] += BRH;
+                while (qx[k] >= OW) { qx[k] -= OW; ++qy[k]; }
+                while (qy[k] >= OH) { qy[k] -= OH; ++qn[k]; }
+            }
+        }
+        if (ch >= 0) {
+            const int buf = ch & 1;
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                const int gg = g + ks * 2;
+                const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sP[buf][(pt * 32 + l31) * LD + gg * 16 + kh * 8]);
+#pragma unroll
+                for (int r = 0; r < 7; ++r) {
+                    const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&sQ[buf][(r * QR + l31) * LD + gg * 16 + kh * 8]);
+                    acc[r] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[r], 0, 0, 0);
+                }
+            }
+        }
+        if (more) {
+            const int buf = (ch + 1) & 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                f32x4 col;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) col[i] = pok[i] ? (float)rp[i][c] : 0.f;
+                *reinterpret_cast<bf16x4*>(&sP[buf][(pcg * 4 + c) * LD + ppg * 4]) = __builtin_convertvector(col, bf16x4);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                if (!qjob[k]) continue;
+                unsigned v[4][2];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) { v[i][0] = qok[k][i] ? rq[k][i][0] : 0u; v[i][1] = qok[k][i] ? rq[k][i][1] : 0u; }
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    // column c of the micro-tile = bf16 half (c & 1) of dword (c >> 1) of each of the four pixels
+                    u32x2 w;
+                    if (c & 1) {
+                        w[0] = (v[0][c >> 1] >> 16) | (v[1][c >> 1] & 0xffff0000u);
+                        w[1] = (v[2][c >> 1] >> 16) | (v[3][c >> 1] & 0xffff0000u);
+                    } else {
+                        w[0] = (v[0][c >> 1] & 0xffffu) | (v[1][c >> 1] << 16);
+                        w[1] = (v[2][c >> 1] & 0xffffu) | (v[3][c >> 1] << 16);
+                    }
+                    *reinterpret_cast<u32x2*>(&sQ[buf][(qr[k] * QR + qcg[k] * 4 + c) * LD + qpg[k] * 4]) = w;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    float* out = a.partial + (size_t)(split * 2 + ks) * 64 * 7 * L;
+    if (l31 < L) {
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = pt * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                out[(size_t)co * (7 * L) + (size_t)(r * L + l31)] = acc[r][e];
+            }
+    }
+}
+
 }  // namespace
 
 int lbc_prep_input_u8(const unsigned char* img_nhwc, void* xp, int xp_bf16, int N, int C, int H, int W, const NormConst& nc, hipStream_t s)
@@ -648,8 +792,19 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
     return lbc_check_launch("stem_fwd");
 }
 
-int lbc_stem_wgrad_split(int N, int H, int W)
+// true when the launch takes stem_wgrad_rows_k (all seven filter rows per workgroup)
+static bool stem_wgrad_rows(int Cin, int bf16) { return bf16 && Cin == 3; }
+
+int lbc_stem_wgrad_split(int N, int H, int W, int Cin, int bf16)
 {
+    if (stem_wgrad_rows(Cin, bf16)) {
+        // workgroups of 64-pixel chunks, two per CU, at least 8 chunks each; every workgroup writes two slabs (one per depth half)
+        const long long chunks = ((long long)N * (H / 2) * (W / 2) + 63) / 64;
+        long long ng = chunks / 8;
+        if (ng > 512) ng = 512;
+        if (ng < 1) ng = 1;
+        return (int)(2 * ng);
+    }
     const long long chunks = ((long long)N * (H / 2) * (W / 2) + 31) / 32;
     long long ns = chunks / 8;
     if (ns > 256) ns = 256;
@@ -662,12 +817,23 @@ int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.Cin == 3 || a.Cin == 7, "stem_wgrad: Cin=%d unsupported", a.Cin);
     const long long M = (long long)a.N * (a.H / 2) * (a.W / 2);
+    LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem_wgrad: bf16 gradients need bf16 = 1");
+    LbcProfScope prof("stem_wgrad", 2.0 * M * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (double)M * 64), s);
+    if (stem_wgrad_rows(a.Cin, a.bf16)) {
+        LBC_REQUIRE(a.xp_bf16, "stem_wgrad: the bf16 kernels read a bf16 padded image");
+        LBC_REQUIRE(a.nsplit >= 2 && a.nsplit % 2 == 0, "stem_wgrad: nsplit %d (use lbc_stem_wgrad_split)", a.nsplit);
+        const int ng = a.nsplit / 2;
+        const long long chunks = (M + 63) / 64;
+        const int rows_per_split = (int)((chunks + ng - 1) / ng) * 64;
+#define LBC_K(T, d) hipLaunchKernelGGL((stem_wgrad_rows_k<T>), dim3((unsigned)ng), dim3(256), 0, s, a, rows_per_split)
+        LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 0);
+#undef LBC_K
+        return lbc_check_launch("stem_wgrad");
+    }
     const int br = a.bf16 ? 64 : 32;                         // pixels per chunk of the kernel
     const long long chunks = (M + br - 1) / br;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * br;
     const dim3 grid((unsigned)a.nsplit * 7);
-    LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem_wgrad: bf16 gradients need bf16 = 1");
-    LbcProfScope prof("stem_wgrad", 2.0 * M * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (double)M * 64), s);
     if (a.bf16) {
         LBC_REQUIRE(a.xp_bf16, "stem_wgrad: the bf16 kernels read a bf16 padded image");
 #define LBC_K(T, CI) hipLaunchKernelGGL((stem_wgrad_bf16_k<CI, T, __bf16>), grid, dim3(256), 0, s, a, rows_per_split)

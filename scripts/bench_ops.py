@@ -41,12 +41,15 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     modes = [int(c) for c in (sys.argv[2] if len(sys.argv) > 2 else "012")]
     ops = (sys.argv[3] if len(sys.argv) > 3 else "fwd,dgrad,wgrad").split(",")
+    only = sys.argv[4] if len(sys.argv) > 4 else ""          # substring filter on the layer name
     lib = _lib.get()
     dev = torch.device("cuda", 0)
     P = _lib.ptr
     st = None
     print("%-8s %-6s %4s %9s %9s" % ("layer", "op", "mode", "ms", "TFLOP/s"))
     for name, H, W, C, K, k, s, p in LAYERS:
+        if only and only not in name:
+            continue
         OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
         flops = 2.0 * N * OH * OW * K * C * k * k
         for mode in modes:

@@ -530,14 +530,17 @@ GLDS_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, 3, -1),
                                                    (7, 20, 48, 128, 128, 3, 1), (7, 20, 48, 128, 128, 3, 3)]]
 
 
+@pytest.mark.parametrize("gen", [2, 1])
 @pytest.mark.parametrize("case", _glds_cases() + GLDS_REAL)
-def test_conv_glds_fwd_dgrad(env, case, lbc_config):
+def test_conv_glds_fwd_dgrad(env, case, gen, lbc_config):
     """forward with the epilogue variants (statistics; residual + ReLU) and the input gradient (flipped taps, identity
     gradient added) against f32 convolutions of the bf16-rounded operands, for every tile shape; ragged M tails, image
     borders inside a tile, several images per tile, 1 .. 18 depth steps"""
     dev, _ = env
     from learningbycheating_amd import _lib
     N, H, W, C, K, k, cfgid = case
+    if gen == 1:
+        lbc_config("LBC_GLDS_V1", 1)       # the first-generation (phase-barrier) kernel, kept for A/B runs
     if cfgid >= 0:
         lbc_config("LBC_GEMM256_MIN_TILES", 1)
         lbc_config("LBC_GEMM256_CFG", cfgid)
