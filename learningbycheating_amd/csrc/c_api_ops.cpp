@@ -137,7 +137,7 @@ HeadWs head_ws(float* w, int N)
     HeadWs h;
     h.rowstat = w;
     h.s_partial = h.rowstat + up64((size_t)N * 40);
-    h.partial2 = h.s_partial + up64((size_t)N * 20 * 65);
+    h.partial2 = h.s_partial + up64((size_t)lbc_head_bwd_max_rows(N) * 20 * 65);
     h.coef = h.partial2 + up64((size_t)8 * 20 * 65);
     h.scratch = h.coef + up64((size_t)3 * 64);
     return h;
@@ -156,7 +156,7 @@ void head_args(const lbc_head_desc* d, HeadArgs& ha)
 size_t lbc_head_workspace(int N)
 {
     if (N < 1) return 0;
-    return (up64((size_t)N * 40) + up64((size_t)N * 20 * 65) + up64((size_t)8 * 20 * 65) + up64((size_t)3 * 64) +
+    return (up64((size_t)N * 40) + up64((size_t)lbc_head_bwd_max_rows(N) * 20 * 65) + up64((size_t)8 * 20 * 65) + up64((size_t)3 * 64) +
             up64((size_t)N * 16 * 20 * 4)) * sizeof(float);
 }
 
@@ -186,9 +186,9 @@ int lbc_head_bwd(const lbc_head_desc* d, const float* pred_all, const float* d_a
     LBC_TRY(lbc_head_bwd_reduce(hb, s));
     HeadBwdFinalizeArgs hf;
     memset(&hf, 0, sizeof(hf));
-    hf.s_partial = ws.s_partial; hf.rows = N; hf.count = (long long)N * d->OH * d->OW;
-    if (N > 8) {
-        LBC_TRY(lbc_partial_reduce(ws.s_partial, N, 20 * 65, ws.partial2, 8, s));
+    hf.s_partial = ws.s_partial; hf.rows = lbc_head_bwd_rows(hb.f); hf.count = (long long)N * d->OH * d->OW;
+    if (hf.rows > 8) {
+        LBC_TRY(lbc_partial_reduce(ws.s_partial, hf.rows, 20 * 65, ws.partial2, 8, s));
         hf.s_partial = ws.partial2; hf.rows = 8;
     }
     for (int b = 0; b < 4; ++b) {

@@ -153,7 +153,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     }
     head_stats_ = alloc(2 * 64);   // shared batch mean / invstd of the decoder output
     head_coef_ = alloc(3 * 64);
-    head_partial_ = alloc(NB * 20 * 65);
+    head_partial_ = alloc(std::max((size_t)lbc_head_bwd_max_rows((int)NB) * 20 * 65, NB * 16 * 20 * 4));   // backward partial rows; forward slice scratch
     pred_all_ = alloc(NB * 40);
     rowstat_ = alloc(NB * 40);
     cmd_ = alloc(NB * 4);
@@ -663,9 +663,9 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
         LBC_TRY(lbc_head_bwd_reduce(hb, s));
         HeadBwdFinalizeArgs hf;
         memset(&hf, 0, sizeof(hf));
-        hf.s_partial = W(head_partial_); hf.rows = N; hf.count = (long long)N * HH_ * HW_;
-        if (N > 8) {   // the finalize kernel is one workgroup walking the rows serially: hand it 8 pre-reduced rows
-            LBC_TRY(lbc_partial_reduce(W(head_partial_), N, 20 * 65, W(partial2_), 8, s));
+        hf.s_partial = W(head_partial_); hf.rows = lbc_head_bwd_rows(hb.f); hf.count = (long long)N * HH_ * HW_;
+        if (hf.rows > 8) {   // the finalize kernel is one workgroup walking the rows serially: hand it 8 pre-reduced rows
+            LBC_TRY(lbc_partial_reduce(W(head_partial_), hf.rows, 20 * 65, W(partial2_), 8, s));
             hf.s_partial = W(partial2_); hf.rows = 8;
         }
         for (int b = 0; b < 4; ++b) {

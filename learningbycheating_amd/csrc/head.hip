@@ -470,6 +470,262 @@ __global__ __launch_bounds__(256) void head_bwd_apply_k(HeadBwdArgs a)
     }
 }
 
+
+// ---- bf16 activations: the backward on v_mfma_f32_32x32x16_bf16 ---------------------------------------------------------------
+// The scalar kernels above spend 20 x 64 LDS-fed FMAs per pixel twice (0.43 + 0.29 ms at batch 256 for 0.25 GB of traffic).
+// Here a wave walks 32-pixel groups; the folded 20 x 64 projection (bf16 values, as in the forward) is stationary in registers.
+//   reduce:  logits[p][bs] = h Wf^T (A = h rows straight from HBM, as head_fwd_mfma_k) -> d[p][bs] in the accumulator layout, which
+//            IS the B-operand layout of the next product  H1^T[c][bs] += sum_p h^T[c][p] d[p][bs]  once the contraction index is
+//            permuted consistently: MFMA j's k-slot i of half kh stands for pixel (e & 3) + 8 (e >> 2) + 4 kh, e = 8 j + i.  The
+//            h^T fragments in that order come from the group's [pixel][channel] LDS image through ds_read_b64_tr_b16.
+//   apply:   logits^T[bs][p] = Wf h^T (operands swapped: same loads) -> d^T in the accumulator layout = B operand of
+//            dh^T[c][p] = sum_bs Wf^T[c][bs] d^T[bs][p] - c1'[c] - c2'[c] h^T[c][p];  the two BatchNorm-backward terms ride on
+//            the same MFMAs: -c1' through two constant-one k-slots (bf16 high + low part), -c2' h as a diagonal A operand
+//            against the h fragments already in registers.  A lane ends up with 4 consecutive channels of its pixel: 8-byte stores.
+// H1 is built from the bf16-rounded d; the mean S0 term head_bwd_finalize_k subtracts is corrected for that rounding (see the end of
+// the reduce kernel), while the stored S0 stays the exact f32 sum.
+constexpr int kHTS = 80;           // LDS row stride (elements) of a wave's 32 x 64 h image: as conv_wgrad_tr.hip's transpose reads
+
+struct HeadRowConst { float k0, gx, gy, cst; };
+
+// per (branch, step) row constants of image n: d = exp(logit_nobias + k0) * (gx px + gy py - cst)
+__device__ __forceinline__ void head_row_consts(const HeadBwdArgs& a, int n, const float* sBf, float* sRow /*[20][4]*/, int tid)
+{
+    if (tid < 20) {
+        const int b = tid / 5, st = tid - b * 5;
+        float gx, gy;
+        row_grad(a, n, b, st, gx, gy);
+        const size_t o2 = (((size_t)n * 4 + b) * 5 + st) * 2;
+        sRow[tid * 4 + 0] = sBf[b * 8 + st] - a.f.rowstat[o2] - logf(a.f.rowstat[o2 + 1]);
+        sRow[tid * 4 + 1] = gx;
+        sRow[tid * 4 + 2] = gy;
+        sRow[tid * 4 + 3] = gx * a.f.pred_all[o2] + gy * a.f.pred_all[o2 + 1];
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void head_bwd_reduce_mfma_k(HeadBwdArgs a, int S)
+{
+    __shared__ float sWf[4 * 320];
+    __shared__ float sBf[4 * 8];
+    __shared__ float sRow[20 * 4];
+    __shared__ __attribute__((aligned(16))) __bf16 sT[4][32 * kHTS];
+    __shared__ float sRed[4][20 * 65];
+    __shared__ float sDiff[4][20];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5, G1 = (lane >> 4) & 1, t16 = lane & 15;
+    const int n = blockIdx.x, slice = blockIdx.y;
+    const int HW = a.f.OH * a.f.OW;
+    for (int b = 0; b < 4; ++b) fold_branch(a.f, b, sWf + b * 320, sBf + b * 8, tid, 256);
+    __syncthreads();
+    head_row_consts(a, n, sBf, sRow, tid);
+    __syncthreads();
+    const bool colok = l31 < 20;
+    const int cb = colok ? l31 / 5 : 0, cs = colok ? l31 - 5 * cb : 0;
+    bf16x8 wb[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wb[g][j] = (__bf16)(colok ? sWf[cb * 320 + cs * 64 + g * 16 + kh * 8 + j] : 0.f);
+    const float k0 = colok ? sRow[l31 * 4 + 0] : 0.f, gx = colok ? sRow[l31 * 4 + 1] : 0.f;
+    const float gy = colok ? sRow[l31 * 4 + 2] : 0.f, cst = colok ? sRow[l31 * 4 + 3] : 0.f;
+    const float* posx = a.f.pos_x[cb];
+    const float* posy = a.f.pos_y[cb];
+    const __bf16* h = static_cast<const __bf16*>(a.f.h) + (size_t)n * HW * 64;
+    __bf16* tile = sT[wave];
+
+    f32x16 accH[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) accH[c][e] = 0.f;
+    float s0 = 0.f, s0r = 0.f;        // sum of d, and of the bf16-rounded d the MFMA consumes
+    const int ngroup = (HW + 31) / 32;
+    for (int grp = slice * 4 + wave; grp < ngroup; grp += 4 * S) {
+        const int pbase = grp * 32;
+        const int pl = pbase + l31 < HW ? pbase + l31 : HW - 1;
+        bf16x8 af[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) af[g] = *reinterpret_cast<const bf16x8*>(h + (size_t)pl * 64 + (size_t)(g * 16 + kh * 8));
+#pragma unroll
+        for (int g = 0; g < 4; ++g) *reinterpret_cast<bf16x8*>(&tile[l31 * kHTS + g * 16 + kh * 8]) = af[g];
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], wb[g], acc, 0, 0, 0);
+        bf16x8 db[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            float d = 0.f;
+            if (p < HW && colok) d = __expf(acc[e] + k0) * ((gx * posx[p] + gy * posy[p]) - cst);
+            const __bf16 dr = (__bf16)d;
+            db[e >> 3][e & 7] = dr;
+            s0 += d;
+            s0r += (float)dr;
+        }
+        // h^T fragments: rows = channels 32 cblk + l31, k-slot i of MFMA j = pixel 16 j + 8 (i >> 2) + 4 kh + (i & 3)
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = 16 * j + 4 * kh + (t16 >> 2);
+                const int col = 32 * c + 16 * G1 + (t16 & 3) * 4;
+                const bf16x4 a0 = lds_read_tr16(&tile[row * kHTS + col]);
+                const bf16x4 a1 = lds_read_tr16(&tile[(row + 8) * kHTS + col]);
+                const bf16x8 at = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                accH[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at, db[j], accH[c], 0, 0, 0);
+            }
+    }
+    // accH[c][e]: channel 32 c + (e & 3) + 8 (e >> 2) + 4 kh, column bs = l31; S0: the two half-waves hold different pixels
+    s0 += __shfl_xor(s0, 32);
+    s0r += __shfl_xor(s0r, 32);
+    if (colok) {
+#pragma unroll
+        for (int c = 0; c < 2; ++c)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) sRed[wave][l31 * 65 + 32 * c + (e & 3) + 8 * (e >> 2) + 4 * kh] = accH[c][e];
+        if (kh == 0) { sRed[wave][l31 * 65 + 64] = s0; sDiff[wave][l31] = s0r - s0; }
+    }
+    __syncthreads();
+    float* out = a.s_partial + ((size_t)n * S + slice) * (20 * 65);
+    // column 64 carries the exact S0 (dbias, dbeta and k1 are sums that vanish analytically); head_bwd_finalize_k forms
+    // S1 = invstd (H1 - mean S0), which must cancel against the ROUNDED d inside H1: fold mean (S0r - S0) into H1 here
+    for (int idx = tid; idx < 20 * 65; idx += 256) {
+        const int bs = idx / 65, c = idx - bs * 65;
+        float v = (sRed[0][idx] + sRed[1][idx]) + (sRed[2][idx] + sRed[3][idx]);
+        if (c < 64) v -= a.f.mean[0][c] * ((sDiff[0][bs] + sDiff[1][bs]) + (sDiff[2][bs] + sDiff[3][bs]));
+        out[idx] = v;
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void head_bwd_apply_mfma_k(HeadBwdArgs a, int S)
+{
+    __shared__ float sWf[4 * 320];
+    __shared__ float sBf[4 * 8];
+    __shared__ float sRow[20 * 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int n = blockIdx.x, slice = blockIdx.y;
+    const int HW = a.f.OH * a.f.OW;
+    for (int b = 0; b < 4; ++b) fold_branch(a.f, b, sWf + b * 320, sBf + b * 8, tid, 256);
+    __syncthreads();
+    head_row_consts(a, n, sBf, sRow, tid);
+    __syncthreads();
+    // A operand of logits^T: row bs = l31, 8 consecutive channels
+    const bool rowok = l31 < 20;
+    const int rb = rowok ? l31 / 5 : 0, rs = rowok ? l31 - 5 * rb : 0;
+    bf16x8 wa[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) wa[g][j] = (__bf16)(rowok ? sWf[rb * 320 + rs * 64 + g * 16 + kh * 8 + j] : 0.f);
+    // per accumulator row e of logits^T (bs = (e & 3) + 8 (e >> 2) + 4 kh; e < 12 covers every bs < 20): row constants
+    float ck0[12], cgx[12], cgy[12], ccst[12];
+    int ebr[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+        const int bs = (e & 3) + 8 * (e >> 2) + 4 * kh;
+        const bool ok = bs < 20;
+        ebr[e] = ok ? bs / 5 : 0;
+        ck0[e] = ok ? sRow[bs * 4 + 0] : -INFINITY;     // exp(-inf) = 0: the padding rows contribute nothing
+        cgx[e] = ok ? sRow[bs * 4 + 1] : 0.f;
+        cgy[e] = ok ? sRow[bs * 4 + 2] : 0.f;
+        ccst[e] = ok ? sRow[bs * 4 + 3] : 0.f;
+    }
+    // A operands of dh^T, rows = channels c = 32 cblk + l31:
+    //   wt[cblk][j]: k-slot i <-> bs(e = 8 j + i): Wf[bs][c]; two spare slots of half kh = 0 (e = 12, 13: bs 24, 25) carry -c1'
+    //   dg[cblk][g']: the diagonal -c2'[c] against the h fragment g = 2 cblk + g' (k-slot i <-> channel 16 g + 8 kh + i)
+    bf16x8 wt[2][2], dg[2][2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+        const int ch = 32 * c + l31;
+        const float iv = a.f.invstd[0][ch], mu = a.f.mean[0][ch];
+        const float c2p = a.chan_coef[64 + ch] * iv;
+        const float c1p = a.chan_coef[ch] - c2p * mu;
+        const __bf16 c1h = (__bf16)(-c1p);
+        const __bf16 c1l = (__bf16)(-c1p - (float)c1h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int e = 8 * j + i;
+                const int bs = (e & 3) + 8 * (e >> 2) + 4 * kh;
+                float v = 0.f;
+                if (bs < 20) v = sWf[(bs / 5) * 320 + (bs % 5) * 64 + ch];
+                __bf16 q = (__bf16)v;
+                if (bs == 24) q = c1h;
+                if (bs == 25) q = c1l;
+                wt[c][j][i] = q;
+            }
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dg[c][gp][i] = (__bf16)((16 * (2 * c + gp) + 8 * kh + i) == ch ? -c2p : 0.f);
+    }
+    const __bf16 one = (__bf16)1.f, zero = (__bf16)0.f;
+    const __bf16* h = static_cast<const __bf16*>(a.f.h) + (size_t)n * HW * 64;
+    __bf16* dh = static_cast<__bf16*>(a.dh) + (size_t)n * HW * 64;
+
+    const int ngroup = (HW + 31) / 32;
+    for (int grp = slice * 4 + wave; grp < ngroup; grp += 4 * S) {
+        const int pbase = grp * 32;
+        const bool live = pbase + l31 < HW;
+        const int pl = live ? pbase + l31 : HW - 1;
+        bf16x8 hb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) hb[g] = *reinterpret_cast<const bf16x8*>(h + (size_t)pl * 64 + (size_t)(g * 16 + kh * 8));
+        float px[4], py[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) { px[b] = a.f.pos_x[b][pl]; py[b] = a.f.pos_y[b][pl]; }
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[g], hb[g], acc, 0, 0, 0);
+        bf16x8 db[2];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+            const float d = __expf(acc[e] + ck0[e]) * ((cgx[e] * px[ebr[e]] + cgy[e] * py[ebr[e]]) - ccst[e]);
+            db[e >> 3][e & 7] = (__bf16)d;
+        }
+        db[1][4] = kh == 0 ? one : zero;      // e = 12, 13 of half 0: bs 24, 25 -- the constant-one slots of -c1' (high, low)
+        db[1][5] = kh == 0 ? one : zero;
+        db[1][6] = zero; db[1][7] = zero;
+        f32x16 o[2];
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) o[c][e] = 0.f;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wt[c][j], db[j], o[c], 0, 0, 0);
+#pragma unroll
+            for (int gp = 0; gp < 2; ++gp) o[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dg[c][gp], hb[2 * c + gp], o[c], 0, 0, 0);
+        }
+        // o[c][e]: channel 32 c + (e & 3) + 8 (e >> 2) + 4 kh of pixel l31: regs 4 q .. 4 q + 3 are 4 consecutive channels
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 2; ++c)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const f32x4 v = {o[c][4 * q], o[c][4 * q + 1], o[c][4 * q + 2], o[c][4 * q + 3]};
+                    *reinterpret_cast<bf16x4*>(dh + (size_t)(pbase + l31) * 64 + (size_t)(32 * c + 8 * q + 4 * kh)) = __builtin_convertvector(v, bf16x4);
+                }
+        }
+    }
+}
+
+// pixel-group slices per image of the MFMA backward kernels: about 1024 workgroups, at most one slice per 4 groups
+static int head_bwd_slices(int N, int HW)
+{
+    int S = (1024 + N - 1) / N;
+    if (S > 16) S = 16;
+    const int cap = ((HW + 31) / 32 + 3) / 4;
+    if (S > cap) S = cap;
+    return S < 1 ? 1 : S;
+}
+static bool head_bwd_mfma(const HeadArgs& f) { return f.act_bf16 && !lbc_opt_on(kOptHeadNoMfma); }
+
 }  // namespace
 
 int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
@@ -499,13 +755,19 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
     return rc;
 }
 
-int lbc_head_bwd_rows(int N) { return N; }
+int lbc_head_bwd_rows(const HeadArgs& f) { return head_bwd_mfma(f) ? f.N * head_bwd_slices(f.N, f.OH * f.OW) : f.N; }
+int lbc_head_bwd_max_rows(int max_batch) { return max_batch + 1024; }
 
 int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.f.mean[0] == a.f.mean[1] && a.f.mean[0] == a.f.mean[2] && a.f.mean[0] == a.f.mean[3],
                 "head backward requires training-mode (shared batch) statistics");
     LbcProfScope prof("head_bwd_reduce", 4.0 * a.f.N * a.f.OH * a.f.OW * 64.0 * 20, 4.0 * a.f.N * (double)a.f.OH * a.f.OW * 64, s);
+    if (head_bwd_mfma(a.f)) {
+        const int S = head_bwd_slices(a.f.N, a.f.OH * a.f.OW);
+        hipLaunchKernelGGL(head_bwd_reduce_mfma_k, dim3((unsigned)a.f.N, (unsigned)S), dim3(256), 0, s, a, S);
+        return lbc_check_launch("head_bwd_reduce");
+    }
 #define LBC_K(T, d) hipLaunchKernelGGL((head_bwd_reduce_k<T>), dim3((unsigned)a.f.N, 4), dim3(256), 0, s, a)
     LBC_DISPATCH_ACT(a.f.act_bf16, LBC_K, 0);
 #undef LBC_K
@@ -523,6 +785,11 @@ int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s)
 {
     const int HW = a.f.OH * a.f.OW;
     LbcProfScope prof("head_bwd_apply", 4.0 * a.f.N * (double)HW * 64.0 * 20, 8.0 * a.f.N * (double)HW * 64, s);
+    if (head_bwd_mfma(a.f)) {
+        const int S = head_bwd_slices(a.f.N, HW);
+        hipLaunchKernelGGL(head_bwd_apply_mfma_k, dim3((unsigned)a.f.N, (unsigned)S), dim3(256), 0, s, a, S);
+        return lbc_check_launch("head_bwd_apply");
+    }
 #define LBC_K(T, d) hipLaunchKernelGGL((head_bwd_apply_k<T>), dim3((unsigned)a.f.N, (unsigned)lbc_cdiv(HW, TP)), dim3(256), 0, s, a)
     LBC_DISPATCH_ACT(a.f.act_bf16, LBC_K, 0);
 #undef LBC_K

@@ -167,11 +167,12 @@ struct HeadBwdArgs {
     HeadArgs f;
     const float* d_all;          // [N][4][5][2] nullable
     const float* d_sel;          // [N][5][2] nullable
-    float* s_partial;            // [N][20*65] : per (branch,step): sum dlogit*h[c] (64) and sum dlogit
+    float* s_partial;            // [lbc_head_bwd_rows][20*65] : per (branch,step): sum dlogit*h[c] (64) and sum dlogit
     void* dh;                    // [N][HW][64] (same element type as h)
     const float* chan_coef;      // pass 2: [2][64] per-channel coefficients (see head.hip)
 };
-int lbc_head_bwd_rows(int N);
+int lbc_head_bwd_rows(const HeadArgs& f);      // rows of s_partial that lbc_head_bwd_reduce writes (N, or N x slices on the MFMA path)
+int lbc_head_bwd_max_rows(int max_batch);      // bound of the above over N <= max_batch
 int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s);
 struct HeadBwdFinalizeArgs {
     const float* s_partial; int rows; long long count;   // count = N*HW
