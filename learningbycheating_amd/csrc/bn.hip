@@ -179,27 +179,45 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
         const long long p0 = (long long)blockIdx.x * a.pix_per_block;
         long long p1 = p0 + a.pix_per_block;
         if (p1 > a.pixels) p1 = a.pixels;
-#pragma unroll 2
-        for (long long p = p0 + pl; p < p1; p += rl) {
-            const long long i = (p * cvn + cg) * V;
+        // batches of kU pixel steps with every load in front of the first store (g_out aliases dz in the executor)
+        constexpr int kU = 4;
+        auto one = [&](long long i, vec g, vec m, vec v) {
             if (OP == 0) {            // plain statistics of x: sum x, sum x^2
-                const vec v = Act<T>::ldv(xx + i);
                 s1 += v;
                 s2 += v * v;
             } else {                  // backward: g = dz * (mask > 0); sum g, sum g * xhat
-                vec g = Act<T>::ldv(dz + i);
                 if (mask) {
-                    vec m = Act<T>::ldv(mask + i);
                     if (a.mask_scale) m = m * msc + msh;
 #pragma unroll
                     for (int e = 0; e < V; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
                 }
                 if (g_out) Act<T>::stv(g_out + i, g);
                 s1 += g;
-                if (xx) {
-                    const vec v = Act<T>::ldv(xx + i);
-                    s2 += g * (v - mean) * inv;
+                if (xx) s2 += g * (v - mean) * inv;
+            }
+        };
+        long long p = p0 + pl;
+        for (; p + (kU - 1) * rl < p1; p += kU * rl) {
+            typename Act<T>::raw g[kU], m[kU], v[kU];
+#pragma unroll
+            for (int u = 0; u < kU; ++u) {
+                const long long i = ((p + u * rl) * cvn + cg) * V;
+                if (OP == 0) { v[u] = Act<T>::ldr(xx + i); g[u] = v[u]; m[u] = v[u]; }
+                else {
+                    g[u] = Act<T>::ldr(dz + i);
+                    m[u] = mask ? Act<T>::ldr(mask + i) : g[u];
+                    v[u] = xx ? Act<T>::ldr(xx + i) : g[u];
                 }
+            }
+#pragma unroll
+            for (int u = 0; u < kU; ++u) one(((p + u * rl) * cvn + cg) * V, Act<T>::cvt(g[u]), Act<T>::cvt(m[u]), Act<T>::cvt(v[u]));
+        }
+        for (; p < p1; p += rl) {
+            const long long i = (p * cvn + cg) * V;
+            if (OP == 0) { const vec v = Act<T>::ldv(xx + i); one(i, v, v, v); }
+            else {
+                const vec g = Act<T>::ldv(dz + i);
+                one(i, g, mask ? Act<T>::ldv(mask + i) : g, xx ? Act<T>::ldv(xx + i) : g);
             }
         }
     }

@@ -12,6 +12,9 @@ template <> struct Act<float> {
     static constexpr bool kBf16 = false;
     static constexpr int kVec = 4;                 // elements per 16-byte access
     using vec = f32x4;
+    using raw = f32x4;                             // 16 bytes as loaded: batched loads keep these and convert at use
+    static __device__ __forceinline__ raw ldr(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ vec cvt(raw r) { return r; }
     static __device__ __forceinline__ vec ldv(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
     static __device__ __forceinline__ void stv(float* p, vec v) { *reinterpret_cast<f32x4*>(p) = v; }
     static __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -23,6 +26,9 @@ template <> struct Act<__bf16> {
     static constexpr bool kBf16 = true;
     static constexpr int kVec = 8;
     using vec = f32x8;
+    using raw = bf16x8;
+    static __device__ __forceinline__ raw ldr(const __bf16* p) { return *reinterpret_cast<const bf16x8*>(p); }
+    static __device__ __forceinline__ vec cvt(raw r) { return __builtin_convertvector(r, f32x8); }
     static __device__ __forceinline__ vec ldv(const __bf16* p) { return __builtin_convertvector(*reinterpret_cast<const bf16x8*>(p), f32x8); }
     static __device__ __forceinline__ void stv(__bf16* p, vec v) { *reinterpret_cast<bf16x8*>(p) = __builtin_convertvector(v, bf16x8); }
     static __device__ __forceinline__ f32x4 ld4(const __bf16* p) { return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4); }
