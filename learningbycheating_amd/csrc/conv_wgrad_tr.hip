@@ -23,18 +23,23 @@
 
 namespace {
 
-constexpr int kRing = 328;      // ring rows: 64 + 2W + 2 live rows + 64 incoming, W <= 96
-constexpr int kRS = 80;         // LDS row stride in elements (160 B): spreads the 4 pixel rows of a transpose read over the banks
+// Ring rows: 64 + 2W + 2 live rows + 64 incoming.  LDS row stride: a transpose read serves 32 lanes per cycle = 4 pixel rows x 2
+// 16-channel halves x 8 banks; with 192-byte rows the eight 8-bank groups are distinct (rows at 0, 48, 32, 16 of 64 banks, the
+// second half + 8), with 160-byte rows row 3 of the second half lands on row 0 of the first (PMC: 45 % of the LDS cycles were
+// bank conflicts).  192-byte rows fit two workgroups per CU up to W = 48; the 96-wide layer-1 maps keep 160.
+constexpr int kRingWide = 328, kRsWide = 80;      // W <= 96
+constexpr int kRingNarrow = 232, kRsNarrow = 96;  // W <= 48
 
 // ALIGN = 8: W % 8 == 0 (a lane's 8-pixel group lies in one image row: whole-group / first-pixel / last-pixel masks).
 // ALIGN = 4: W % 4 == 0 (the 5 x 12 maps of layer 4): the same per 4-pixel half of the group (the second half may sit in
 // the next row).  ALIGN = 0: any W >= 8, every pixel gets its own flags.
-template <int ALIGN>
+template <int ALIGN, int kRS, int kRing>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_per_split)
 {
     constexpr int BRH = 64;
     __shared__ __attribute__((aligned(16))) __bf16 sP[2][BRH * kRS];
-    __shared__ __attribute__((aligned(16))) __bf16 sQ[kRing * kRS];
+    constexpr int kMirror = 24;                       // >= 18: see the tap loop
+    __shared__ __attribute__((aligned(16))) __bf16 sQ[(kRing + kMirror) * kRS];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wp = wave >> 1, wq = wave & 1;
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                 h = __builtin_convertvector(v, bf16x8);
             }
             *reinterpret_cast<bf16x8*>(&sQ[rel * kRS + seg * 8]) = h;
+            if (rel < kMirror) *reinterpret_cast<bf16x8*>(&sQ[(rel + kRing) * kRS + seg * 8]) = h;
         }
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -158,16 +164,8 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                 if (left[1]) a1l[0] = (__bf16)0.f;
                 if (right[1]) a1r[3] = (__bf16)0.f;
             }
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const int r = t / 3, s = t - 3 * r;
-                int row = base + 16 * g + 8 * kh + (t16 >> 2) + r * W + s;       // halo row of pixel + (r-1, s-1)
-                row = row >= kRing ? row - kRing : row;
-                int row4 = row + 4;
-                row4 = row4 >= kRing ? row4 - kRing : row4;
-                const int qcol = 32 * wq + 16 * G1 + (t16 & 3) * 4;
-                const bf16x4 b0 = lds_read_tr16(&sQ[row * kRS + qcol]);
-                const bf16x4 b1 = lds_read_tr16(&sQ[row4 * kRS + qcol]);
+            // one tap: masked P^T fragment x Q fragment (two transpose reads, 4 + 4 pixels)
+            auto tap = [&](const int r, const int s, const bf16x4 b0, const bf16x4 b1) {
                 bf16x8 af;
                 if constexpr (ALIGN != 0) {
                     bf16x4 u0 = s == 0 ? a0l : (s == 2 ? a0r : a0);
@@ -191,7 +189,20 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                     af = __builtin_bit_cast(bf16x8, bits);
                 }
                 const bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[t], 0, 0, 0);
+                acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[r * 3 + s], 0, 0, 0);
+            };
+            const int qlane = (8 * kh + (t16 >> 2)) * kRS + 32 * wq + 16 * G1 + (t16 & 3) * 4;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                // ring rows of this filter row's three taps: lo + [0, 17] (8 kh + t16 / 4 + s + 4).  lo is wave-uniform and the
+                // first kMirror ring rows are mirrored behind the ring, so a span that straddles the wrap point reads on into the
+                // mirror: the six reads are ONE address + immediate offsets (the per-lane wrap arithmetic of every read made this
+                // kernel VALU-bound -- PMC: VALU busy 36 %, MFMA 28 %).  (Requesting the fragments one filter row ahead of their
+                // MFMAs from a second register set was measured 5 % slower.)
+                const int lo = base + 16 * g + r * W;
+                const __bf16* q = &sQ[(lo >= kRing ? lo - kRing : lo) * kRS + qlane];
+#pragma unroll
+                for (int s = 0; s < 3; ++s) tap(r, s, lds_read_tr16(q + s * kRS), lds_read_tr16(q + (s + 4) * kRS));
             }
             x0 += 16;
             while (x0 >= W) { x0 -= W; if (++y >= H) y = 0; }
@@ -218,6 +229,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                 int slot = base + HRW + srow + 32 * j;          // appended rows never overlap the live halo (HRW + 64 <= kRing)
                 slot = slot >= kRing ? slot - kRing : slot;
                 *reinterpret_cast<bf16x8*>(&sQ[slot * kRS + seg * 8]) = hq;
+                if (slot < kMirror) *reinterpret_cast<bf16x8*>(&sQ[(slot + kRing) * kRS + seg * 8]) = hq;
             }
         }
         base += BRH;
@@ -242,7 +254,7 @@ bool lbc_wgrad_tr_eligible(const WgradArgs& a)
 {
     const bool off = lbc_opt_on(kOptNoWgradTr);   // A/B switch
     return !off && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.OH == a.H && a.OW == a.W && !a.p_scale &&
-           a.W >= 8 && 64 + 2 * a.W + 2 + 64 <= kRing && a.CP % 64 == 0 && a.CQ % 64 == 0;
+           a.W >= 8 && 64 + 2 * a.W + 2 + 64 <= kRingWide && a.CP % 64 == 0 && a.CQ % 64 == 0;
 }
 
 int lbc_wgrad_tr_pick_split(const WgradArgs& a)
@@ -266,8 +278,16 @@ int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s)
     const long long chunks = (M + 63) / 64;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 64;
     const unsigned blocks = (unsigned)((a.CP / 64) * (a.CQ / 64) * a.nsplit);
-    if (a.W % 8 == 0)      hipLaunchKernelGGL(conv_wgrad_tr_k<8>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
-    else if (a.W % 4 == 0) hipLaunchKernelGGL(conv_wgrad_tr_k<4>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
-    else                   hipLaunchKernelGGL(conv_wgrad_tr_k<0>, dim3(blocks), dim3(256), 0, s, a, rows_per_split);
+#define LBC_WT(AL)                                                                                                              \
+    do {                                                                                                                        \
+        if (64 + 2 * a.W + 2 + 64 <= kRingNarrow)                                                                               \
+            hipLaunchKernelGGL((conv_wgrad_tr_k<AL, kRsNarrow, kRingNarrow>), dim3(blocks), dim3(256), 0, s, a, rows_per_split); \
+        else                                                                                                                    \
+            hipLaunchKernelGGL((conv_wgrad_tr_k<AL, kRsWide, kRingWide>), dim3(blocks), dim3(256), 0, s, a, rows_per_split);     \
+    } while (0)
+    if (a.W % 8 == 0)      LBC_WT(8);
+    else if (a.W % 4 == 0) LBC_WT(4);
+    else                   LBC_WT(0);
+#undef LBC_WT
     return lbc_check_launch("conv_wgrad_tr");
 }
