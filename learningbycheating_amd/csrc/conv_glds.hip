@@ -306,8 +306,11 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
     static_assert(WM * WN == 8 && NT == 2 && (MT == 2 || MT == 4), "conv_glds2: wave tiling");
     constexpr int NBUF = 4;
     constexpr int TILE_A = BM * 64, TILE_B = BN * 64, BUF = TILE_A + TILE_B;     // bytes per K-tile: rows of 32 bf16
-    constexpr int NA = BM / 128, NB = BN / 128, NL = NA + NB;   // 1-KiB DMA pieces (16 rows) per wave per K-tile
-    static_assert(BM % 128 == 0 && BN % 128 == 0, "conv_glds2: tile extents");
+    // 1-KiB DMA pieces (16 rows) per wave per K-tile.  BN = 64 (the 64-channel layers) has four weight pieces for eight waves:
+    // waves 4..7 re-issue the pieces of waves 0..3 (same bytes to the same LDS rows), which keeps every wave's vmcnt arithmetic equal
+    constexpr int NA = BM / 128, NB = BN >= 128 ? BN / 128 : 1, NL = NA + NB;
+    constexpr int BWAVES = BN >= 128 ? 8 : BN / 16;
+    static_assert(BM % 128 == 0 && (BN % 128 == 0 || BN == 64), "conv_glds2: tile extents");
     constexpr int OROW = BN * 2 + 16;                           // staged output row: BN bf16 + 16 bytes (rows 4 apart on distinct banks)
     constexpr int STAGE = BM * OROW;
     constexpr int RED = WM * 2 * BN * 4;
@@ -343,9 +346,14 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         const int row = (wave * NA + j) * 16 + (lane >> 2);
         const int m = m0 + row;
         int bits = 0;
+        // output pixel m = (n, oy, ox) reads the gathered tensor around (oy * S, ox * S): S = 2 (forward of the stride-2 convolutions,
+        // input gradient of the transposed convolutions) only in the gather mode
+        const int mm = m < a.M ? m : 0;
+        const int ox = mm % a.OW;
+        const int oy = (mm / a.OW) % a.OH;
+        const int n = mm / (a.OW * a.OH);
+        const int x = ox * a.S, y = oy * a.S;
         if (m < a.M) {
-            const int x = m % W;
-            const int y = (m / W) % H;
             for (int t = 0; t < T; ++t) {
                 const int r = t / KW, s = t - r * KW;
                 const int dy = MODE == 0 ? r - PAD : PAD - r;
@@ -355,12 +363,12 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         }
         amask[j] = bits;
         // swizzle on the SOURCE: LDS slot (row, s) holds segment s ^ ((row >> 2) & 3)
-        aoff[j] = (m < a.M ? m : 0) * C + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        aoff[j] = ((n * H + y) * W + x) * C + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
     }
     int boff[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int row = (wave * NB + j) * 16 + (lane >> 2);
+        const int row = ((wave % BWAVES) * NB + j) * 16 + (lane >> 2);
         boff[j] = (n0 + row) * (T * C) + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
     }
     // ---- fragment roles: row l31 of a 32-row block, depth step g (16 channels), half kh: slot (2g + kh) ^ ((l31 >> 2) & 3)
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
     auto issue = [&]() {
         char* base = smem + is_buf * BUF;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) lds_dma16(DIAG == 2 ? zero : win + (boff[j] + is_koffs), base + TILE_A + (wave * NB + j) * 1024);
+        for (int j = 0; j < NB; ++j) lds_dma16(DIAG == 2 ? zero : win + (boff[j] + is_koffs), base + TILE_A + ((wave % BWAVES) * NB + j) * 1024);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
             const bool ok = ((amask[j] >> is_ti) & 1) && DIAG != 2;
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
 
 struct GldsCfg { int bm, bn; double eff; };
 // cfg ids kLbcCfgGlds + 0 .. 3; eff = measured relative MFMA efficiency of a full round of tiles (MI355X, batch 256)
-const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128, 256, 0.95}, {512, 128, 1.0}};
+const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128, 256, 0.95}, {512, 128, 1.0}, {512, 64, 1.0}};
 
 }  // namespace
 
@@ -564,9 +572,15 @@ const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128,
 int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
 {
     if (lbc_opt_on(kOptNoGemm256)) return -1;
-    if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || a.S != 1 || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
-    if (a.KH != a.KW || (a.KH != 3 && a.KH != 1) || a.P != (a.KH - 1) / 2) return -1;
-    if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || a.C % 64 || (mode != 0 && mode != 1)) return -1;
+    if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
+    if (a.KH != a.KW || (a.KH != 3 && a.KH != 1) || a.P != (a.KH - 1) / 2 || a.C % 64 || (mode != 0 && mode != 1)) return -1;
+    if (a.M != a.N * a.OH * a.OW || (long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return -1;
+    if (a.S == 1) { if (a.H != a.OH || a.W != a.OW) return -1; }
+    else {
+        // stride 2: gather mode of the second-generation kernel only (forward of the stride-2 convolutions and downsamples,
+        // input gradient of the transposed convolutions)
+        if (a.S != 2 || mode != 0 || lbc_opt_on(kOptGldsV1) || a.OH != (a.H + 2 * a.P - a.KH) / 2 + 1 || a.OW != (a.W + 2 * a.P - a.KW) / 2 + 1) return -1;
+    }
     // One workgroup per CU: a tile shape qualifies when it fills at least three quarters of the 256 CUs; among the shapes
     // that do, the one with the best (round quantisation x per-shape efficiency) wins.
     const long long fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 192;
@@ -577,6 +591,7 @@ int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
         const GldsCfg& c = kGldsCfg[i];
         if (a.K % c.bn) continue;
         if (forced >= 0 && forced != i) continue;
+        if (c.bn == 64 && (a.K != 64 || lbc_opt_on(kOptGldsV1) || forced != i)) continue;   // 64-channel layers: measured, not (yet) the default
         const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn);
         if (tiles < fill) continue;
         const double score = c.eff * (double)tiles / (double)(((tiles + 255) / 256) * 256);
@@ -616,7 +631,8 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
         if (cfg == kLbcCfgGlds + 0) LBC_GL2(256, 256, 2, 4);
         else if (cfg == kLbcCfgGlds + 1) LBC_GL2(256, 128, 4, 2);
         else if (cfg == kLbcCfgGlds + 2) LBC_GL2(128, 256, 2, 4);
-        else LBC_GL2(512, 128, 4, 2);
+        else if (cfg == kLbcCfgGlds + 3) LBC_GL2(512, 128, 4, 2);
+        else LBC_GL2(512, 64, 8, 1);
 #undef LBC_GL2
         return lbc_check_launch("conv_glds2");
     }
@@ -628,7 +644,8 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     if (cfg == kLbcCfgGlds + 0) LBC_GL(256, 256, 2, 4, 2);
     else if (cfg == kLbcCfgGlds + 1) LBC_GL(256, 128, 4, 2, 3);
     else if (cfg == kLbcCfgGlds + 2) LBC_GL(128, 256, 2, 4, 3);
-    else LBC_GL(512, 128, 4, 2, 2);
+    else if (cfg == kLbcCfgGlds + 3) LBC_GL(512, 128, 4, 2, 2);
+    else { lbc_set_error("conv_glds: the 512 x 64 shape exists in the second-generation kernel only"); return LBC_EINVAL; }
 #undef LBC_GL
     return lbc_check_launch("conv_glds");
 }

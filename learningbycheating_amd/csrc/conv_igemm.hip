@@ -498,9 +498,10 @@ int lbc_igemm_rows(const IgemmArgs& a, int cfg)
 
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode)
 {
-    if (lbc_opt(kOptForceCfg) < 0 && !lbc_conv3x3_halo_eligible(a, mode)) {     // a forced tile policy pins conv_igemm.hip
+    if (lbc_opt(kOptForceCfg) < 0) {     // a forced tile policy pins conv_igemm.hip
         const int g = lbc_conv_glds_pick(a, mode);
-        if (g >= 0) return g;
+        // the 64-channel layers have two candidates: conv_halo.hip, unless the 512 x 64 LDS-DMA shape is selected
+        if (g >= 0 && (g == kLbcCfgGlds + 4 || !lbc_conv3x3_halo_eligible(a, mode))) return g;
     }
     return lbc_igemm_pick(a.M, a.K);
 }

@@ -719,7 +719,7 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
             a.M = N * D.H * D.W; a.LH = D.H; a.LW = D.W; a.ostep = 1;
             a.bf16 = bf16_; a.act_bf16 = act_bf16_;
             if (act_bf16_) { a.w = W(D.wn); a.w_bf16 = 1; }
-            LBC_TRY(lbc_igemm_launch(a, 1, 0, lbc_igemm_pick(a.M, a.K), s));   // F = d bn(x)
+            LBC_TRY(lbc_igemm_launch(a, 1, 0, act_bf16_ ? lbc_igemm_pick_for(a, 0) : lbc_igemm_pick(a.M, a.K), s));   // F = d bn(x)
             // BatchNorm backward; for the first decoder stage only the 512 trunk channels carry on
             float* dst = i == 0 ? bwd_D_ : E;
             LBC_TRY(bn_backward(D.bn, F, nullptr, nullptr, xin, ipix, dst, i == 0 ? 512 : D.Cin, s));

@@ -130,8 +130,8 @@ int lbc_igemm_pick(long long M, int K);            // tile configuration 0..2 of
 // tile configuration for a fully described launch: conv_glds.hip's (kLbcCfgGlds + 0..2) when eligible, else lbc_igemm_pick
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
-constexpr int kLbcGldsCfgs = 4;
-int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128} or -1
+constexpr int kLbcGldsCfgs = 5;
+int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64} or -1
 int lbc_conv_glds_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 // 256 zero bytes in device memory (per device, allocated on first use): source of the zero padding of LDS-DMA staging

@@ -374,6 +374,33 @@ def test_conv_wgrad_tap_fused(env, cfg):
     assert relerr(dw2, w2.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
 
 
+@pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 3, 1), (1, 12, 14, 128, 256, 3, 2), (3, 8, 10, 64, 128, 1, 3), (2, 6, 34, 128, 128, 3, 3)] +
+                         [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128, 3, -1), (64, 20, 48, 128, 256, 3, -1), (64, 40, 96, 64, 128, 1, -1), (256, 10, 24, 256, 512, 3, -1)]])
+def test_conv_glds_stride2_gather(env, case, lbc_config):
+    """stride-2 forward (3x3 pad 1 and the 1x1 downsample) on the LDS-DMA kernel: odd output extents, borders, statistics"""
+    dev, _ = env
+    from learningbycheating_amd import _lib
+    N, H, W, C, K, k, cfgid = case
+    if cfgid >= 0:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+        lbc_config("LBC_GEMM256_CFG", cfgid)
+    p = (k - 1) // 2
+    x, w = make((N, H, W, C, K, k, 2, p), 190 + C + K)
+    x = rbf(x)
+    ref = F.conv2d(x, rbf(w), None, 2, p)
+    rows = ctypes.c_int(0)
+    d = _lib.ConvDesc(N, H, W, C, K, k, k, 2, p, 0, 3, 0)
+    _lib.check(_lib.get().lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
+    M = N * ref.shape[2] * ref.shape[3]
+    assert rows.value in ([-(-M // GLDS_BM[cfgid])] if cfgid >= 0 else [-(-M // b) for b in (128, 256, 512)]), (rows.value, M)
+    y, st = Conv(dev).fwd(x, w, 2, p, stats=True, bf16=3)
+    assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    lbc_config("LBC_NO_GEMM256", 1)
+    y3, _ = Conv(dev).fwd(x, w, 2, p, bf16=3)
+    assert relerr(y, y3) < 2.0 ** -7
+
+
 # ---- randomized small shapes on the emulator (and the GPU): ragged pixel counts, odd widths, images smaller than a tile -----
 def _rand_shapes(seed, count, wmin, wmax, wstep=1):
     g = torch.Generator().manual_seed(seed)
@@ -512,7 +539,7 @@ def test_deconv_f32_large_tile_configs(env, cfg, cfgid, force_cfg):
 
 
 # ---- 8-wave LDS-DMA convolution (conv_glds.hip): bf16 tensors + bf16 weight copies --------------------------------------------
-GLDS_BM = {0: 256, 1: 256, 2: 128, 3: 512}      # tile rows of LBC_GEMM256_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128
+GLDS_BM = {0: 256, 1: 256, 2: 128, 3: 512, 4: 512}      # tile rows of LBC_GEMM256_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64
 
 
 def _glds_cases():
@@ -521,6 +548,7 @@ def _glds_cases():
                                (5, 9, 13, 128, 128, 3)]:
         for cfgid in ((0, 2) if K % 256 == 0 else (1, 3)):
             out.append((N, H, W, C, K, k, cfgid))
+    out += [(2, 9, 17, 64, 64, 3, 4), (1, 30, 20, 128, 64, 3, 4)]      # 512 x 64 tiles (second-generation kernel only)
     return out
 
 
@@ -540,6 +568,8 @@ def test_conv_glds_fwd_dgrad(env, case, gen, lbc_config):
     from learningbycheating_amd import _lib
     N, H, W, C, K, k, cfgid = case
     if gen == 1:
+        if cfgid == 4:
+            pytest.skip("512 x 64 tiles exist in the second-generation kernel only")
         lbc_config("LBC_GLDS_V1", 1)       # the first-generation (phase-barrier) kernel, kept for A/B runs
     if cfgid >= 0:
         lbc_config("LBC_GEMM256_MIN_TILES", 1)
