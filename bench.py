@@ -218,6 +218,8 @@ def main():
                     help="default: the workload's.  f32: exact-f32 MFMA everywhere (the parity path). bf16: mixed precision of BASELINE.json "
                          "config 3 -- bf16 MFMA operands and bf16 activation storage, f32 accumulation / master weights / gradients / "
                          "BatchNorm / soft-argmax / loss / Adam. bf16_mfma: bf16 MFMA operands only, every tensor f32")
+    ap.add_argument("--grad-allreduce", choices=["f32", "bf16", "auto"], default="auto",
+                    help="dtype of the gradient buckets on the wire (N > 1): auto = bf16 in the bf16 mode (BASELINE config 3), f32 otherwise")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL over xGMI, one rank per GPU); gloo lets several ranks share one GPU to exercise the N > 1 code "
                          "path on a single-GPU box -- its numbers mean nothing")
@@ -301,13 +303,14 @@ def main():
                 broadcast_module(m)
         pool.pos = 0
         pool.prefetch(0); pool.prefetch(1)
+        gdt = torch.bfloat16 if (args.grad_allreduce == "bf16" or (args.grad_allreduce == "auto" and dt_name == "bf16")) else None
         if kind == "birdview":
-            tr = NativeTrainer(teacher, None, per_gpu, (7, 192, 192), device, phase="birdview", lr=1e-4, world_size=world)
+            tr = NativeTrainer(teacher, None, per_gpu, (7, 192, 192), device, phase="birdview", lr=1e-4, world_size=world, grad_dtype=gdt)
         else:
-            warm = NativeTrainer(student, None, per_gpu, (3, 160, 384), device, phase="l1_all", lr=1e-3, world_size=world)
+            warm = NativeTrainer(student, None, per_gpu, (3, 160, 384), device, phase="l1_all", lr=1e-3, world_size=world, grad_dtype=gdt)
             run_steps(warm, args.init_steps, "warm")
             del warm
-            tr = NativeTrainer(student, teacher, per_gpu, (3, 160, 384), device, phase=1, lr=1e-4, world_size=world)
+            tr = NativeTrainer(student, teacher, per_gpu, (3, 160, 384), device, phase=1, lr=1e-4, world_size=world, grad_dtype=gdt)
         weights = []
         run_steps(tr, warmup, "train", weights)
         torch.cuda.synchronize()
@@ -361,7 +364,9 @@ def main():
         if tj and dt_name in tj:
             t = tj[dt_name]        # {"traffic_bytes_per_launch", "algorithmic_bytes_per_launch", "kernel", "source"}
             roof["traffic"] = t.get("traffic_bytes_per_launch")
-            roof["traffic_over_algorithmic"] = t.get("ratio")
+            gb = sum(v["gbyte"] for v in conv.values())
+            roof["algorithmic_bytes_per_launch"] = round(gb * 1e9 / max(n, 1))
+            roof["traffic_over_algorithmic"] = round(roof["traffic"] * max(n, 1) / (gb * 1e9), 3) if gb and roof["traffic"] else None
             roof["traffic_kernel"] = t.get("kernel")
             roof["traffic_source"] = t.get("source")
         bn = {k: v for k, v in br.items() if k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "channel_stats")}
@@ -389,7 +394,8 @@ def main():
                "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": "%s [%s], 160x384 RGB + 7x192x192 bird-view uint8 NHWC frames as the dataset stores them (%s), global batch %d "
-                                      "(%d/GPU), %s, local BatchNorm, Adam lr 1e-4" % (wl["what"], args.workload, feed, global_batch, per_gpu, DTYPE_TEXT[dtype]),
+                                      "(%d/GPU), %s, local BatchNorm, %sAdam lr 1e-4" % (wl["what"], args.workload, feed, global_batch, per_gpu, DTYPE_TEXT[dtype],
+                                         "" if world == 1 else ("%s gradient buckets over RCCL, " % ("bf16" if (args.grad_allreduce == "bf16" or (args.grad_allreduce == "auto" and dtype == "bf16")) else "f32"))),
                           "global_batch": global_batch, "parallelism": "dp%d" % world,
                           "waypoint_tolerance_vs_f32": WAYPOINT_TOLERANCE[{"f32": "fp32"}.get(dtype, dtype)]},
                "loss": loss_mean, "loss_finite": bool(loss_mean == loss_mean and abs(loss_mean) != float("inf")),

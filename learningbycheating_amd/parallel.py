@@ -27,7 +27,12 @@ def stage_ranges(grad_spans):
 
 
 class StageAllReducer:
-    def __init__(self, grad_flat, grad_spans, group=None, force=False):
+    """grad_dtype: None / torch.float32 = the f32 buckets are reduced in place (bit-reproducible sum order per RCCL ring);
+    torch.bfloat16 = every bucket is cast into a bf16 staging buffer on the communication stream, reduced there (half the
+    bytes on the xGMI links: 46 MB instead of 92 MB per step for ResNet-34) and cast back into the f32 gradient buffer --
+    the usual compressed-gradient data parallelism of a bf16 run with f32 master weights (BASELINE.json config 3)."""
+
+    def __init__(self, grad_flat, grad_spans, group=None, force=False, grad_dtype=None):
         self.flat = grad_flat
         self.ranges = stage_ranges(grad_spans)
         self.group = group
@@ -36,21 +41,34 @@ class StageAllReducer:
         self.cuda = grad_flat.is_cuda
         self.comm = torch.cuda.Stream(device=grad_flat.device) if self.cuda and self.active else None
         self.pending = []
+        self.staging = None
+        if self.active and grad_dtype is not None and grad_dtype != grad_flat.dtype:
+            self.staging = torch.empty(grad_flat.numel(), dtype=grad_dtype, device=grad_flat.device)
+
+    def _reduce(self, lo, hi):
+        bucket = self.flat[lo:hi]
+        if self.staging is None:
+            self.pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            return
+        # compressed bucket: cast, reduce, cast back -- all in stream order (the cast back must see the reduced values)
+        st = self.staging[lo:hi]
+        st.copy_(bucket)
+        dist.all_reduce(st, op=dist.ReduceOp.SUM, group=self.group)
+        bucket.copy_(st)
 
     def launch(self, stage):
         """call right after enqueueing backward stage `stage` on the current stream"""
         if not self.active:
             return
         lo, hi = self.ranges[stage]
-        bucket = self.flat[lo:hi]
         if self.comm is not None:
             ev = torch.cuda.Event()
             ev.record()
             with torch.cuda.stream(self.comm):
                 self.comm.wait_event(ev)
-                self.pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._reduce(lo, hi)
         else:
-            self.pending.append(dist.all_reduce(bucket, op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+            self._reduce(lo, hi)
 
     def wait(self):
         for w in self.pending:

@@ -26,7 +26,7 @@ class NativeTrainer:
     image space), 'birdview' (privileged agent vs ground-truth waypoints), 'l1_all' (all branches vs
     given normalised targets; used to warm-start synthetic benchmarks below the horizon)."""
 
-    def __init__(self, student, teacher, batch, image_shape, device, phase=1, lr=1e-4, world_size=1, group=None, camera=None):
+    def __init__(self, student, teacher, batch, image_shape, device, phase=1, lr=1e-4, world_size=1, group=None, camera=None, grad_dtype=None):
         self.student, self.teacher, self.phase, self.batch, self.world = student, teacher, phase, batch, world_size
         self.device = device
         student.train()
@@ -37,7 +37,7 @@ class NativeTrainer:
             self.teng = teacher.engine((batch, 7, 192, 192), device, max_batch=batch, with_grads=False)
         self.cam = camera or camera_struct()
         self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
-        self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group)
+        self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group, grad_dtype=grad_dtype)   # grad_dtype: see parallel.py
         self.loss = torch.zeros(batch, dtype=torch.float32, device=device)
         self.dpred_all = torch.zeros((batch, 4, 5, 2), dtype=torch.float32, device=device)
         self.dpred_sel = torch.zeros((batch, 5, 2), dtype=torch.float32, device=device)

@@ -46,7 +46,7 @@ def test_stage_ranges_partition_the_gradient_buffer():
     assert r[0][1] == total and r[5][0] == 0
 
 
-def _reduce_worker(rank, world, port, q):
+def _reduce_worker(rank, world, port, q, grad_dtype=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -55,7 +55,7 @@ def _reduce_worker(rank, world, port, q):
     g = torch.Generator().manual_seed(100 + rank)
     flat = torch.randn(total, generator=g)
     mine = flat.clone()
-    red = StageAllReducer(flat, offs)
+    red = StageAllReducer(flat, offs, grad_dtype=grad_dtype)
     for st in range(6):
         red.launch(st)
     red.wait()
@@ -86,6 +86,75 @@ def test_staged_allreduce_gloo_world2():
     want = res[0][1] + res[1][1]
     assert torch.allclose(res[0][2], want) and torch.allclose(res[1][2], want)
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])      # broadcast_module
+
+
+def test_staged_allreduce_bf16_buckets_gloo_world2():
+    """compressed buckets: every rank ends with the same values, equal to the sum of the bf16-rounded shards up to one bf16
+    rounding of the result"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q, torch.bfloat16)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = res[0][1].bfloat16().float() + res[1][1].bfloat16().float()
+    assert torch.equal(res[0][2], res[1][2])
+    assert ((res[0][2] - want).abs() <= want.abs() * 2.0 ** -7 + 1e-6).all()
+
+
+def _rccl_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    from learningbycheating_amd.parallel import StageAllReducer, broadcast_module
+    offs, total = _offsets_for_image_model()
+    dev = torch.device("cuda", rank)
+    out = []
+    for gdt in (None, torch.bfloat16):
+        g = torch.Generator().manual_seed(300 + rank)
+        flat = torch.randn(total, generator=g).to(dev)
+        red = StageAllReducer(flat, offs, grad_dtype=gdt)
+        for st in range(6):
+            flat[red.ranges[st][0]:red.ranges[st][1]].mul_(1.0)
+            red.launch(st)
+        red.wait()
+        torch.cuda.synchronize()
+        out.append(flat[::50021].cpu())
+    lin = torch.nn.Linear(8, 8).to(dev)
+    broadcast_module(lin)
+    q.put((rank, out[0], out[1], lin.weight.detach().cpu()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.gpu
+def test_staged_allreduce_rccl_world2():
+    """two ranks on two GPUs over RCCL: f32 buckets = the sum of the shards, bf16 buckets within one bf16 rounding of it,
+    broadcast_module leaves rank 0's weights everywhere.  Skipped on a one-GPU box."""
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    shards = [torch.randn(_offsets_for_image_model()[1], generator=torch.Generator().manual_seed(300 + r))[::50021] for r in range(2)]
+    want = shards[0] + shards[1]
+    assert torch.allclose(res[0][1], want, rtol=0, atol=1e-6) and torch.equal(res[0][1], res[1][1])
+    wantb = shards[0].bfloat16().float() + shards[1].bfloat16().float()
+    assert torch.equal(res[0][2], res[1][2]) and ((res[0][2] - wantb).abs() <= wantb.abs() * 2.0 ** -7 + 1e-6).all()
+    assert torch.equal(res[0][3], res[1][3])
 
 
 def _dp_worker(rank, world, port, q):
