@@ -286,31 +286,33 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
 // above at batch 256 (LBC_GLDS_DIAG runs): with the DMA stream removed a 256 x 256 launch still needs 68 of 77 us, the
 // 2-byte output stores cost 12 us and the barrier-separated fragment reads 14 us -- the matrix pipe waits on the phase
 // structure (two barriers per 8 MFMAs), not on memory.  Here
-//   * a K-tile is one filter tap x 32 channels (64-byte LDS rows, 16-byte slot XOR-ed with (row >> 2) & 3), four K-tiles
-//     in the ring: tile t + 3 is issued while tile t computes, so a DMA piece has two tile periods to land;
-//   * ONE barrier per K-tile (16 MFMAs per wave).  A wave's fragment reads for the next depth step are issued between the
-//     MFMAs of the current one (two register sets), so the barrier finds every wave with its next fragments in registers;
+//   * ONE barrier per K-tile (one filter tap x 32 or 64 channels: 16 / 32 MFMAs per wave); a DMA piece has ~2000 MFMA cycles to
+//     land (four 32-channel tiles or two 64-channel tiles in the ring).  A wave's fragment reads for the next depth step are
+//     issued between the MFMAs of the current one (two register sets), so the barrier finds every wave with its next
+//     fragments in registers;
 //   * the output tile goes through LDS: bf16 rows, then 16-byte coalesced stores (was 128 two-byte stores per lane).
-// Synchronisation of K-tile t (buffer t & 3):
-//   first half :  reads (t, step 1) | 8 MFMAs (t, step 0);  s_waitcnt vmcnt: own pieces of tile t + 1 landed;  lgkmcnt(0);  s_barrier
-//   second half:  DMA pieces of tile t + 3 -> buffer (t - 1) & 3;  reads (t + 1, step 0) | 8 MFMAs (t, step 1)
-//   RAW: tile t + 1 is read only after the barrier of tile t, which every wave enters after its pieces of t + 1 have landed.
-//   WAR: buffer (t - 1) & 3 is refilled after the barrier of tile t; its last reads (tile t - 1, step 1) were retired by the
-//        lgkmcnt(0) in front of the barrier of tile t - 1.
 #define LBC_SG(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
-template <int BM, int BN, int WM, int WN, int MODE, int DIAG = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
+template <int BM, int BN, int WM, int WN, int MODE, int KT, int DIAG = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
 __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
     static_assert(WM * WN == 8 && NT == 2 && (MT == 2 || MT == 4), "conv_glds2: wave tiling");
-    constexpr int NBUF = 4;
-    constexpr int TILE_A = BM * 64, TILE_B = BN * 64, BUF = TILE_A + TILE_B;     // bytes per K-tile: rows of 32 bf16
-    // 1-KiB DMA pieces (16 rows) per wave per K-tile.  BN = 64 (the 64-channel layers) has four weight pieces for eight waves:
-    // waves 4..7 re-issue the pieces of waves 0..3 (same bytes to the same LDS rows), which keeps every wave's vmcnt arithmetic equal
-    constexpr int NA = BM / 128, NB = BN >= 128 ? BN / 128 : 1, NL = NA + NB;
-    constexpr int BWAVES = BN >= 128 ? 8 : BN / 16;
-    static_assert(BM % 128 == 0 && (BN % 128 == 0 || BN == 64), "conv_glds2: tile extents");
+    // K-tile = one filter tap x KT channels.  KT = 32: 64-byte LDS rows, four tiles in the ring.  KT = 64: 128-byte rows = whole
+    // cache lines per DMA row (a 64-byte row leaves half of every 128-byte line it pulls through L2 -> L1 unused; the same
+    // line comes again nine K-tiles later), two tiles in the ring, half as many barriers; same prefetch distance in cycles.
+    static_assert(KT == 32 || KT == 64, "conv_glds2: K-tile depth");
+    constexpr int ROWB = KT * 2;                                // bytes per LDS row
+    constexpr int NBUF = KT == 32 ? 4 : 2;
+    constexpr int KS = KT / 16;                                 // depth steps (one MFMA k) per K-tile
+    constexpr int SEGS = ROWB / 16;                             // 16-byte segments per row
+    constexpr int PROWS = 1024 / ROWB;                          // rows per 1-KiB DMA piece
+    constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB, BUF = TILE_A + TILE_B;
+    // 1-KiB DMA pieces per wave per K-tile.  When the weight tile has fewer than eight pieces (BN = 64) the upper waves re-issue
+    // the pieces of the lower ones (same bytes to the same LDS rows), which keeps every wave's vmcnt arithmetic equal
+    constexpr int NA = BM / (PROWS * 8), NB = BN >= PROWS * 8 ? BN / (PROWS * 8) : 1, NL = NA + NB;
+    constexpr int BWAVES = BN >= PROWS * 8 ? 8 : BN / PROWS;
+    static_assert(BM % (PROWS * 8) == 0 && (BN % (PROWS * 8) == 0 || BN == 64), "conv_glds2: tile extents");
     constexpr int OROW = BN * 2 + 16;                           // staged output row: BN bf16 + 16 bytes (rows 4 apart on distinct banks)
     constexpr int STAGE = BM * OROW;
     constexpr int RED = WM * 2 * BN * 4;
@@ -337,13 +339,17 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
 
     const __bf16* xin = static_cast<const __bf16*>(a.x);
     const __bf16* win = static_cast<const __bf16*>(a.w);
-    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 3) * 8;
+    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 7) * 8;
 
-    // ---- DMA roles: piece (wave * NA + j) of the A tile = rows 16 * piece .. + 15, lane -> (row = lane >> 2, segment = lane & 3)
+    // 16-byte slot XOR of a row: rows 4 (64-byte rows) / 2 (128-byte rows) apart differ, so that every ds_read_b128 lane group
+    // (16 consecutive rows, one segment) hits 16 distinct slots
+    auto rowswz = [](int row) { return KT == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
+    // ---- DMA roles: piece (wave * NA + j) of the A tile = PROWS rows, lane -> (row = lane / SEGS, segment = lane % SEGS)
+    const int prow = lane / SEGS, pseg = lane % SEGS;
     int aoff[NA], amask[NA];
 #pragma unroll
     for (int j = 0; j < NA; ++j) {
-        const int row = (wave * NA + j) * 16 + (lane >> 2);
+        const int row = (wave * NA + j) * PROWS + prow;
         const int m = m0 + row;
         int bits = 0;
         // output pixel m = (n, oy, ox) reads the gathered tensor around (oy * S, ox * S): S = 2 (forward of the stride-2 convolutions,
@@ -362,22 +368,24 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
             }
         }
         amask[j] = bits;
-        // swizzle on the SOURCE: LDS slot (row, s) holds segment s ^ ((row >> 2) & 3)
-        aoff[j] = ((n * H + y) * W + x) * C + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        // swizzle on the SOURCE: LDS slot (row, s) holds segment s ^ rowswz(row)
+        aoff[j] = ((n * H + y) * W + x) * C + (pseg ^ rowswz(row)) * 8;
     }
     int boff[NB];
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const int row = ((wave % BWAVES) * NB + j) * 16 + (lane >> 2);
-        boff[j] = (n0 + row) * (T * C) + ((lane & 3) ^ ((row >> 2) & 3)) * 8;
+        const int row = ((wave % BWAVES) * NB + j) * PROWS + prow;
+        boff[j] = (n0 + row) * (T * C) + (pseg ^ rowswz(row)) * 8;
     }
-    // ---- fragment roles: row l31 of a 32-row block, depth step g (16 channels), half kh: slot (2g + kh) ^ ((l31 >> 2) & 3)
-    const int swz = (l31 >> 2) & 3;
-    const int koff0 = ((0 + kh) ^ swz) << 4, koff1 = ((2 + kh) ^ swz) << 4;
-    const int aBase = (wm * WTM + l31) * 64;
-    const int bBase = TILE_A + (wn * WTN + l31) * 64;
+    // ---- fragment roles: row l31 of a 32-row block, depth step g (16 channels), half kh: slot (2g + kh) ^ rowswz(l31)
+    const int swz = rowswz(l31);
+    int koff[KS];
+#pragma unroll
+    for (int g = 0; g < KS; ++g) koff[g] = ((2 * g + kh) ^ swz) << 4;
+    const int aBase = (wm * WTM + l31) * ROWB;
+    const int bBase = TILE_A + (wn * WTN + l31) * ROWB;
 
-    const int cpt = C / 32;
+    const int cpt = C / KT;
     const int nit = T * cpt;
 
     f32x16 acc[MT][NT];
@@ -388,102 +396,123 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // the DMA stream walks K-tiles in order: (32-channel slab, tap), taps inner (the nine shifted reads of a slab hit in L2)
+    // the DMA stream walks K-tiles in order: (KT-channel slab, tap), taps inner (the nine shifted reads of a slab hit in L2)
     int is_ti = 0, is_s = 0, is_buf = 0;
     int is_shift = (MODE == 0 ? -(PAD * W + PAD) : PAD * W + PAD) * C;     // element offset of tap (0, 0), slab 0
     int is_koffs = 0;
     auto issue = [&]() {
         char* base = smem + is_buf * BUF;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) lds_dma16(DIAG == 2 ? zero : win + (boff[j] + is_koffs), base + TILE_A + ((wave % BWAVES) * NB + j) * 1024);
+        for (int j = 0; j < NB; ++j) lds_dma16((DIAG == 2 || DIAG == 4) ? zero : win + (boff[j] + is_koffs), base + TILE_A + ((wave % BWAVES) * NB + j) * 1024);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const bool ok = ((amask[j] >> is_ti) & 1) && DIAG != 2;
+            const bool ok = ((amask[j] >> is_ti) & 1) && DIAG != 2 && DIAG != 3;
             const __bf16* src = ok ? xin + (aoff[j] + is_shift) : zero;
             lds_dma16(src, base + (wave * NA + j) * 1024);
         }
-        // next K-tile: tap (r, s) -> (r, s + 1) -> (r + 1, 0) -> next 32-channel slab, tap (0, 0).  (Walking the two 32-channel
-        // halves of a 128-byte line back to back instead was measured 4-6 % slower at batch 256.)
+        // next K-tile: tap (r, s) -> (r, s + 1) -> (r + 1, 0) -> next slab, tap (0, 0).  (With KT = 32, walking the two halves of
+        // a 128-byte line back to back instead was measured 4-6 % slower at batch 256.)
         const int step = MODE == 0 ? C : -C;
         ++is_ti; ++is_s;
         is_shift += step; is_koffs += C;
         if (is_s == KW) { is_s = 0; is_shift += step * (W - KW); }
         if (is_ti == T) {
             is_ti = 0;
-            is_shift += 32 - step * (W * a.KH);
-            is_koffs += 32 - T * C;
+            is_shift += KT - step * (W * a.KH);
+            is_koffs += KT - T * C;
         }
         is_buf = (is_buf + 1) & (NBUF - 1);
     };
 
-    bf16x8 fa0[MT], fb0[NT], fa1[MT], fb1[NT];
-#define LBC_RD(bufp, KOFF, FA, FB)                                                                                   \
+    bf16x8 fa[2][MT], fb[2][NT];        // two register sets: depth step g computes from set g & 1 while set (g + 1) & 1 is read
+#define LBC_RD(bufp, G, SET)                                                                                         \
     do {                                                                                                             \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i) FA[i] = *reinterpret_cast<const bf16x8*>((bufp) + aBase + i * 2048 + (KOFF)); \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j) FB[j] = *reinterpret_cast<const bf16x8*>((bufp) + bBase + j * 2048 + (KOFF)); \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) fa[SET][i] = *reinterpret_cast<const bf16x8*>((bufp) + aBase + i * 32 * ROWB + koff[G]); \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) fb[SET][j] = *reinterpret_cast<const bf16x8*>((bufp) + bBase + j * 32 * ROWB + koff[G]); \
     } while (0)
-#define LBC_MM(FA, FB)                                                                                               \
+#define LBC_MM(SET)                                                                                                  \
     do {                                                                                                             \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                               \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(FA[i], FB[j], acc[i][j], 0, 0, 0);               \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);     \
     } while (0)
+    // one MFMA, one fragment read, ...: the reads of the next depth step between the MFMAs of the current one
+#define LBC_MIX()                                                                                                    \
+    do {                                                                                                             \
+        _Pragma("unroll") for (int k = 0; k < MT + NT; ++k) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); }                  \
+        if (MT * NT > MT + NT) LBC_SG(0x008, MT * NT - (MT + NT));                                                   \
+    } while (0)
+    // wait until at most `tiles` K-tiles of this wave's DMA pieces are outstanding (s_waitcnt takes an immediate)
+    auto wait_tiles = [&](int tiles) {
+        if (tiles >= 3) LBC_WAIT_VM(3 * NL);
+        else if (tiles == 2) LBC_WAIT_VM(2 * NL);
+        else if (tiles == 1) LBC_WAIT_VM(NL);
+        else LBC_WAIT_VM(0);
+    };
 
-    // ---- prologue: up to three K-tiles in flight, tile 0 landed and visible, its first fragments in registers
-    issue();
-    if (nit > 1) issue();
-    if (nit > 2) issue();
-    if (nit > 2) LBC_WAIT_VM(2 * NL);
-    else if (nit > 1) LBC_WAIT_VM(NL);
-    else LBC_WAIT_VM(0);
+    // ---- prologue: the ring full (up to NBUF K-tiles in flight), tile 0 landed and visible, its first fragments in registers
+#pragma unroll
+    for (int i = 0; i < NBUF; ++i)
+        if (i < nit) issue();
+    wait_tiles((nit < NBUF ? nit : NBUF) - 1);
     __builtin_amdgcn_s_barrier();
-    LBC_RD(smem, koff0, fa0, fb0);
+    LBC_RD(smem, 0, 0);
 
-    // ---- steady state: tiles 0 .. nit - 4 (each issues tile t + 3): straight-line body, no conditionals, the DMA address
+    // Synchronisation of K-tile t (buffer t % NBUF), once per tile, in front of its LAST depth step:
+    //   s_waitcnt vmcnt: own pieces of tile t + 1 landed (NBUF - 2 younger tiles may stay in flight);  lgkmcnt(0);  s_barrier
+    //   then: DMA pieces of tile t + NBUF -> the buffer of tile t;  reads (t + 1, step 0) | MFMAs (t, last step)
+    //   RAW: tile t + 1 is read only after this barrier, which every wave enters after its pieces of t + 1 have landed.
+    //   WAR: the buffer of tile t is refilled after this barrier; its last reads (step KS - 1, issued during step KS - 2) were
+    //        retired by the lgkmcnt(0) in front of it.
+    // ---- steady state: tiles that still have a tile t + NBUF to issue: straight-line body, no conditionals, the DMA address
     //      arithmetic and the fragment reads spread between the MFMAs
     int t = 0;
-    for (; t + 3 < nit; ++t) {
+    for (; t + NBUF < nit; ++t) {
         const char* bb = smem + (t & (NBUF - 1)) * BUF;
         const char* bn = smem + ((t + 1) & (NBUF - 1)) * BUF;
-        LBC_RD(bb, koff1, fa1, fb1);
-        LBC_MM(fa0, fb0);
 #pragma unroll
-        for (int k = 0; k < MT + NT; ++k) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); }
-        LBC_SG(0x008, MT * NT - (MT + NT));
-        __builtin_amdgcn_sched_barrier(0);        // the MFMAs above stay above: nothing is scheduled across the barrier
-        LBC_WAIT_VM(NL);                          // own pieces of tile t + 1 landed (those of tile t + 2 stay in flight)
+        for (int g = 0; g + 1 < KS; ++g) {
+            LBC_RD(bb, g + 1, (g + 1) & 1);
+            LBC_MM(g & 1);
+            LBC_MIX();
+            __builtin_amdgcn_sched_barrier(0);    // the MFMAs of a step stay inside it: nothing is scheduled across the barrier below
+        }
+        LBC_WAIT_VM((NBUF - 2) * NL);
         LBC_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        LBC_RD(bn, koff0, fa0, fb0);
-        LBC_MM(fa1, fb1);
+        LBC_RD(bn, 0, 0);
+        LBC_MM((KS - 1) & 1);
         if (DIAG != 1) issue();
 #pragma unroll
         for (int k = 0; k < MT * NT; ++k) {
             LBC_SG(0x008, 1);
             if (k < MT + NT) LBC_SG(0x100, 1);
-            LBC_SG(0x036, 10);                    // VALU | SALU | VMEM: the address arithmetic and DMA pieces of tile t + 3
+            LBC_SG(0x036, 10);                    // VALU | SALU | VMEM: the address arithmetic and DMA pieces of tile t + NBUF
         }
         __builtin_amdgcn_sched_barrier(0);
     }
-    // ---- the last (up to) three tiles: nothing left to issue
+    // ---- the last (up to) NBUF tiles: nothing left to issue
     for (; t < nit; ++t) {
         const char* bb = smem + (t & (NBUF - 1)) * BUF;
         const char* bn = smem + ((t + 1) & (NBUF - 1)) * BUF;
-        LBC_RD(bb, koff1, fa1, fb1);
-        LBC_MM(fa0, fb0);
 #pragma unroll
-        for (int k = 0; k < MT + NT; ++k) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); }
-        LBC_SG(0x008, MT * NT - (MT + NT));
-        if (t + 2 < nit) LBC_WAIT_VM(NL);
-        else LBC_WAIT_VM(0);
+        for (int g = 0; g + 1 < KS; ++g) {
+            LBC_RD(bb, g + 1, (g + 1) & 1);
+            LBC_MM(g & 1);
+            LBC_MIX();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const int left = nit - t - 2;             // tiles younger than t + 1 that were issued
+        wait_tiles(left < 0 ? 0 : (left > NBUF - 2 ? NBUF - 2 : left));
         LBC_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < nit) LBC_RD(bn, koff0, fa0, fb0);
-        LBC_MM(fa1, fb1);
+        if (t + 1 < nit) LBC_RD(bn, 0, 0);
+        LBC_MM((KS - 1) & 1);
     }
 #undef LBC_RD
 #undef LBC_MM
+#undef LBC_MIX
 
     // ---- epilogue: affine / bias / residual / ReLU on the accumulators, per-channel (sum, sum^2), bf16 tile staged in LDS
     LBC_WAIT_LGKM0();
@@ -617,15 +646,27 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const int diag = lbc_opt(kOptGldsDiag) > 0 ? (int)lbc_opt(kOptGldsDiag) : 0;
     if (!lbc_opt_on(kOptGldsV1)) {
         LBC_REQUIRE(a.C % 32 == 0, "conv_glds: channel count");
+        // K-tile depth: 64 channels (whole cache lines per DMA row, half the barriers), except the 512 x 128 shape on >= 128
+        // channels (measured at batch 256: layer 2 0.098 ms with 32-channel tiles, 0.104 with 64; everything else equal or
+        // better with 64); LBC_GLDS_KT = 32 / 64 pins one
+        const bool kt64 = lbc_opt(kOptGldsKt) > 0 ? lbc_opt(kOptGldsKt) != 32 : !(cfg == kLbcCfgGlds + 3 && a.C >= 128);
 #define LBC_GL2(BMv, BNv, WMv, WNv)                                                                                          \
     do {                                                                                                                     \
-        if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0>), grid, dim3(512), 0, s, a, zero);            \
-        else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1>), grid, dim3(512), 0, s, a, zero);            \
+        if (kt64) {                                                                                                          \
+            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64>), grid, dim3(512), 0, s, a, zero);    \
+            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64>), grid, dim3(512), 0, s, a, zero);    \
+        } else {                                                                                                             \
+            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 32>), grid, dim3(512), 0, s, a, zero);    \
+            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 32>), grid, dim3(512), 0, s, a, zero);    \
+        }                                                                                                                    \
     } while (0)
         const long long dg = lbc_opt(kOptGldsDiag);
         if (dg > 0 && cfg == kLbcCfgGlds + 0 && mode == 0) {        // 1 = no DMA stream in the steady state, 2 = every piece from the zero page
-            if (dg == 1) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 1>), grid, dim3(512), 0, s, a, zero);
-            else         hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 2>), grid, dim3(512), 0, s, a, zero);
+            // 1 = no DMA stream in the steady state, 2 = every piece from the zero page, 3 = activation pieces from the zero page, 4 = weight pieces
+            if (dg == 1)      hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 1>), grid, dim3(512), 0, s, a, zero);
+            else if (dg == 2) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 2>), grid, dim3(512), 0, s, a, zero);
+            else if (dg == 3) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 3>), grid, dim3(512), 0, s, a, zero);
+            else              hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 4>), grid, dim3(512), 0, s, a, zero);
             return lbc_check_launch("conv_glds2");
         }
         if (cfg == kLbcCfgGlds + 0) LBC_GL2(256, 256, 2, 4);

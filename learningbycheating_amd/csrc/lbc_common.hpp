@@ -49,6 +49,7 @@ enum LbcOpt {
     kOptGemm256Cfg,        // LBC_GEMM256_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128)
     kOptGldsDiag,          // LBC_GLDS_DIAG: timing experiments on conv_glds.hip (wrong results): see lbc_conv_glds_launch
     kOptGldsV1,            // LBC_GLDS_V1: 1 = the first-generation (phase-barrier) kernel of conv_glds.hip
+    kOptGldsKt,            // LBC_GLDS_KT: 32 = 32-channel K-tiles in conv_glds2 (default 64)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
