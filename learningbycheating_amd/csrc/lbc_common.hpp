@@ -50,6 +50,7 @@ enum LbcOpt {
     kOptGldsDiag,          // LBC_GLDS_DIAG: timing experiments on conv_glds.hip (wrong results): see lbc_conv_glds_launch
     kOptGldsV1,            // LBC_GLDS_V1: 1 = the first-generation (phase-barrier) kernel of conv_glds.hip
     kOptGldsKt,            // LBC_GLDS_KT: 32 = 32-channel K-tiles in conv_glds2 (default 64)
+    kOptStemV1,            // LBC_STEM_V1: 1 = the first-generation bf16 stem forward (seven staged chunks per tile)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

@@ -742,6 +742,160 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_rows_k(StemWgradArgs a, int
     }
 }
 
+// bf16 stem forward, second generation (bf16 padded image).  The kernel above walks the seven filter rows as seven staged
+// chunks per 128-pixel tile: per chunk every thread issues 6 - 14 four-byte loads, converts, writes LDS, and the weights
+// are re-staged from f32 for every tile -- 343 us (RGB) / 466 us (7-channel bird view) at batch 256 for 0.6 / 0.4 GB of
+// traffic.  Here
+//   * a tile is 64 output pixels of ONE output row: its input is a band of 7 image rows x (2 * 64 + 5) pixels, i.e. seven
+//     contiguous byte ranges, copied raw (bf16, 4-byte loads, coalesced) into LDS -- no conversion, no transposition;
+//   * the A fragment of (filter row r, depth step g) for pixel p is the 8 consecutive bf16 at element 2 p Cin + 16 g + 8 kh
+//     of band row r: four ds_read_b32 (pixel stride 3 or 7 dwords: conflict-free); the k columns past the 7 Cin real ones read
+//     the neighbouring pixels (finite values) against zero weights;
+//   * the weights live in registers as bf16 B fragments for the whole (persistent) workgroup: 56 / 112 VGPRs;
+//   * the next tile's band is prefetched into registers while the current one is multiplied; the output tile goes through
+//     LDS to 16-byte stores; BatchNorm partial sums accumulate in registers across the workgroup's tiles (one row per workgroup).
+template <int CIN, typename T>
+__global__ __launch_bounds__(256, 2) void stem_fwd_rows_k(StemArgs a, int ntiles, int tiles_x)
+{
+    constexpr int L = 7 * CIN;
+    constexpr int KG = (L + 15) / 16;                          // depth steps per filter row (2 or 4)
+    constexpr int BX = 64;                                     // output pixels per tile
+    constexpr int BL = (2 * (BX - 1) + 7) * CIN;               // band elements per image row actually needed
+    constexpr int BD = (BL + 1) / 2;                           // ... in dwords
+    constexpr int RS = ((2 * (BX - 1) * CIN + KG * 16) * 2 + 15) / 16 * 16;   // LDS bytes per band row incl. the over-read of the last pixel
+    constexpr int NLD = (7 * BD + 255) / 256;                  // band dwords per thread
+    constexpr int OLD = 64 + (sizeof(T) == 2 ? 8 : 4);         // staged output row (elements): 64 channels + pad
+    __shared__ __attribute__((aligned(16))) char sBand[2][7 * RS];
+    __shared__ __attribute__((aligned(16))) T sOut[BX * OLD];
+    __shared__ float sRed[2][2][64];
+
+    const __bf16* xpad = static_cast<const __bf16*>(a.xp);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int wm = wave & 1, wn = wave >> 1;                   // pixel half, channel half
+    const int OH = a.H / 2, OW = a.W / 2;
+    const int Hp = a.H + 6, Wp = a.W + 6;
+    const long long total_elems = (long long)a.N * Hp * Wp * CIN;
+
+    // the band rows' tails (elements BL .. RS/2) are only ever read against zero weights: zero them once so they stay finite
+    for (int i = tid; i < 2 * 7 * RS / 4; i += 256) reinterpret_cast<unsigned*>(&sBand[0][0])[i] = 0u;
+
+    // B fragments: output channel 32 wn + l31, k-slot i of step (r, g) = filter column 16 g + 8 kh + i (zero past 7 Cin)
+    bf16x8 bw[7][KG];
+    {
+        const float* wrow = a.w + (size_t)(32 * wn + l31) * (49 * CIN);
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int g = 0; g < KG; ++g)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 16 * g + 8 * kh + i;
+                    bw[r][g][i] = (__bf16)(k < L ? wrow[r * L + (k < L ? k : 0)] : 0.f);
+                }
+    }
+    // band copy roles
+    int br[NLD], bj[NLD];
+#pragma unroll
+    for (int q = 0; q < NLD; ++q) {
+        const int idx = tid + 256 * q;
+        br[q] = idx / BD;
+        bj[q] = idx - br[q] * BD;
+    }
+    unsigned regs[NLD];
+    auto band_load = [&](int tile) {
+        const int xt = tile % tiles_x;
+        const int t2 = tile / tiles_x;
+        const int oy = t2 % OH, n = t2 / OH;
+        const long long e0 = ((long long)(n * Hp + 2 * oy) * Wp + 2 * xt * BX) * CIN;
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const long long e = e0 + (long long)br[q] * Wp * CIN + 2 * bj[q];
+            const bool ok = br[q] < 7 && e + 1 < total_elems;      // past the tensor only behind the last tile's last pixels
+            regs[q] = ok ? *reinterpret_cast<const unsigned*>(xpad + e) : 0u;
+        }
+    };
+    auto band_store = [&](int buf) {
+#pragma unroll
+        for (int q = 0; q < NLD; ++q)
+            if (br[q] < 7) *reinterpret_cast<unsigned*>(&sBand[buf][br[q] * RS + bj[q] * 4]) = regs[q];
+    };
+
+    float s1 = 0.f, s2 = 0.f;
+    int tile = blockIdx.x, it = 0;
+    if (tile < ntiles) band_load(tile);
+    __syncthreads();                                           // the zero fill above is complete
+    if (tile < ntiles) band_store(0);
+    __syncthreads();
+    for (; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        const int next = tile + gridDim.x;
+        if (next < ntiles) band_load(next);
+        const int xt = tile % tiles_x;
+        const int t2 = tile / tiles_x;
+        const int oy = t2 % OH, n = t2 / OH;
+        const int ox0 = xt * BX;
+        f32x16 acc;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+        const char* band = &sBand[buf][0] + ((32 * wm + l31) * 2 * CIN + 8 * kh) * 2;
+#pragma unroll
+        for (int r = 0; r < 7; ++r)
+#pragma unroll
+            for (int g = 0; g < KG; ++g) {
+                const unsigned* src = reinterpret_cast<const unsigned*>(band + r * RS + g * 32);
+                typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+                const u32x4 raw = {src[0], src[1], src[2], src[3]};
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, raw), bw[r][g], acc, 0, 0, 0);
+            }
+        // stage the 64 x 64 output tile and accumulate the statistics of the live pixels
+        const int col = 32 * wn + l31;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int prow = 32 * wm + (e & 3) + 8 * (e >> 2) + 4 * kh;
+            const float v = acc[e];
+            Act<T>::st1(&sOut[prow * OLD + col], v);
+            if (ox0 + prow < OW) { s1 += v; s2 += v * v; }
+        }
+        if (next < ntiles) band_store(buf ^ 1);
+        __syncthreads();
+        {
+            constexpr int EPT = 16;                            // elements per thread: 64 x 64 / 256
+            const int prow = tid >> 2, c0 = (tid & 3) * EPT;
+            if (ox0 + prow < OW) {
+                T* dst = static_cast<T*>(a.y) + ((size_t)(n * OH + oy) * OW + (size_t)(ox0 + prow)) * 64 + c0;
+                const T* srcp = &sOut[prow * OLD + c0];
+#pragma unroll
+                for (int v = 0; v < EPT * (int)sizeof(T) / 16; ++v)
+                    reinterpret_cast<f32x4*>(dst)[v] = reinterpret_cast<const f32x4*>(srcp)[v];
+            }
+        }
+        __syncthreads();                                       // sOut and the consumed band buffer are free again
+    }
+    if (a.stats) {
+        s1 += __shfl_xor(s1, 32);
+        s2 += __shfl_xor(s2, 32);
+        if (kh == 0) { sRed[wm][0][32 * wn + l31] = s1; sRed[wm][1][32 * wn + l31] = s2; }
+        __syncthreads();
+        if (tid < 64) {
+            float* dst = a.stats + (size_t)blockIdx.x * 2 * 64;
+            dst[tid] = sRed[0][0][tid] + sRed[1][0][tid];
+            dst[64 + tid] = sRed[0][1][tid] + sRed[1][1][tid];
+        }
+    }
+}
+
+// workgroups of the persistent kernel above (= its BatchNorm partial rows)
+static int stem_rows_grid(int N, int H, int W, int Cin)
+{
+    // as many workgroups as are resident at once (139 VGPRs -> 3 per CU for RGB, 238 -> 2 for the 7-channel bird view): a fourth
+    // wave of workgroups would start when the first ones finish and leave most CUs idle at the end
+    const long long tiles = (long long)N * (H / 2) * lbc_cdiv(W / 2, 64);
+    const long long grid = 256 * (Cin == 3 ? 3 : 2);
+    return (int)(tiles < grid ? tiles : grid);
+}
+static bool stem_fwd_rows(const StemArgs& a) { return a.bf16 && a.xp_bf16 && !lbc_opt_on(kOptStemV1); }
+
 }  // namespace
 
 int lbc_prep_input_u8(const unsigned char* img_nhwc, void* xp, int xp_bf16, int N, int C, int H, int W, const NormConst& nc, hipStream_t s)
@@ -768,7 +922,11 @@ int lbc_prep_input(const float* img_nchw, void* xp, int xp_bf16, int N, int C, i
     return lbc_check_launch("prep_input");
 }
 
-int lbc_stem_rows(const StemArgs& a) { return lbc_cdiv((long long)a.N * (a.H / 2) * (a.W / 2), 128); }
+int lbc_stem_rows(const StemArgs& a)
+{
+    if (stem_fwd_rows(a)) return stem_rows_grid(a.N, a.H, a.W, a.Cin);
+    return lbc_cdiv((long long)a.N * (a.H / 2) * (a.W / 2), 128);
+}
 
 int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
 {
@@ -779,6 +937,15 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
     const double Ms = (double)a.N * (a.H / 2) * (a.W / 2);
     LbcProfScope prof("stem_fwd", 2.0 * Ms * 64 * 49 * a.Cin, (a.xp_bf16 ? 2.0 : 4.0) * (double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (a.act_bf16 ? 2.0 : 4.0) * Ms * 64, s);
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem: bf16 output needs bf16 = 1");
+    if (stem_fwd_rows(a)) {
+        const int tx = lbc_cdiv(a.W / 2, 64);
+        const int ntiles = a.N * (a.H / 2) * tx;
+#define LBC_K(T, CI) hipLaunchKernelGGL((stem_fwd_rows_k<CI, T>), grid, dim3(256), 0, s, a, ntiles, tx)
+        if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
+        else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
+#undef LBC_K
+        return lbc_check_launch("stem_fwd");
+    }
     if (a.bf16) {
         LBC_REQUIRE(a.xp_bf16, "stem: the bf16 kernels read a bf16 padded image");
 #define LBC_K(T, CI) hipLaunchKernelGGL((stem_fwd_bf16_k<CI, T, __bf16>), grid, dim3(256), 0, s, a)
