@@ -568,9 +568,9 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         }
     }
     __syncthreads();
-    {
-        __bf16* yout = static_cast<__bf16*>(a.y);
-        constexpr int SEG = BN / 8;                     // 16-byte segments per output row
+    __bf16* yout = static_cast<__bf16*>(a.y);
+    constexpr int SEG = BN / 8;                         // 16-byte segments per output row
+    if (a.bnb_y == nullptr) {
 #pragma unroll 4
         for (int idx = tid; idx < BM * SEG; idx += 512) {
             const int row = idx / SEG, sg = idx - row * SEG;
@@ -579,14 +579,56 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
                 *reinterpret_cast<bf16x8*>(yout + (size_t)m * (size_t)a.K + (size_t)(n0 + sg * 8)) =
                     *reinterpret_cast<const bf16x8*>(smem + row * OROW + sg * 16);
         }
-    }
-    if (a.stats && tid < BN) {
-        float t1 = 0.f, t2 = 0.f;
+        if (a.stats && tid < BN) {
+            float t1 = 0.f, t2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
-        float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
-        dst[n0 + tid] = t1;
-        dst[a.K + n0 + tid] = t2;
+            for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
+            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+            dst[n0 + tid] = t1;
+            dst[a.K + n0 + tid] = t2;
+        }
+    } else {
+        // Fused BatchNorm-backward reduce (IgemmArgs::bnb_*): the copy-out pass reads the pre-BN activation next to the staged
+        // gradient (16 bytes each), masks, stores, and sums (g, g * xhat) for the thread's fixed 8-channel segment
+        // (512 % SEG == 0); the 512 / SEG threads of a segment are combined through LDS in thread order (deterministic).
+        static_assert(512 % SEG == 0, "conv_glds2: segment ownership");
+        const __bf16* by = static_cast<const __bf16*>(a.bnb_y);
+        const int sg = tid % SEG;
+        const int c0 = n0 + sg * 8;
+        const f32x8 bsc = ParamVec<8>::ld(a.bnb_scale + c0), bsh = ParamVec<8>::ld(a.bnb_shift + c0);
+        const f32x8 bmu = ParamVec<8>::ld(a.bnb_mean + c0), biv = ParamVec<8>::ld(a.bnb_invstd + c0);
+        f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
+#pragma unroll 4
+        for (int row = tid / SEG; row < BM; row += 512 / SEG) {
+            const int m = m0 + row;
+            if (m < a.M) {
+                const size_t o = (size_t)m * (size_t)a.K + (size_t)c0;
+                const f32x8 yv = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(by + o), f32x8);
+                f32x8 g = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(smem + row * OROW + sg * 16), f32x8);
+                const f32x8 z = yv * bsc + bsh;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+                *reinterpret_cast<bf16x8*>(yout + o) = __builtin_convertvector(g, bf16x8);
+                t1 += g;
+                t2 += g * (yv - bmu) * biv;
+            }
+        }
+        __syncthreads();                                // the staged tile has been consumed: its LDS holds the partial sums now
+        float* ps = reinterpret_cast<float*>(smem);     // [512][16]
+        ParamVec<8>::st(ps + tid * 16, t1);
+        ParamVec<8>::st(ps + tid * 16 + 8, t2);
+        __syncthreads();
+        if (a.stats && tid < BN) {
+            const int seg = tid >> 3, e = tid & 7;
+            float u1 = 0.f, u2 = 0.f;
+            for (int k = 0; k < 512 / SEG; ++k) {
+                u1 += ps[(k * SEG + seg) * 16 + e];
+                u2 += ps[(k * SEG + seg) * 16 + 8 + e];
+            }
+            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+            dst[n0 + tid] = u1;
+            dst[a.K + n0 + tid] = u2;
+        }
     }
 }
 #undef LBC_SG

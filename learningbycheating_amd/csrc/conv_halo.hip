@@ -28,7 +28,7 @@ constexpr int kHaloRowsMax = 336;   // 128 + 2*W + 2 with W <= 103
 // CU, whose load / MFMA / store phases overlap) and the MFMA loop reads one LDS fragment per MFMA with no barrier.
 // Measured phase costs of the single-workgroup-per-CU predecessor (weights in LDS, 133 KB) were additive:
 // skeleton 0.05 + MFMA 0.06 + output stores 0.05 + halo 0.03 ms per launch = 0.185 ms.
-template <int MODE>
+template <int MODE, bool BNB>
 __global__ __launch_bounds__(256, 2) void conv3x3_c64_k(IgemmArgs a)
 {
     constexpr int BM = 128, BN = 64, BK = 64, LDK = BK + 8;
@@ -136,16 +136,30 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_k(IgemmArgs a)
         // read inside the store loop, every 2-byte load is waited for on its own (32 serial L2 round trips per tile).
         float s1 = 0.f, s2 = 0.f;
         const int col = wn * 32 + l31;
+        // fused BatchNorm-backward reduce (IgemmArgs::bnb_*): this lane's channel constants
+        // (BNB is a template parameter: the register file is full of weights, and the plain instantiation must not pay for it;
+        //  the fused instantiation serves conv2's input gradient, which has no residual)
+        const __bf16* bnb = BNB ? static_cast<const __bf16*>(a.bnb_y) : nullptr;
+        float bsc = 0.f, bsh = 0.f, bmu = 0.f, biv = 0.f;
+        if (BNB) { bsc = a.bnb_scale[col]; bsh = a.bnb_shift[col]; bmu = a.bnb_mean[col]; biv = a.bnb_invstd[col]; }
 #pragma unroll
         for (int hb = 0; hb < MT * 2; ++hb) {          // 8 accumulator rows at a time (the register file is full of weights)
             const int mi = hb >> 1, e0 = (hb & 1) * 8;
-            float rv[8];
-            if (resid) {
+            float rv[8], bv[8];
+            if (!BNB && resid) {
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     const int e = e0 + k;
                     const int m = m0 + (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
                     rv[k] = (float)resid[(unsigned)(m < M ? m : 0) * (unsigned)BN + (unsigned)col];
+                }
+            }
+            if (BNB) {
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    const int e = e0 + k;
+                    const int m = m0 + (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                    bv[k] = (float)bnb[(unsigned)(m < M ? m : 0) * (unsigned)BN + (unsigned)col];
                 }
             }
 #pragma unroll
@@ -158,11 +172,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_k(IgemmArgs a)
                     float v = acc[mi][e];
                     if (a.post_scale) v = v * a.post_scale[col] + a.post_shift[col];
                     if (a.bias) v += a.bias[col];
-                    if (resid) v += rv[k];
+                    if (!BNB && resid) v += rv[k];
                     if (a.relu) v = fmaxf(v, 0.f);
-                    yout[o] = (__bf16)v;
-                    s1 += v;
-                    s2 += v * v;
+                    if (BNB) {
+                        // sums of the STORED (bf16) gradient, as the separate reduce pass sees it
+                        const float g = (bv[k] * bsc + bsh > 0.f) ? (float)(__bf16)v : 0.f;
+                        yout[o] = (__bf16)g;
+                        s1 += g;
+                        s2 += g * (bv[k] - bmu) * biv;
+                    } else {
+                        yout[o] = (__bf16)v;
+                        s1 += v;
+                        s2 += v * v;
+                    }
                 }
             }
         }
@@ -198,7 +220,11 @@ int lbc_conv3x3_halo_launch(const IgemmArgs& a, int mode, hipStream_t s)
     int cap = 512;
     if (lbc_opt(kOptHaloBlocks) >= 8) cap = (int)lbc_opt(kOptHaloBlocks) & ~7;   // tests: force multi-tile workgroups
     if (nb > cap) nb = cap;
-    if (mode == 0) hipLaunchKernelGGL((conv3x3_c64_k<0>), dim3((unsigned)nb), dim3(256), 0, s, a);
-    else           hipLaunchKernelGGL((conv3x3_c64_k<1>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    if (a.bnb_y) {
+        LBC_REQUIRE(mode == 1 && !a.resid, "conv3x3_halo: the fused BatchNorm-backward reduce serves input gradients without a residual");
+        hipLaunchKernelGGL((conv3x3_c64_k<1, true>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    }
+    else if (mode == 0) hipLaunchKernelGGL((conv3x3_c64_k<0, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
+    else                hipLaunchKernelGGL((conv3x3_c64_k<1, false>), dim3((unsigned)nb), dim3(256), 0, s, a);
     return lbc_check_launch("conv3x3_c64");
 }

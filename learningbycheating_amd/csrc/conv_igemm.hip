@@ -496,6 +496,13 @@ int lbc_igemm_rows(const IgemmArgs& a, int cfg)
     return lbc_cdiv(a.M, kCfgBM[cfg]);
 }
 
+bool lbc_igemm_fuses_bn_bwd(const IgemmArgs& a, int wmajor, int mode, int cfg)
+{
+    if (lbc_opt_on(kOptNoBnBwdFuse) || mode != 1 || !a.act_bf16) return false;
+    if (cfg >= kLbcCfgGlds) return !lbc_opt_on(kOptGldsV1);          // conv_glds2_k
+    return wmajor && !a.resid && lbc_conv3x3_halo_eligible(a, mode); // conv3x3_c64_k<1, true>
+}
+
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode)
 {
     if (lbc_opt(kOptForceCfg) < 0) {     // a forced tile policy pins conv_igemm.hip

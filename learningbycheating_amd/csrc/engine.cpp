@@ -485,15 +485,21 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
 // ---------------------------------------------------------------------------------------
 // BatchNorm backward: reduce (sum g, sum g*xhat) -> dgamma/dbeta + coefficients -> dx
 int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
-                     float* dx, int Cout, hipStream_t s, const BN* mask_bn, bool join_before_apply)
+                     float* dx, int Cout, hipStream_t s, const BN* mask_bn, bool join_before_apply, int reduced_rows)
 {
-    ChanReduceArgs r;
-    memset(&r, 0, sizeof(r));
-    r.x = x; r.dz = dz; r.mask = mask; r.g_out = g_out; r.mean = W(bn.mean); r.invstd = W(bn.invstd);
-    if (mask_bn) { r.mask_scale = W(mask_bn->scale); r.mask_shift = W(mask_bn->shift); }
-    r.partial = W(partial_); r.pixels = pixels; r.C = bn.C; r.act_bf16 = act_bf16_;
-    LBC_TRY(lbc_chan_reduce(r, 1, s));
-    int rows = lbc_chan_reduce_rows(pixels, bn.C);
+    int rows = reduced_rows;
+    if (reduced_rows <= 0) {
+        ChanReduceArgs r;
+        memset(&r, 0, sizeof(r));
+        r.x = x; r.dz = dz; r.mask = mask; r.g_out = g_out; r.mean = W(bn.mean); r.invstd = W(bn.invstd);
+        if (mask_bn) { r.mask_scale = W(mask_bn->scale); r.mask_shift = W(mask_bn->shift); }
+        r.partial = W(partial_); r.pixels = pixels; r.C = bn.C; r.act_bf16 = act_bf16_;
+        LBC_TRY(lbc_chan_reduce(r, 1, s));
+        rows = lbc_chan_reduce_rows(pixels, bn.C);
+    } else {
+        mask = nullptr;          // dz is the masked gradient already
+        g_out = const_cast<float*>(dz);
+    }
     const float* part = W(partial_);
     if (rows > kLbcFinalizeRows) {
         LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * bn.C, W(partial2_), 64, s));
@@ -538,8 +544,10 @@ int Net::conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const floa
 }
 
 // dx[N,H,W,Cin] = dgrad(dy) (+ resid).  For the 1x1/2 downsample only the even-even phase is touched.
-int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s)
+int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s, const BN* bnb,
+                    const float* bnb_y, int* fused_rows)
 {
+    if (fused_rows) *fused_rows = 0;
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
     a.x = dy; a.w = P(c.w); a.y = dx; a.resid = resid;
@@ -559,7 +567,14 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     if (c.s == 1) {
         a.LH = c.H; a.LW = c.W; a.ostep = 1;
         a.M = N * c.H * c.W;
-        return lbc_igemm_launch(a, wmajor, 1, wmajor ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K), s);
+        const int cfg = wmajor ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K);
+        if (bnb && bnb_y && fused_rows && lbc_igemm_fuses_bn_bwd(a, wmajor, 1, cfg)) {
+            a.bnb_y = bnb_y; a.bnb_scale = W(bnb->scale); a.bnb_shift = W(bnb->shift);
+            a.bnb_mean = W(bnb->mean); a.bnb_invstd = W(bnb->invstd);
+            a.stats = W(partial_);
+            *fused_rows = lbc_igemm_rows(a, cfg);
+        }
+        return lbc_igemm_launch(a, wmajor, 1, cfg, s);
     }
     a.LH = c.H / 2; a.LW = c.W / 2; a.ostep = 2;
     a.M = N * a.LH * a.LW;
@@ -581,14 +596,17 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
     // out = relu(bn2(y2) + identity): mask by out, keep masked gradient in D for the identity path
     LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E, b.b2.C, s, nullptr, true));   // E = dY2
     LBC_TRY(fork(s));
+    // the reduce pass of bn1's backward rides on conv2's input-gradient epilogue where that kernel can (mask = bn1(y1) > 0 and
+    // xhat both come from y1: one extra read instead of a 4-tensor pass)
+    int fr = 0;
     if (b.fuse_z1) {
         LBC_TRY(conv_wgrad_pre(b.c2, W(b.c1.y), &b.b1, E, N, wstream(s)));
-        LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                               // F = dZ1
-        LBC_TRY(bn_backward(b.b1, F, W(b.c1.y), F, W(b.c1.y), pix, E, b.b1.C, s, &b.b1, true));   // E = dY1 (mask = bn1(y1) > 0)
+        LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s, &b.b1, W(b.c1.y), &fr));        // F = dZ1 (masked when fr > 0)
+        LBC_TRY(bn_backward(b.b1, F, W(b.c1.y), F, W(b.c1.y), pix, E, b.b1.C, s, &b.b1, true, fr));   // E = dY1 (mask = bn1(y1) > 0)
     } else {
         LBC_TRY(conv_wgrad(b.c2, W(b.z1), E, N, wstream(s)));
-        LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s));                               // F = dZ1
-        LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E, b.b1.C, s, nullptr, true));   // E = dY1
+        LBC_TRY(conv_dgrad(b.c2, E, nullptr, F, N, s, &b.b1, W(b.c1.y), &fr));        // F = dZ1 (masked when fr > 0)
+        LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E, b.b1.C, s, nullptr, true, fr));   // E = dY1
     }
     LBC_TRY(fork(s));
     LBC_TRY(conv_wgrad(b.c1, xin, E, N, wstream(s)));

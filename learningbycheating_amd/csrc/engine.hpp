@@ -104,8 +104,9 @@ private:
     int weight_prep(hipStream_t s);
     bool conv_takes_glds(const Conv& c, int N) const;
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
+    // reduced_rows > 0: dz is already masked and partial_ holds that many rows of (sum g, sum g * xhat) (fused into the producer)
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
-                    float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr, bool join_before_apply = false);
+                    float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr, bool join_before_apply = false, int reduced_rows = 0);
     // Backward runs the weight gradients of the residual blocks on an internal side stream, next to the input gradients that
     // consume the same dY (independent work; it fills the chip at small per-GPU batches).  fork: the side stream waits for
     // everything enqueued on s so far; join: s waits for the side stream.  Inactive while the launch profiler is on.
@@ -116,7 +117,10 @@ private:
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     bool side_allowed_ = true, side_on_ = false, side_dirty_ = false;
     int conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s);
-    int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s);
+    // bnb (+ bnb_y): fuse the reduce pass of that BatchNorm's backward into the epilogue when the kernel can (*fused_rows = partial
+    // rows written to partial_, else 0)
+    int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s, const BN* bnb = nullptr,
+                   const float* bnb_y = nullptr, int* fused_rows = nullptr);
     int block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s);
     int backward_impl(const float* d_sel, const float* d_all, int stage, hipStream_t s);
     long long generation_ = 0;

@@ -51,6 +51,7 @@ enum LbcOpt {
     kOptGldsV1,            // LBC_GLDS_V1: 1 = the first-generation (phase-barrier) kernel of conv_glds.hip
     kOptGldsKt,            // LBC_GLDS_KT: 32 = 32-channel K-tiles in conv_glds2 (default 64)
     kOptStemV1,            // LBC_STEM_V1: 1 = the first-generation bf16 stem forward (seven staged chunks per tile)
+    kOptNoBnBwdFuse,       // LBC_NO_BN_BWD_FUSE: 1 = BatchNorm-backward reduce always as its own pass (A/B, tests)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
@@ -108,7 +109,18 @@ struct IgemmArgs {
     int bf16;             // 1: bf16 MFMA operands (f32 accumulation), needs wmajor weights and C % 64 == 0
     int act_bf16;         // 1: x / y / resid are bf16 tensors (requires bf16 = 1)
     int w_bf16;           // 1: w is a bf16 copy of the weights (requires bf16 = 1, depth-contiguous)
+    // Fused BatchNorm-backward reduce (input-gradient launches whose output is the gradient wrt relu(bn(bnb_y))): the epilogue
+    // stores g = out * (bnb_y * bnb_scale + bnb_shift > 0) and writes the partial rows (sum g, sum g * xhat),
+    // xhat = (bnb_y - bnb_mean) * bnb_invstd, to `stats` -- what channel_reduce_k (op 1) would compute in a pass of its own.
+    // Only kernels for which lbc_igemm_fuses_bn_bwd() is true honour it.
+    const void* bnb_y;    // like y, or nullptr
+    const float* bnb_scale;
+    const float* bnb_shift;
+    const float* bnb_mean;
+    const float* bnb_invstd;
 };
+// true when the kernel a (cfg, wmajor, mode) launch takes implements IgemmArgs::bnb_*
+bool lbc_igemm_fuses_bn_bwd(const IgemmArgs& a, int wmajor, int mode, int cfg);
 
 // One launch converts every convolution weight of a network to bf16, in its own layout w[A][T][B] and transposed
 // wt[B][T][A] (the depth-contiguous operand of the input-gradient / transposed-convolution GEMMs).

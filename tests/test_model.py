@@ -460,6 +460,37 @@ def test_native_trainer_runs_and_is_deterministic(env):
     assert not torch.equal(before, student.deconv[1].weight.detach())
 
 
+@pytest.mark.parametrize("glds", [False, True])
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 16, marks=gpu)])
+def test_bn_backward_reduce_fused_into_dgrad_epilogue(env, kind, backbone, h, w, n, glds, lbc_config):
+    """bf16 mode: the reduce pass of bn1's backward rides on conv2's input-gradient epilogue (conv_halo.hip for the 64-channel
+    layer, conv_glds.hip when selected).  Same rounding points as the separate pass (sums of the stored bf16 gradient), only the
+    order of the partial rows differs: every gradient tensor must agree with the unfused executor to f32 summation noise."""
+    dev, _ = env
+    if glds:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+    sd = O.make_state_dict(kind, backbone, 11, h, w)
+    x, speed, cmd = _inputs(kind, n, h, w, 9)
+    g = torch.Generator().manual_seed(6)
+    d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g), torch.randn((n, 5, 2), generator=g)
+    grads = []
+    for nofuse in (0, 1):
+        lbc_config("LBC_NO_BN_BWD_FUSE", nofuse)
+        eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=2)
+        eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
+        eng.backward(d_sel.to(dev), d_all.to(dev))
+        grads.append({k: v.detach().cpu().clone() for k, v in eng.grad_views.items()})
+    rel = []
+    for k in grads[0]:
+        a, b = grads[0][k], grads[1][k]
+        rel.append((a - b).abs().max().item() / (b.abs().max().item() + 1e-12))
+    rel.sort()
+    # a different order of f32 partial sums can flip a bf16 rounding of dY1 (relative step 2^-8) for isolated elements, which
+    # the layers below amplify (measured on the 34-layer network at batch 16 with every eligible layer fused: worst tensor 2.2e-2
+    # of its largest entry, median tensor 5.9e-3 = one to two bf16 steps; the 18-layer emulator case stays below 5e-3)
+    assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
+
+
 @pytest.mark.parametrize("precision", [1, 2, "2-tiles128", "2-glds"])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),
                                                  pytest.param("birdview", "resnet18", 192, 192, 8, marks=gpu)])
