@@ -80,7 +80,6 @@ class FramePool:
         self.speed = (torch.rand(n_frames, generator=g) * 10).pin_memory()
         self.cmd = torch.randint(1, 5, (n_frames,), generator=g).float()
         self.loc = (torch.rand((n_frames, 5, 2), generator=g) * 192).pin_memory()
-        self.onehot_stage = [torch.empty((batch, 4)).pin_memory() for _ in range(2)]
 
         def slot():
             d = {"bv": torch.empty((batch, 192, 192, 7), dtype=torch.uint8, device=device), "speed": torch.empty(batch, device=device),
@@ -100,10 +99,13 @@ class FramePool:
     def prefetch(self, k):
         """enqueue the H2D copies of the next batch into slot k (call right after the step that used slot k was enqueued)"""
         from learningbycheating_amd.bird_view.utils.train_utils import one_hot
-        self.ready[k].synchronize()          # the host never runs more than two steps ahead (the pinned one-hot stage is reused)
+        self.ready[k].synchronize()          # the host never runs more than two steps ahead
         s = slice(self.pos, self.pos + self.batch)
         self.pos = (self.pos + self.batch) % self.n
-        self.onehot_stage[k].copy_(one_hot(self.cmd[s]))      # reference bird_view/utils/train_utils.py:33-40, per batch, on the host
+        # reference bird_view/utils/train_utils.py:33-40, per batch, on the host.  The 4 KB result goes up from pageable memory:
+        # a pinned buffer that the GPU has read is expensive to rewrite on this platform (inference.py, scripts/diag_latency.py);
+        # the frame arrays below are written once and only ever read by the DMA engine
+        onehot = one_hot(self.cmd[s])
         d = self.slots[k]
         with torch.cuda.stream(self.copy):
             self.copy.wait_event(self.free[k])               # the step that read slot k has finished with it
@@ -112,7 +114,7 @@ class FramePool:
             d["bv"].copy_(self.bv[s], non_blocking=True)
             d["speed"].copy_(self.speed[s], non_blocking=True)
             d["loc"].copy_(self.loc[s], non_blocking=True)
-            d["onehot"].copy_(self.onehot_stage[k], non_blocking=True)
+            d["onehot"].copy_(onehot, non_blocking=True)
             self.ready[k].record(self.copy)
 
     def get(self, k):

@@ -138,7 +138,11 @@ class DeviceLoader:
         self.aug = augmenter_mod.BatchAugmenter(None, seed=seed * 31 + rank) if self.strategy else None
         self.images_seen = dataset.batch_read_number
         cuda = self.device.type == "cuda"
-        pin = (lambda t: t.pin_memory()) if cuda else (lambda t: t)
+        # Staging in pageable memory unless LBC_PIN_STAGING=1: on the MI355X boxes a pinned buffer that the GPU has read since
+        # the CPU last wrote it is slow to rewrite (184 KB: 3.2 ms, then 5.7 ms for the next H2D -- scripts/diag_latency.py),
+        # and these buffers are rewritten for every batch; from pageable memory the runtime stages the copy itself
+        import os
+        pin = (lambda t: t.pin_memory()) if (cuda and os.environ.get("LBC_PIN_STAGING") == "1") else (lambda t: t)
         B = batch_size
         self.stage = [{"rgb": pin(torch.empty((B, 160, 384, 3), dtype=torch.uint8)), "bv": pin(torch.empty((B, 320, 320, 7), dtype=torch.uint8)),
                        "loc": pin(torch.empty((B, dataset.n_step, 2))), "speed": pin(torch.empty(B)), "cmd": torch.empty(B)} for _ in range(2)]

@@ -899,5 +899,24 @@ def test_batch1_inference_session_matches_reference_forward(env, kind, backbone,
         for _ in range(50):
             ses.run_step(frame, 3.0, 2)
         lat[name] = (time.perf_counter() - t0) / 50 * 1e3
-    _diag(dev, "batch-1 inference %s %s f32: |waypoint - oracle| max %.2e; latency per run_step (H2D + forward + D2H): hipGraph %.3f ms, eager %.3f ms"
-          % (kind, backbone, worst, lat["graph"], lat["eager"]))
+    # the same session in the bf16 mode (what a deployed agent would run): within the declared tolerance of the f32 session
+    from learningbycheating_amd import WAYPOINT_TOLERANCE
+    net3 = (ImagePolicyModelSS if kind == "image" else BirdViewPolicyModelSS)(backbone, all_branch=True)
+    net3.load_state_dict(sd)
+    net3.precision = "bf16"
+    ses_b = PolicySession(net3, dev, use_graph=True)
+    frame = torch.randint(0, 256, (h, w, c), generator=g, dtype=torch.uint8)
+    if kind == "birdview":
+        frame = (frame > 230).to(torch.uint8) * 255
+    db = float(np.abs(ses_b.run_step(frame.numpy(), 4.0, 3) - ses_g.run_step(frame.numpy(), 4.0, 3)).max())
+    assert db < 3 * WAYPOINT_TOLERANCE["bf16"], db     # (an uncalibrated random network: looser than the trained-like bound)
+    zf = np.zeros((h, w, c), np.uint8)
+    for _ in range(5):
+        ses_b.run_step(zf, 3.0, 2)
+    t0 = time.perf_counter()
+    for _ in range(50):
+        ses_b.run_step(zf, 3.0, 2)
+    lat["bf16"] = (time.perf_counter() - t0) / 50 * 1e3
+    _diag(dev, "batch-1 inference %s %s: f32 |waypoint - oracle| max %.2e, bf16 vs f32 %.2e; latency per run_step (H2D + forward + D2H): "
+               "f32 hipGraph %.3f ms, f32 eager %.3f ms, bf16 hipGraph %.3f ms"
+          % (kind, backbone, worst, db, lat["graph"], lat["eager"], lat["bf16"]))
