@@ -778,13 +778,21 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
         f.dgamma = G(stem_bn_.g); f.dbeta = G(stem_bn_.b);
         f.coefA = W(stem_bn_.cA); f.coefB = W(stem_bn_.cB); f.coefD = W(stem_bn_.cD);
         LBC_TRY(lbc_bn_bwd_finalize(f, s));
-        BnBwdApplyArgs ap;
-        memset(&ap, 0, sizeof(ap));
-        ap.g = W(g0_); ap.x = W(y0_); ap.coefA = W(stem_bn_.cA); ap.coefB = W(stem_bn_.cB); ap.coefD = W(stem_bn_.cD);
-        ap.mean = W(stem_bn_.mean); ap.invstd = W(stem_bn_.invstd);
-        ap.dx = W(g0_); ap.pixels = pix; ap.C = 64; ap.Cout = 64; ap.act_bf16 = act_bf16_;
-        LBC_TRY(lbc_bn_bwd_apply(ap, s));
         StemWgradArgs sw;
+        memset(&sw, 0, sizeof(sw));
+        if (lbc_stem_wgrad_fuses_bn_bwd(d_.in_channels, bf16_)) {
+            // the apply pass dx = A (g - k1 - xhat k2) feeds only the stem's weight gradient (nothing lies below conv1): that kernel
+            // forms it while it stages g (-1 read and -1 write of the largest activation, +1 read of y0 there)
+            sw.bn_y = W(y0_); sw.bn_coefA = W(stem_bn_.cA); sw.bn_coefB = W(stem_bn_.cB); sw.bn_coefD = W(stem_bn_.cD);
+            sw.bn_mean = W(stem_bn_.mean); sw.bn_invstd = W(stem_bn_.invstd);
+        } else {
+            BnBwdApplyArgs ap;
+            memset(&ap, 0, sizeof(ap));
+            ap.g = W(g0_); ap.x = W(y0_); ap.coefA = W(stem_bn_.cA); ap.coefB = W(stem_bn_.cB); ap.coefD = W(stem_bn_.cD);
+            ap.mean = W(stem_bn_.mean); ap.invstd = W(stem_bn_.invstd);
+            ap.dx = W(g0_); ap.pixels = pix; ap.C = 64; ap.Cout = 64; ap.act_bf16 = act_bf16_;
+            LBC_TRY(lbc_bn_bwd_apply(ap, s));
+        }
         sw.xp = W(xp_); sw.xp_bf16 = bf16_; sw.dy = W(g0_); sw.partial = W(wg_partial_);
         sw.N = N; sw.H = H0; sw.W = W0; sw.Cin = d_.in_channels; sw.act_bf16 = act_bf16_; sw.bf16 = bf16_;
         sw.nsplit = lbc_stem_wgrad_split(N, H0, W0, d_.in_channels, bf16_);

@@ -114,7 +114,12 @@ struct StemWgradArgs {
     int N, H, W, Cin, nsplit;
     int act_bf16;
     int bf16;                    // 1: bf16 MFMA operands (f32 accumulation)
+    // Fused BatchNorm-backward apply (nullable; honoured when lbc_stem_wgrad_fuses_bn_bwd()): dy holds the masked gradient g wrt
+    // bn1's output and the kernel forms dy' = A (g - k1 - xhat k2), xhat = (bn_y - mean) invstd, as it stages dy
+    const void* bn_y;            // [N][H/2][W/2][64] pre-BN stem output (same element type as dy)
+    const float* bn_coefA; const float* bn_coefB; const float* bn_coefD; const float* bn_mean; const float* bn_invstd;
 };
+bool lbc_stem_wgrad_fuses_bn_bwd(int Cin, int bf16);
 int lbc_stem_wgrad_split(int N, int H, int W, int Cin, int bf16);   // partial slabs of the kernel a (Cin, bf16) launch takes
 int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s);
 

@@ -655,7 +655,15 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_rows_k(StemWgradArgs a, int
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[r][e] = 0.f;
 
-    preg_t rp[4];
+    // fused BatchNorm-backward apply (StemWgradArgs::bn_*): this thread's four channels
+    const T* bny = static_cast<const T*>(a.bn_y);
+    f32x4 cA = {1.f, 1.f, 1.f, 1.f}, cB = {0.f, 0.f, 0.f, 0.f}, cD = cB, cM = cB, cI = cB;
+    if (bny) {
+        cA = *reinterpret_cast<const f32x4*>(a.bn_coefA + pcg * 4); cB = *reinterpret_cast<const f32x4*>(a.bn_coefB + pcg * 4);
+        cD = *reinterpret_cast<const f32x4*>(a.bn_coefD + pcg * 4); cM = *reinterpret_cast<const f32x4*>(a.bn_mean + pcg * 4);
+        cI = *reinterpret_cast<const f32x4*>(a.bn_invstd + pcg * 4);
+    }
+    preg_t rp[4], ry[4];
     unsigned rq[3][4][2];
     bool pok[4], qok[3][4];
     for (int ch = -1; ch < nchunk; ++ch) {
@@ -667,6 +675,7 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_rows_k(StemWgradArgs a, int
                 const int m = mc + 4 * ppg + i;
                 pok[i] = m < mend;
                 rp[i] = *reinterpret_cast<const preg_t*>(dy + (size_t)(pok[i] ? m : 0) * 64 + (size_t)(pcg * 4));
+                if (bny) ry[i] = *reinterpret_cast<const preg_t*>(bny + (size_t)(pok[i] ? m : 0) * 64 + (size_t)(pcg * 4));
             }
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
@@ -704,7 +713,11 @@ __global__ __launch_bounds__(256, 2) void stem_wgrad_rows_k(StemWgradArgs a, int
             for (int c = 0; c < 4; ++c) {
                 f32x4 col;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) col[i] = pok[i] ? (float)rp[i][c] : 0.f;
+                for (int i = 0; i < 4; ++i) {
+                    float g = (float)rp[i][c];
+                    if (bny) g = cA[c] * (g - cB[c] - ((float)ry[i][c] - cM[c]) * cI[c] * cD[c]);     // as bn_bwd_apply_k
+                    col[i] = pok[i] ? g : 0.f;
+                }
                 *reinterpret_cast<bf16x4*>(&sP[buf][(pcg * 4 + c) * LD + ppg * 4]) = __builtin_convertvector(col, bf16x4);
             }
 #pragma unroll
@@ -961,6 +974,7 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
 
 // true when the launch takes stem_wgrad_rows_k (all seven filter rows per workgroup)
 static bool stem_wgrad_rows(int Cin, int bf16) { return bf16 && Cin == 3; }
+bool lbc_stem_wgrad_fuses_bn_bwd(int Cin, int bf16) { return stem_wgrad_rows(Cin, bf16) && !lbc_opt_on(kOptNoBnBwdFuse); }
 
 int lbc_stem_wgrad_split(int N, int H, int W, int Cin, int bf16)
 {
@@ -986,6 +1000,7 @@ int lbc_stem_wgrad(const StemWgradArgs& a, hipStream_t s)
     const long long M = (long long)a.N * (a.H / 2) * (a.W / 2);
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem_wgrad: bf16 gradients need bf16 = 1");
     LbcProfScope prof("stem_wgrad", 2.0 * M * 64 * 49 * a.Cin, 4.0 * ((double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (double)M * 64), s);
+    LBC_REQUIRE(!a.bn_y || lbc_stem_wgrad_fuses_bn_bwd(a.Cin, a.bf16), "stem_wgrad: this kernel has no fused BatchNorm-backward apply");
     if (stem_wgrad_rows(a.Cin, a.bf16)) {
         LBC_REQUIRE(a.xp_bf16, "stem_wgrad: the bf16 kernels read a bf16 padded image");
         LBC_REQUIRE(a.nsplit >= 2 && a.nsplit % 2 == 0, "stem_wgrad: nsplit %d (use lbc_stem_wgrad_split)", a.nsplit);
