@@ -30,21 +30,9 @@
 //        before the barrier the refilling wave has just crossed.
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
+#include "conv_lds_dma.hpp"
 
 namespace {
-
-// s_waitcnt immediate, gfx9 layout: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[5:4] at [15:14]
-constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | ((vm >> 4) << 14) | (7 << 4) | ((lgkm & 15) << 8); }
-#define LBC_WAIT_VM(n) __builtin_amdgcn_s_waitcnt(waitcnt_imm((n), 15))
-#define LBC_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0))
-
-typedef __attribute__((address_space(1))) const void* gas_ptr;
-typedef __attribute__((address_space(3))) void* las_ptr;
-// 16 bytes per lane from a per-lane global address to (wave-uniform LDS base) + 16 * lane
-__device__ __forceinline__ void lds_dma16(const void* g, void* lds_wave_base)
-{
-    __builtin_amdgcn_global_load_lds((gas_ptr)g, (las_ptr)lds_wave_base, 16, 0, 0);
-}
 
 template <int BM, int BN, int WM, int WN, int NBUF, int MODE>
 __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* zero_page, const int diag)
@@ -514,122 +502,8 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
 #undef LBC_MM
 #undef LBC_MIX
 
-    // ---- epilogue: affine / bias / residual / ReLU on the accumulators, per-channel (sum, sum^2), bf16 tile staged in LDS
-    LBC_WAIT_LGKM0();
-    __builtin_amdgcn_s_barrier();                      // every wave has left the main loop: the ring is free
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    const __bf16* resid = static_cast<const __bf16*>(a.resid);
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        float rv[16][NT];
-        if (resid) {        // fetched per 32-row block before its use: inside the loop every 2-byte load is waited for alone
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const size_t ob = (size_t)(m < a.M ? m : 0) * (size_t)a.K;
-#pragma unroll
-                for (int nj = 0; nj < NT; ++nj) rv[r][nj] = (float)resid[ob + (size_t)(n0 + wn * WTN + nj * 32 + l31)];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const bool live = m0 + row < a.M;
-#pragma unroll
-            for (int nj = 0; nj < NT; ++nj) {
-                const int cl = wn * WTN + nj * 32 + l31;
-                const int col = n0 + cl;
-                float v = acc[mi][nj][r];
-                if (a.post_scale) v = v * a.post_scale[col] + a.post_shift[col];
-                if (a.bias) v += a.bias[col];
-                if (resid) v += rv[r][nj];
-                if (a.relu) v = fmaxf(v, 0.f);
-                *reinterpret_cast<__bf16*>(smem + row * OROW + cl * 2) = (__bf16)v;
-                if (live) { s1[nj] += v; s2[nj] += v * v; }
-            }
-        }
-    }
-    float* red = reinterpret_cast<float*>(smem + STAGE);   // [WM][2][BN]
-    if (a.stats) {
-#pragma unroll
-        for (int nj = 0; nj < NT; ++nj) {
-            s1[nj] += __shfl_xor(s1[nj], 32);
-            s2[nj] += __shfl_xor(s2[nj], 32);
-        }
-        if (kh == 0) {
-#pragma unroll
-            for (int nj = 0; nj < NT; ++nj) {
-                const int c = wn * WTN + nj * 32 + l31;
-                red[(wm * 2 + 0) * BN + c] = s1[nj];
-                red[(wm * 2 + 1) * BN + c] = s2[nj];
-            }
-        }
-    }
-    __syncthreads();
-    __bf16* yout = static_cast<__bf16*>(a.y);
-    constexpr int SEG = BN / 8;                         // 16-byte segments per output row
-    if (a.bnb_y == nullptr) {
-#pragma unroll 4
-        for (int idx = tid; idx < BM * SEG; idx += 512) {
-            const int row = idx / SEG, sg = idx - row * SEG;
-            const int m = m0 + row;
-            if (m < a.M)
-                *reinterpret_cast<bf16x8*>(yout + (size_t)m * (size_t)a.K + (size_t)(n0 + sg * 8)) =
-                    *reinterpret_cast<const bf16x8*>(smem + row * OROW + sg * 16);
-        }
-        if (a.stats && tid < BN) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
-            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
-            dst[n0 + tid] = t1;
-            dst[a.K + n0 + tid] = t2;
-        }
-    } else {
-        // Fused BatchNorm-backward reduce (IgemmArgs::bnb_*): the copy-out pass reads the pre-BN activation next to the staged
-        // gradient (16 bytes each), masks, stores, and sums (g, g * xhat) for the thread's fixed 8-channel segment
-        // (512 % SEG == 0); the 512 / SEG threads of a segment are combined through LDS in thread order (deterministic).
-        static_assert(512 % SEG == 0, "conv_glds2: segment ownership");
-        const __bf16* by = static_cast<const __bf16*>(a.bnb_y);
-        const int sg = tid % SEG;
-        const int c0 = n0 + sg * 8;
-        const f32x8 bsc = ParamVec<8>::ld(a.bnb_scale + c0), bsh = ParamVec<8>::ld(a.bnb_shift + c0);
-        const f32x8 bmu = ParamVec<8>::ld(a.bnb_mean + c0), biv = ParamVec<8>::ld(a.bnb_invstd + c0);
-        f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
-#pragma unroll 4
-        for (int row = tid / SEG; row < BM; row += 512 / SEG) {
-            const int m = m0 + row;
-            if (m < a.M) {
-                const size_t o = (size_t)m * (size_t)a.K + (size_t)c0;
-                const f32x8 yv = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(by + o), f32x8);
-                f32x8 g = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(smem + row * OROW + sg * 16), f32x8);
-                const f32x8 z = yv * bsc + bsh;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
-                *reinterpret_cast<bf16x8*>(yout + o) = __builtin_convertvector(g, bf16x8);
-                t1 += g;
-                t2 += g * (yv - bmu) * biv;
-            }
-        }
-        __syncthreads();                                // the staged tile has been consumed: its LDS holds the partial sums now
-        float* ps = reinterpret_cast<float*>(smem);     // [512][16]
-        ParamVec<8>::st(ps + tid * 16, t1);
-        ParamVec<8>::st(ps + tid * 16 + 8, t2);
-        __syncthreads();
-        if (a.stats && tid < BN) {
-            const int seg = tid >> 3, e = tid & 7;
-            float u1 = 0.f, u2 = 0.f;
-            for (int k = 0; k < 512 / SEG; ++k) {
-                u1 += ps[(k * SEG + seg) * 16 + e];
-                u2 += ps[(k * SEG + seg) * 16 + 8 + e];
-            }
-            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
-            dst[n0 + tid] = u1;
-            dst[a.K + n0 + tid] = u2;
-        }
-    }
+    // ---- epilogue (conv_lds_dma.hpp): affine / bias / residual / ReLU, LDS-staged 16-byte stores, statistics / fused BN-backward reduce
+    lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, mtile);
 }
 #undef LBC_SG
 
