@@ -1,0 +1,303 @@
+// 3x3 / stride-1 / pad-1 convolution (forward and input gradient) on bf16 tensors for gfx950 with the ACTIVATION HALO staged
+// once per 64-channel slab: the third member of the LDS-DMA family (conv_glds.hip explains the family).
+// reference arithmetic: BasicBlock conv1 / conv2, bird_view/models/resnet.py:15-22,38-54, and their autograd.
+//
+// Why: conv_glds2_k streams the activation tile of every (tap, slab) K-tile separately -- nine shifted copies of the same
+// rows -- and its timing experiments put ~20 us of a 72 us layer-3 launch on the latency of that stream.
+// Here a workgroup stages, per 64-channel slab, the BM + 2W + 2 input rows its BM output pixels can touch ONCE (LDS-DMA, two
+// buffers: slab c + 1 lands while slab c is multiplied); the nine taps are row offsets of the fragment reads, exactly as in
+// conv_halo.hip.  Only the weights still stream per (tap, slab): a ring of NBUFB tiles of BN x 64, as in conv_glds2_k.
+//   * LDS rows are 128 bytes, 16-byte slot XOR-ed with (row >> 1) & 7 (on the DMA source and on the read) -> conflict-free
+//     ds_read_b128; a tap changes the row, hence the XOR term: 2 VALU per fragment read (one v_xor, one v_lshl_add).
+//   * Image borders: a lane whose tap leaves the image reads a 128-byte ZERO ROW instead (the last row of the halo buffer, which
+//     lies past the halo and is filled from the zero page; one select on the row base per (tap, 32-row block)) -- no masking
+//     of the fragments themselves.
+//   * Synchronisation as conv_glds2_k with 64-channel K-tiles: one barrier per K-tile in front of its last depth step; the
+//     wave's own weight pieces of the next K-tile are waited for with a counted vmcnt (halo pieces are always OLDER in the
+//     wave's DMA queue than the first weight tile of their slab: they are issued in the first 9 - NBUFB taps of the
+//     previous slab, that weight tile after them -- so the same wait covers them).
+#include "lbc_common.hpp"
+#include "lbc_act.hpp"
+#include "conv_lds_dma.hpp"
+
+namespace {
+
+#define LBC_SG(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+
+template <int BM, int BN, int WM, int WN, int HRMAX, int NBUFB, int MODE>
+__global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* zero_page)
+{
+    constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    static_assert(WM * WN == 8 && NT == 2 && (MT == 2 || MT == 4), "conv_hdma: wave tiling");
+    static_assert(HRMAX % 64 == 0 && BN % 64 == 0 && (NBUFB == 2 || NBUFB == 4), "conv_hdma: staging");
+    constexpr int KS = 4;                                       // depth steps of 16 channels per K-tile
+    constexpr int ABYTES = HRMAX * 128;                         // one halo buffer: HRMAX rows x 64 channels
+    constexpr int TILE_B = BN * 128;
+    constexpr int BRING = 2 * ABYTES;                           // weight ring behind the two halo buffers
+    constexpr int MAIN = BRING + NBUFB * TILE_B;
+    constexpr int ZROW = (HRMAX - 1) * 128;                     // last row of either halo buffer: always beyond the halo, filled from the zero page
+    constexpr int EPI = lds_dma_epilogue_bytes<BM, BN, WM>();
+    constexpr int SMEM = MAIN > EPI ? MAIN : EPI;
+    static_assert(SMEM <= 160 * 1024, "conv_hdma: LDS");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
+    constexpr int HPW = HRMAX / 64;                             // 1-KiB halo pieces (8 rows) per wave per slab
+    constexpr int NBW = BN / 64;                                // 1-KiB weight pieces per wave per K-tile
+    constexpr int ATAPS = 9 - NBUFB;                            // taps of a slab whose issue slot may carry halo pieces (see above)
+    constexpr int AP = (HPW + ATAPS - 1) / ATAPS;               // halo pieces per such tap
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int W = a.W, H = a.H, C = a.C;
+
+    const int ntn = a.K / BN;
+    int tile_id;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int mtile = tile_id / ntn;
+    const int m0 = mtile * BM;
+    const int n0 = (tile_id - mtile * ntn) * BN;
+
+    const __bf16* xin = static_cast<const __bf16*>(a.x);
+    const __bf16* win = static_cast<const __bf16*>(a.w);
+    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 7) * 8;
+
+    // ---- DMA roles.  Halo row hr holds input pixel m0 - (W + 1) + hr; rows outside the tensor come from the zero page (they are
+    //      only ever met by taps that the border select below redirects, but they must not be read from unmapped memory), and so
+    //      do the buffer rows past the halo (BM + 2W + 2 < HRMAX): the last of them is the ZERO ROW of the border select
+    const int prow = lane >> 3, pseg = lane & 7;
+    int aoff[HPW];
+    bool aval[HPW];
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) {
+        const int row = (wave * HPW + j) * 8 + prow;
+        const int q = m0 - (W + 1) + row;
+        aval[j] = q >= 0 && q < a.M && row < BM + 2 * W + 2;
+        aoff[j] = (aval[j] ? q : 0) * C + (pseg ^ ((row >> 1) & 7)) * 8;
+    }
+    int boff[NBW];
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) {
+        const int row = (wave * NBW + j) * 8 + prow;
+        boff[j] = (n0 + row) * (9 * C) + (pseg ^ ((row >> 1) & 7)) * 8;
+    }
+    // ---- fragment roles.  Weights: row l31 of a 32-row block, slot (2g + kh) ^ ((l31 >> 1) & 7).  Activations: halo row of the
+    //      centre tap per 32-row block + per-lane tap validity
+    int koffB[KS];
+#pragma unroll
+    for (int g = 0; g < KS; ++g) koffB[g] = ((2 * g + kh) ^ ((l31 >> 1) & 7)) << 4;
+    const int bBase = BRING + (wn * WTN + l31) * 128;
+    int rowc[MT], amask[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+        const int row = wm * WTM + i * 32 + l31;
+        rowc[i] = W + 1 + row;
+        const int m = m0 + row;
+        int bits = 0;
+        if (m < a.M) {
+            const int x = m % W;
+            const int y = (m / W) % H;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int r = t / 3, s = t - 3 * r;
+                const int dy = MODE == 0 ? r - 1 : 1 - r;
+                const int dx = MODE == 0 ? s - 1 : 1 - s;
+                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
+            }
+        }
+        amask[i] = bits;
+    }
+
+    const int nslab = C / 64;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // halo pieces [p0, p1) of slab `slab` into halo buffer slab & 1
+    auto issue_a = [&](const int slab, const int p0, const int p1) {
+        char* base = smem + (slab & 1) * ABYTES;
+#pragma unroll
+        for (int j = 0; j < HPW; ++j) {
+            if (j < p0 || j >= p1) continue;
+            const __bf16* src = aval[j] ? xin + (aoff[j] + slab * 64) : zero;
+            lds_dma16(src, base + (wave * HPW + j) * 1024);
+        }
+    };
+    // weight tile of K-tile k = (slab, tap) into ring slot k % NBUFB
+    auto issue_b = [&](const int slab, const int tap, const int slot) {
+        char* base = smem + BRING + slot * TILE_B;
+        const int koffs = tap * C + slab * 64;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) lds_dma16(win + (boff[j] + koffs), base + (wave * NBW + j) * 1024);
+    };
+
+    // per (tap, 32-row block): byte offset of the lane's halo row in its buffer (or of the zero row) and the XOR term of its slot
+    int abase[2][MT], axor[2][MT];          // [set]: the K-tile being multiplied / the next one
+    auto tap_addr = [&](const int tap, const int slab, int (&base)[MT], int (&xr)[MT]) {
+        const int r = tap / 3, s = tap - 3 * r;
+        const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
+        const int abuf = (slab & 1) * ABYTES;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int hr = rowc[i] + off;
+            const bool ok = (amask[i] >> tap) & 1;
+            base[i] = abuf + (ok ? (hr << 7) : ZROW);
+            xr[i] = ok ? (kh ^ ((hr >> 1) & 7)) : kh;            // slot (2g + kh) ^ f(hr) = 2g ^ (kh ^ f(hr))
+        }
+    };
+
+    bf16x8 fa[2][MT], fb[2][NT];            // two register sets: depth step g computes from set g & 1 while set (g + 1) & 1 is read
+#define LBC_RD(SLOT, G, SET, ASET)                                                                                               \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
+            fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + abase[ASET][i] + (((2 * (G)) ^ axor[ASET][i]) << 4));           \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
+            fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + bBase + j * 32 * 128 + koffB[G]);             \
+    } while (0)
+#define LBC_MM(SET)                                                                                                              \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);                 \
+    } while (0)
+
+    // ---- prologue: the halo of slab 0 and up to NBUFB weight tiles in flight; everything of K-tile 0 landed and visible
+    issue_a(0, 0, HPW);
+    const int nk = 9 * nslab;
+#pragma unroll
+    for (int k = 0; k < NBUFB; ++k)
+        if (k < nk) issue_b(0, k, k);        // (nk >= 9 > NBUFB: the first NBUFB K-tiles are taps of slab 0)
+    LBC_WAIT_VM((NBUFB - 1) * NBW);
+    __builtin_amdgcn_s_barrier();
+    tap_addr(0, 0, abase[0], axor[0]);
+    LBC_RD(0, 0, 0, 0);
+
+    // One slab = nine K-tiles, taps unrolled.  LAST: no slab c + 1 to prefetch, and the weight ring drains.
+    auto slab_body = [&](const int c, auto last_tag) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        // The (row base, XOR term) of a tap do not depend on the slab: left alone, the compiler hoists all 9 x MT pairs out of
+        // the slab loop (72 registers at MT = 4 -> 800 bytes of scratch per lane).  Make the inputs opaque per slab instead:
+        // recomputing them is 5 VALU per (tap, 32-row block) next to 4 MT MFMAs.
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rowc[i]), "+v"(amask[i]));
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int k = 9 * c + t;
+            const int slot = k & (NBUFB - 1), nslot = (k + 1) & (NBUFB - 1);
+            const int cur = t & 1, nxt = cur ^ 1;                         // address set of this tap / of the next K-tile
+            const bool has_next = !LAST || t < 8;
+#pragma unroll
+            for (int g = 0; g + 1 < KS; ++g) {
+                LBC_RD(slot, g + 1, (g + 1) & 1, cur);
+                LBC_MM(g & 1);
+                if (g == 1 && has_next) tap_addr(t < 8 ? t + 1 : 0, t < 8 ? c : c + 1, abase[nxt], axor[nxt]);
+#pragma unroll
+                for (int q = 0; q < MT + NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); LBC_SG(0x002, 3); }
+                if (MT * NT > MT + NT) LBC_SG(0x008, MT * NT - (MT + NT));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // own weight pieces of K-tile k + 1 landed; up to NBUFB - 2 younger tiles may stay in flight (fewer while the ring drains)
+            {
+                constexpr int younger_max = NBUFB - 2;
+                const int left = LAST ? (7 - t > 0 ? 7 - t : 0) : younger_max;
+                const int allow = left < younger_max ? left : younger_max;
+                if (allow >= 2) LBC_WAIT_VM(2 * NBW);
+                else if (allow == 1) LBC_WAIT_VM(NBW);
+                else LBC_WAIT_VM(0);
+            }
+            LBC_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_sched_barrier(0);
+            if (has_next) LBC_RD(nslot, 0, 0, nxt);
+            LBC_MM((KS - 1) & 1);
+            if (!LAST || t + NBUFB < 9) {
+                const int kn = t + NBUFB;                                  // K-tile k + NBUFB -> the ring slot of K-tile k
+                issue_b(kn < 9 ? c : c + 1, kn < 9 ? kn : kn - 9, slot);
+            }
+            if (!LAST && t < ATAPS && t * AP < HPW) issue_a(c + 1, t * AP, (t + 1) * AP < HPW ? (t + 1) * AP : HPW);
+#pragma unroll
+            for (int q = 0; q < MT * NT; ++q) {
+                LBC_SG(0x008, 1);
+                if (q < MT + NT) LBC_SG(0x100, 1);
+                LBC_SG(0x036, 8);                                          // VALU | SALU | VMEM: address arithmetic and DMA pieces
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // nine taps flip the set parity: the next slab's tap 0 (computed into set 1 during tap 8) is expected in set 0
+#pragma unroll
+        for (int i = 0; i < MT; ++i) { abase[0][i] = abase[1][i]; axor[0][i] = axor[1][i]; }
+    };
+    for (int c = 0; c + 1 < nslab; ++c) slab_body(c, std::false_type{});
+    slab_body(nslab - 1, std::true_type{});
+#undef LBC_RD
+#undef LBC_MM
+
+    // ---- epilogue (conv_lds_dma.hpp)
+    lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, mtile);
+}
+#undef LBC_SG
+
+struct HdmaCfg { int bm, bn, hrmax; };
+// cfg ids kLbcCfgHdma + 0 .. 2
+const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{256, 256, 320}, {256, 128, 384}, {128, 256, 192}};
+
+}  // namespace
+
+// Tile configuration for a launch, or -1 when the launch keeps conv_glds.hip / conv_igemm.hip.
+int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
+{
+    if (lbc_opt_on(kOptNoHdma) || lbc_opt_on(kOptNoGemm256) || lbc_opt_on(kOptGldsV1)) return -1;
+    if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
+    if (a.KH != 3 || a.KW != 3 || a.P != 1 || a.S != 1 || a.C % 64 || (mode != 0 && mode != 1)) return -1;
+    if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || (long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return -1;
+    if ((long long)a.K * 9 * a.C >= (1ll << 31)) return -1;
+    const long long fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 192;
+    const long long forced = lbc_opt(kOptHdmaCfg);          // tests / tuning: pin one shape
+    int best = -1;
+    double best_score = 0.0;
+    for (int i = 0; i < kLbcHdmaCfgs; ++i) {
+        const HdmaCfg& c = kHdmaCfg[i];
+        if (a.K % c.bn) continue;
+        if (forced >= 0 && forced != i) continue;
+        if (i == 0 && forced != 0) continue;                // 256 x 256: 128 accumulator registers per wave leave too few for the rest (108 bytes of scratch): tests only
+        if (c.bm + 2 * a.W + 2 >= c.hrmax) continue;        // the halo of a tile + one zero row must fit its LDS buffer
+        const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn);
+        if (tiles < fill) continue;
+        const double score = (double)tiles / (double)(((tiles + 255) / 256) * 256) * (c.bm * c.bn >= 256 * 256 ? 1.0 : 0.9);
+        if (score > best_score) { best_score = score; best = i; }
+    }
+    return best < 0 ? -1 : kLbcCfgHdma + best;
+}
+
+int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kHdmaCfg[cfg - kLbcCfgHdma].bm); }
+
+int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
+{
+    LBC_REQUIRE(cfg >= kLbcCfgHdma && cfg < kLbcCfgHdma + kLbcHdmaCfgs, "conv_hdma: bad cfg %d", cfg);
+    const HdmaCfg c = kHdmaCfg[cfg - kLbcCfgHdma];
+    LBC_REQUIRE(a.K % c.bn == 0 && a.C % 64 == 0 && c.bm + 2 * a.W + 2 < c.hrmax, "conv_hdma: shape not tileable");
+    const void* zero = nullptr;
+    int rc = lbc_zero_page(&zero);
+    if (rc) return rc;
+    const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
+#define LBC_HD(BMv, BNv, WMv, WNv, HRv, NBv)                                                                                 \
+    do {                                                                                                                     \
+        if (mode == 0) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0>), grid, dim3(512), 0, s, a, zero);   \
+        else           hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 1>), grid, dim3(512), 0, s, a, zero);   \
+    } while (0)
+    if (cfg == kLbcCfgHdma + 0) LBC_HD(256, 256, 2, 4, 320, 2);
+    else if (cfg == kLbcCfgHdma + 1) LBC_HD(256, 128, 4, 2, 384, 4);
+    else LBC_HD(128, 256, 2, 4, 192, 2);
+#undef LBC_HD
+    return lbc_check_launch("conv_hdma");
+}

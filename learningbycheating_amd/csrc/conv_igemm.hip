@@ -491,6 +491,7 @@ int lbc_weight_prep(const WeightPrepArgs& a, hipStream_t s)
 
 int lbc_igemm_rows(const IgemmArgs& a, int cfg)
 {
+    if (cfg >= kLbcCfgHdma) return lbc_conv_hdma_rows(a, cfg);
     if (cfg >= kLbcCfgGlds) return lbc_conv_glds_rows(a, cfg);
     if (lbc_conv3x3_halo_eligible(a, 0)) return lbc_cdiv(a.M, 128);   // that kernel always works on 128-pixel tiles
     return lbc_cdiv(a.M, kCfgBM[cfg]);
@@ -499,13 +500,18 @@ int lbc_igemm_rows(const IgemmArgs& a, int cfg)
 bool lbc_igemm_fuses_bn_bwd(const IgemmArgs& a, int wmajor, int mode, int cfg)
 {
     if (lbc_opt_on(kOptNoBnBwdFuse) || mode != 1 || !a.act_bf16) return false;
-    if (cfg >= kLbcCfgGlds) return !lbc_opt_on(kOptGldsV1);          // conv_glds2_k
+    if (cfg >= kLbcCfgGlds) return !lbc_opt_on(kOptGldsV1);          // conv_glds2_k, conv_hdma_k (shared epilogue)
     return wmajor && !a.resid && lbc_conv3x3_halo_eligible(a, mode); // conv3x3_c64_k<1, true>
 }
 
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode)
 {
     if (lbc_opt(kOptForceCfg) < 0) {     // a forced tile policy pins conv_igemm.hip
+        // 3x3 stride-1 launches of the wide layers: the halo-staged LDS-DMA kernel first
+        if (!lbc_conv3x3_halo_eligible(a, mode)) {
+            const int h = lbc_conv_hdma_pick(a, mode);
+            if (h >= 0) return h;
+        }
         const int g = lbc_conv_glds_pick(a, mode);
         // the 64-channel layers have two candidates: conv_halo.hip, unless the 512 x 64 LDS-DMA shape is selected
         if (g >= 0 && (g == kLbcCfgGlds + 4 || !lbc_conv3x3_halo_eligible(a, mode))) return g;
@@ -525,7 +531,7 @@ int lbc_igemm_pick(long long M, int K)
 
 int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStream_t s)
 {
-    LBC_REQUIRE(cfg >= 0 && cfg < kLbcCfgGlds + kLbcGldsCfgs, "igemm: bad cfg %d", cfg);
+    LBC_REQUIRE(cfg >= 0 && cfg < kLbcCfgHdma + kLbcHdmaCfgs, "igemm: bad cfg %d", cfg);
     LBC_REQUIRE(a.C % (a.bf16 ? 64 : 32) == 0, "igemm: gathered channels %d not a multiple of %d", a.C, a.bf16 ? 64 : 32);
     LBC_REQUIRE(!a.bf16 || wmajor, "igemm: the bf16 path needs depth-contiguous weights (transpose first)");
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "igemm: bf16 activations need bf16 = 1");
@@ -550,12 +556,17 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     const double in_elems = (double)a.N * a.H * a.W * a.C * ((mode == 1 && a.S == 2) ? nph / 4.0 : 1.0);
     // profile class = kernel family + GEMM orientation
     const bool halo = cfg < kLbcCfgGlds && wmajor && lbc_conv3x3_halo_eligible(a, mode);
-    const char* pname = cfg >= kLbcCfgGlds ? (mode == 0 ? "conv_glds_gather" : "conv_glds_transposed")
+    const char* pname = cfg >= kLbcCfgHdma ? (mode == 0 ? "conv_hdma_gather" : "conv_hdma_transposed")
+                        : cfg >= kLbcCfgGlds ? (mode == 0 ? "conv_glds_gather" : "conv_glds_transposed")
                         : halo ? (mode == 0 ? "conv_halo_gather" : "conv_halo_transposed")
                                : (mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed");
     LbcProfScope prof(pname, 2.0 * a.M * nph * a.K * (double)a.C * taps,
                       (a.act_bf16 ? 2.0 : 4.0) * (in_elems + nph * (double)a.M * a.K * (a.resid ? 2 : 1)) +
                           (a.w_bf16 ? 2.0 : 4.0) * taps * nph * a.C * a.K, s);
+    if (cfg >= kLbcCfgHdma) {
+        LBC_REQUIRE(wmajor && lbc_conv_hdma_pick(a, mode) >= 0, "igemm: launch not eligible for the halo-staged LDS-DMA kernel");
+        return lbc_conv_hdma_launch(a, mode, cfg, s);
+    }
     if (cfg >= kLbcCfgGlds) {
         LBC_REQUIRE(wmajor && lbc_conv_glds_pick(a, mode) >= 0, "igemm: launch not eligible for the 8-wave LDS-DMA kernel");
         return lbc_conv_glds_launch(a, mode, cfg, s);

@@ -263,7 +263,7 @@ bool Net::conv_takes_glds(const Conv& c, int N) const
     a.N = N; a.H = c.H; a.W = c.W; a.C = c.Cin; a.OH = c.OH; a.OW = c.OW; a.K = c.Cout;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p; a.M = N * c.OH * c.OW; a.LH = c.OH; a.LW = c.OW; a.ostep = 1;
     a.bf16 = 1; a.act_bf16 = 1; a.w_bf16 = 1;
-    return lbc_conv_glds_pick(a, 0) >= 0;
+    return lbc_igemm_pick_for(a, 0) >= kLbcCfgGlds;        // conv_glds.hip or conv_hdma.hip
 }
 
 int Net::weight_prep(hipStream_t s)

@@ -52,6 +52,8 @@ enum LbcOpt {
     kOptGldsKt,            // LBC_GLDS_KT: 32 = 32-channel K-tiles in conv_glds2 (default 64)
     kOptStemV1,            // LBC_STEM_V1: 1 = the first-generation bf16 stem forward (seven staged chunks per tile)
     kOptNoBnBwdFuse,       // LBC_NO_BN_BWD_FUSE: 1 = BatchNorm-backward reduce always as its own pass (A/B, tests)
+    kOptNoHdma,            // LBC_NO_HDMA: 1 = never use the halo-staged LDS-DMA convolution (conv_hdma.hip)
+    kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
@@ -145,6 +147,11 @@ int lbc_igemm_pick(long long M, int K);            // tile configuration 0..2 of
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
 constexpr int kLbcGldsCfgs = 5;
+constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256}
+constexpr int kLbcHdmaCfgs = 3;
+int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
+int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
+int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64} or -1
 int lbc_conv_glds_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);

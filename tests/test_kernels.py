@@ -374,6 +374,55 @@ def test_conv_wgrad_tap_fused(env, cfg):
     assert relerr(dw2, w2.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
 
 
+# ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
+HDMA_BM = {0: 256, 1: 256, 2: 128}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256
+HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
+              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2)]
+HDMA_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, -1), (64, 10, 24, 256, 256, -1), (256, 5, 12, 512, 512, -1),
+                                                   (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 0)]]
+
+
+@pytest.mark.parametrize("case", HDMA_SMALL + HDMA_REAL)
+def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
+    """forward (statistics; residual + ReLU) and input gradient (flipped taps, identity gradient added) of the halo-staged kernel
+    against f32 convolutions of the bf16-rounded operands: ragged M tails, image borders and several images inside a tile, one
+    to eight channel slabs, one or two column tiles, halo rows before / after the tensor"""
+    dev, _ = env
+    from learningbycheating_amd import _lib
+    N, H, W, C, K, cfgid = case
+    if cfgid >= 0:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+        lbc_config("LBC_HDMA_CFG", cfgid)
+    x, w = make((N, H, W, C, K, 3, 1, 1), 290 + C + K)
+    x = rbf(x)
+    ref = F.conv2d(x, rbf(w), None, 1, 1)
+    rows = ctypes.c_int(0)
+    d = _lib.ConvDesc(N, H, W, C, K, 3, 3, 1, 1, 0, 3, 0)
+    _lib.check(_lib.get().lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
+    M = N * H * W
+    assert rows.value in ([-(-M // HDMA_BM[cfgid])] if cfgid >= 0 else [-(-M // b) for b in (128, 256)]), (rows.value, M)
+    y, st = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
+    assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(st[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), rtol=1e-3)
+    g = torch.Generator().manual_seed(291)
+    r = rbf(torch.randn(ref.shape, generator=g))
+    y2, _ = Conv(dev).fwd(x, w, 1, 1, resid=r, relu=1, bf16=3)
+    assert relerr(y2, F.relu(ref + r)) < 1e-4 + OUT_TOL[2]
+    xg = x.clone().requires_grad_(True)
+    yy = F.conv2d(xg, rbf(w), None, 1, 1)
+    dy = rbf(torch.randn(yy.shape, generator=g))
+    yy.backward(dy)
+    if K % 64 == 0 and C % 128 == 0:        # the input gradient's output channels are C: needs a column tile of 128 / 256
+        rr = rbf(torch.randn(x.shape, generator=g))
+        dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
+        assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
+    # A/B: the per-tap LDS-DMA kernel on the same launch gives the same result up to summation order
+    lbc_config("LBC_NO_HDMA", 1)
+    y3, _ = Conv(dev).fwd(x, w, 1, 1, bf16=3)
+    assert relerr(y, y3) < 2.0 ** -7
+
+
 @pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 3, 1), (1, 12, 14, 128, 256, 3, 2), (3, 8, 10, 64, 128, 1, 3), (2, 6, 34, 128, 128, 3, 3)] +
                          [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128, 3, -1), (64, 20, 48, 128, 256, 3, -1), (64, 40, 96, 64, 128, 1, -1), (256, 10, 24, 256, 512, 3, -1)]])
 def test_conv_glds_stride2_gather(env, case, lbc_config):
@@ -571,6 +620,7 @@ def test_conv_glds_fwd_dgrad(env, case, gen, lbc_config):
         if cfgid == 4:
             pytest.skip("512 x 64 tiles exist in the second-generation kernel only")
         lbc_config("LBC_GLDS_V1", 1)       # the first-generation (phase-barrier) kernel, kept for A/B runs
+    lbc_config("LBC_NO_HDMA", 1)           # this test is about conv_glds.hip (3x3 stride-1 launches prefer conv_hdma.hip otherwise)
     if cfgid >= 0:
         lbc_config("LBC_GEMM256_MIN_TILES", 1)
         lbc_config("LBC_GEMM256_CFG", cfgid)
