@@ -88,9 +88,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
     }
     // ---- fragment roles.  Weights: row l31 of a 32-row block, slot (2g + kh) ^ ((l31 >> 1) & 7).  Activations: halo row of the
     //      centre tap per 32-row block + per-lane tap validity
-    int koffB[KS];
-#pragma unroll
-    for (int g = 0; g < KS; ++g) koffB[g] = ((2 * g + kh) ^ ((l31 >> 1) & 7)) << 4;
+    const int bxor = kh ^ ((l31 >> 1) & 7);                    // slot (2g + kh) ^ f(row) = 2g ^ (kh ^ f(row))
     const int bBase = BRING + (wn * WTN + l31) * 128;
     int rowc[MT], amask[MT];
 #pragma unroll
@@ -142,7 +140,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
     };
 
     // per (tap, 32-row block): byte offset of the lane's halo row in its buffer (or of the zero row) and the XOR term of its slot
-    int abase[2][MT], axor[2][MT];          // [set]: the K-tile being multiplied / the next one
+    int abase[MT], axor[MT];                // of the K-tile whose fragments are being read; recomputed for the next one after its last read
     auto tap_addr = [&](const int tap, const int slab, int (&base)[MT], int (&xr)[MT]) {
         const int r = tap / 3, s = tap - 3 * r;
         const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
@@ -157,12 +155,12 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
     };
 
     bf16x8 fa[2][MT], fb[2][NT];            // two register sets: depth step g computes from set g & 1 while set (g + 1) & 1 is read
-#define LBC_RD(SLOT, G, SET, ASET)                                                                                               \
+#define LBC_RD(SLOT, G, SET)                                                                                                     \
     do {                                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
-            fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + abase[ASET][i] + (((2 * (G)) ^ axor[ASET][i]) << 4));           \
+            fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + (((2 * (G)) ^ axor[i]) << 4));           \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
-            fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + bBase + j * 32 * 128 + koffB[G]);             \
+            fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + bBase + j * 32 * 128 + (((2 * (G)) ^ bxor) << 4));             \
     } while (0)
 #define LBC_MM(SET)                                                                                                              \
     do {                                                                                                                         \
@@ -179,8 +177,8 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
         if (k < nk) issue_b(0, k, k);        // (nk >= 9 > NBUFB: the first NBUFB K-tiles are taps of slab 0)
     LBC_WAIT_VM((NBUFB - 1) * NBW);
     __builtin_amdgcn_s_barrier();
-    tap_addr(0, 0, abase[0], axor[0]);
-    LBC_RD(0, 0, 0, 0);
+    tap_addr(0, 0, abase, axor);
+    LBC_RD(0, 0, 0);
 
     // One slab = nine K-tiles, taps unrolled.  LAST: no slab c + 1 to prefetch, and the weight ring drains.
     auto slab_body = [&](const int c, auto last_tag) {
@@ -194,13 +192,13 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
         for (int t = 0; t < 9; ++t) {
             const int k = 9 * c + t;
             const int slot = k & (NBUFB - 1), nslot = (k + 1) & (NBUFB - 1);
-            const int cur = t & 1, nxt = cur ^ 1;                         // address set of this tap / of the next K-tile
             const bool has_next = !LAST || t < 8;
 #pragma unroll
             for (int g = 0; g + 1 < KS; ++g) {
-                LBC_RD(slot, g + 1, (g + 1) & 1, cur);
+                LBC_RD(slot, g + 1, (g + 1) & 1);
+                // the reads of the last depth step are out: the addresses are free for the next K-tile's (tap, slab)
+                if (g == KS - 2 && has_next) tap_addr(t < 8 ? t + 1 : 0, t < 8 ? c : c + 1, abase, axor);
                 LBC_MM(g & 1);
-                if (g == 1 && has_next) tap_addr(t < 8 ? t + 1 : 0, t < 8 ? c : c + 1, abase[nxt], axor[nxt]);
 #pragma unroll
                 for (int q = 0; q < MT + NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); LBC_SG(0x002, 3); }
                 if (MT * NT > MT + NT) LBC_SG(0x008, MT * NT - (MT + NT));
@@ -218,7 +216,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
             LBC_WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
-            if (has_next) LBC_RD(nslot, 0, 0, nxt);
+            if (has_next) LBC_RD(nslot, 0, 0);
             LBC_MM((KS - 1) & 1);
             if (!LAST || t + NBUFB < 9) {
                 const int kn = t + NBUFB;                                  // K-tile k + NBUFB -> the ring slot of K-tile k
@@ -233,9 +231,6 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
             }
             __builtin_amdgcn_sched_barrier(0);
         }
-        // nine taps flip the set parity: the next slab's tap 0 (computed into set 1 during tap 8) is expected in set 0
-#pragma unroll
-        for (int i = 0; i < MT; ++i) { abase[0][i] = abase[1][i]; axor[0][i] = axor[1][i]; }
     };
     for (int c = 0; c + 1 < nslab; ++c) slab_body(c, std::false_type{});
     slab_body(nslab - 1, std::true_type{});
