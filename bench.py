@@ -397,7 +397,7 @@ def main():
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": "%s [%s], 160x384 RGB + 7x192x192 bird-view uint8 NHWC frames as the dataset stores them (%s), global batch %d "
                                       "(%d/GPU), %s, local BatchNorm, %sAdam lr 1e-4" % (wl["what"], args.workload, feed, global_batch, per_gpu, DTYPE_TEXT[dtype],
-                                         "" if world == 1 else ("%s gradient buckets over RCCL, " % ("bf16" if (args.grad_allreduce == "bf16" or (args.grad_allreduce == "auto" and dtype == "bf16")) else "f32"))),
+                                         "" if world == 1 else ("%s gradient buckets over %s, " % ("bf16" if (args.grad_allreduce == "bf16" or (args.grad_allreduce == "auto" and dtype == "bf16")) else "f32", "RCCL" if args.dist_backend == "nccl" else args.dist_backend))),
                           "global_batch": global_batch, "parallelism": "dp%d" % world,
                           "waypoint_tolerance_vs_f32": WAYPOINT_TOLERANCE[{"f32": "fp32"}.get(dtype, dtype)]},
                "loss": loss_mean, "loss_finite": bool(loss_mean == loss_mean and abs(loss_mean) != float("inf")),
