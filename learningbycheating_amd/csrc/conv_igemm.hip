@@ -507,8 +507,8 @@ bool lbc_igemm_fuses_bn_bwd(const IgemmArgs& a, int wmajor, int mode, int cfg)
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode)
 {
     if (lbc_opt(kOptForceCfg) < 0) {     // a forced tile policy pins conv_igemm.hip
-        // 3x3 stride-1 launches of the wide layers: the halo-staged LDS-DMA kernel first
-        if (!lbc_conv3x3_halo_eligible(a, mode)) {
+        // 3x3 stride-1 launches: the halo-staged LDS-DMA kernels first (the 64-channel layer has its own persistent variant)
+        {
             const int h = lbc_conv_hdma_pick(a, mode);
             if (h >= 0) return h;
         }

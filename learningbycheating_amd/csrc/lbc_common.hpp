@@ -54,6 +54,7 @@ enum LbcOpt {
     kOptNoBnBwdFuse,       // LBC_NO_BN_BWD_FUSE: 1 = BatchNorm-backward reduce always as its own pass (A/B, tests)
     kOptNoHdma,            // LBC_NO_HDMA: 1 = never use the halo-staged LDS-DMA convolution (conv_hdma.hip)
     kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256)
+    kOptNoHdma64,          // LBC_NO_HDMA64: 1 = the 64-channel layer keeps conv_halo.hip
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
@@ -147,8 +148,8 @@ int lbc_igemm_pick(long long M, int K);            // tile configuration 0..2 of
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
 constexpr int kLbcGldsCfgs = 5;
-constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256}
-constexpr int kLbcHdmaCfgs = 3;
+constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 persistent (C = K = 64)}
+constexpr int kLbcHdmaCfgs = 4;
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);

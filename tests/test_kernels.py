@@ -375,11 +375,13 @@ def test_conv_wgrad_tap_fused(env, cfg):
 
 
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
-HDMA_BM = {0: 256, 1: 256, 2: 128}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256
+HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64)
 HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
-              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2)]
+              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2),
+              (2, 9, 17, 64, 64, 3), (5, 12, 40, 64, 64, 3), (1, 7, 96, 64, 64, 3)]       # the last three: several tiles per persistent workgroup needs LBC_HALO_BLOCKS-like forcing on the GPU only
 HDMA_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, -1), (64, 10, 24, 256, 256, -1), (256, 5, 12, 512, 512, -1),
-                                                   (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 0)]]
+                                                   (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 0),
+                                                   (32, 40, 96, 64, 64, -1), (40, 48, 48, 64, 64, -1)]]
 
 
 @pytest.mark.parametrize("case", HDMA_SMALL + HDMA_REAL)
@@ -393,6 +395,8 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     if cfgid >= 0:
         lbc_config("LBC_GEMM256_MIN_TILES", 1)
         lbc_config("LBC_HDMA_CFG", cfgid)
+    if cfgid == 3:
+        lbc_config("LBC_HALO_BLOCKS", 2)       # two persistent workgroups: several tiles each (the halo double buffer)
     x, w = make((N, H, W, C, K, 3, 1, 1), 290 + C + K)
     x = rbf(x)
     ref = F.conv2d(x, rbf(w), None, 1, 1)
@@ -413,7 +417,7 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     yy = F.conv2d(xg, rbf(w), None, 1, 1)
     dy = rbf(torch.randn(yy.shape, generator=g))
     yy.backward(dy)
-    if K % 64 == 0 and C % 128 == 0:        # the input gradient's output channels are C: needs a column tile of 128 / 256
+    if K % 64 == 0 and (C % 128 == 0 or C == K == 64):        # the input gradient's output channels are C: needs a column tile of 128 / 256 (or the 64-channel kernel)
         rr = rbf(torch.randn(x.shape, generator=g))
         dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
         assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
