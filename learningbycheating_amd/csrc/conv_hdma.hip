@@ -466,7 +466,9 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     if (a.KH != 3 || a.KW != 3 || a.P != 1 || a.S != 1 || a.C % 64 || (mode != 0 && mode != 1)) return -1;
     if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || (long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return -1;
     if ((long long)a.K * 9 * a.C >= (1ll << 31)) return -1;
-    const long long fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 192;
+    // one workgroup per CU; worth it from about 96 tiles (measured at 120 tiles = layer 2 at batch 32: 0.020 ms against 0.027 ms for
+    // the 64 x 64 register-staged tiles; at 60 tiles = layer 3 at batch 32 it loses, 0.029 vs 0.027)
+    const long long fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 96;
     const long long forced = lbc_opt(kOptHdmaCfg);          // tests / tuning: pin one shape
     if (a.C == 64 && a.K == 64) {                           // the 64-channel layer: persistent tiles of 256 pixels
         // measured at batch 256: 0.224 ms against 0.127 ms of conv_halo.hip -- next to 144 registers of stationary weights the
