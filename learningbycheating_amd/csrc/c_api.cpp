@@ -74,11 +74,11 @@ static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const void* w
     LBC_REQUIRE(d->H % 2 == 0 && d->W % 2 == 0, "dgrad s2: odd spatial size %dx%d", d->H, d->W);
     a.LH = d->H / 2; a.LW = d->W / 2; a.ostep = 2;
     a.M = d->N * a.LH * a.LW;
-    const int cfg = lbc_igemm_pick(a.M, a.K);
+    a.nphase = 4;        // one launch for the four output-parity phases (statistics rows ph * per + tile)
+    const int cfg = wmajor ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K);
     const int per = lbc_igemm_rows(a, cfg);
     if (stats_rows) *stats_rows = 4 * per;
     if (!dx) return LBC_OK;
-    a.nphase = 4;        // one launch for the four output-parity phases (statistics rows ph * per + tile)
     return lbc_igemm_launch(a, wmajor, 1, cfg, s);
 }
 

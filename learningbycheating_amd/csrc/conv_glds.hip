@@ -280,7 +280,10 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
 //     fragments in registers;
 //   * the output tile goes through LDS: bf16 rows, then 16-byte coalesced stores (was 128 two-byte stores per lane).
 #define LBC_SG(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
-template <int BM, int BN, int WM, int WN, int MODE, int KT, int DIAG = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
+// PH = 1 (MODE 1 only): the four output-parity phases of a stride-2 transposed launch in one grid (input gradient of the stride-2
+// 3x3 convolutions, ConvTranspose2d forward): workgroups [ph * n, (ph + 1) * n) serve phase ph = 2 oy0 + ox0, whose output pixels
+// (2 ly + oy0, 2 lx + ox0) gather x at (ly + dy, lx + dx) through the 1 / 2 / 2 / 4 taps with (oy0 + 1 - r, ox0 + 1 - s) even.
+template <int BM, int BN, int WM, int WN, int MODE, int KT, int DIAG = 0, int PH = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
 __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
@@ -315,9 +318,16 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
     const int W = a.W, H = a.H, C = a.C, T = a.KH * a.KW, KW = a.KW, PAD = a.P;
 
     const int ntn = a.K / BN;
-    int tile_id;
+    int tile_id, oy0 = 0, ox0 = 0, stat_tile0 = 0;
     {
-        const int nwg = gridDim.x, b = blockIdx.x;
+        int nwg = gridDim.x, b = blockIdx.x;
+        if (PH) {
+            nwg = gridDim.x >> 2;
+            const int ph = blockIdx.x / nwg;
+            b = blockIdx.x - ph * nwg;
+            oy0 = ph >> 1; ox0 = ph & 1;
+            stat_tile0 = ph * (nwg / ntn);                   // statistics rows: phase-major
+        }
         const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
         tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
     }
@@ -332,6 +342,21 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
     // 16-byte slot XOR of a row: rows 4 (64-byte rows) / 2 (128-byte rows) apart differ, so that every ds_read_b128 lane group
     // (16 consecutive rows, one segment) hits 16 distinct slots
     auto rowswz = [](int row) { return KT == 32 ? (row >> 2) & 3 : (row >> 1) & 7; };
+    // PH: the phase's taps: element shift of the gathered pixel and weight offset per tap (wave-uniform)
+    int ph_ntap = 0, ph_shift[4] = {0, 0, 0, 0}, ph_koff[4] = {0, 0, 0, 0}, ph_dy[4] = {0, 0, 0, 0}, ph_dx[4] = {0, 0, 0, 0};
+    if (PH) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, sx = t - 3 * r;
+            if ((((oy0 + 1 - r) & 1) == 0) && (((ox0 + 1 - sx) & 1) == 0)) {
+                const int dy = (oy0 + 1 - r) >> 1, dx = (ox0 + 1 - sx) >> 1;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q == ph_ntap) { ph_shift[q] = (dy * W + dx) * C; ph_koff[q] = t * C; ph_dy[q] = dy; ph_dx[q] = dx; }
+                ++ph_ntap;
+            }
+        }
+    }
     // ---- DMA roles: piece (wave * NA + j) of the A tile = PROWS rows, lane -> (row = lane / SEGS, segment = lane % SEGS)
     const int prow = lane / SEGS, pseg = lane % SEGS;
     int aoff[NA], amask[NA];
@@ -343,11 +368,17 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         // output pixel m = (n, oy, ox) reads the gathered tensor around (oy * S, ox * S): S = 2 (forward of the stride-2 convolutions,
         // input gradient of the transposed convolutions) only in the gather mode
         const int mm = m < a.M ? m : 0;
-        const int ox = mm % a.OW;
-        const int oy = (mm / a.OW) % a.OH;
-        const int n = mm / (a.OW * a.OH);
-        const int x = ox * a.S, y = oy * a.S;
-        if (m < a.M) {
+        const int ox = PH ? mm % a.LW : mm % a.OW;              // PH: lattice coordinates (ly, lx)
+        const int oy = PH ? (mm / a.LW) % a.LH : (mm / a.OW) % a.OH;
+        const int n = PH ? mm / (a.LW * a.LH) : mm / (a.OW * a.OH);
+        const int x = PH ? ox : ox * a.S, y = PH ? oy : oy * a.S;
+        if (PH) {
+            if (m < a.M) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (q < ph_ntap && y + ph_dy[q] < H && x + ph_dx[q] < W) bits |= 1 << q;
+            }
+        } else if (m < a.M) {
             for (int t = 0; t < T; ++t) {
                 const int r = t / KW, s = t - r * KW;
                 const int dy = MODE == 0 ? r - PAD : PAD - r;
@@ -374,7 +405,8 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
     const int bBase = TILE_A + (wn * WTN + l31) * ROWB;
 
     const int cpt = C / KT;
-    const int nit = T * cpt;
+    const int ntaps = PH ? ph_ntap : T;
+    const int nit = ntaps * cpt;
 
     f32x16 acc[MT][NT];
 #pragma unroll
@@ -386,8 +418,9 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
 
     // the DMA stream walks K-tiles in order: (KT-channel slab, tap), taps inner (the nine shifted reads of a slab hit in L2)
     int is_ti = 0, is_s = 0, is_buf = 0;
-    int is_shift = (MODE == 0 ? -(PAD * W + PAD) : PAD * W + PAD) * C;     // element offset of tap (0, 0), slab 0
-    int is_koffs = 0;
+    int is_shift = PH ? ph_shift[0] : (MODE == 0 ? -(PAD * W + PAD) : PAD * W + PAD) * C;     // element offset of the first tap, slab 0
+    int is_koffs = PH ? ph_koff[0] : 0;
+    int is_slab = 0;
     auto issue = [&]() {
         char* base = smem + is_buf * BUF;
 #pragma unroll
@@ -400,14 +433,23 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         }
         // next K-tile: tap (r, s) -> (r, s + 1) -> (r + 1, 0) -> next slab, tap (0, 0).  (With KT = 32, walking the two halves of
         // a 128-byte line back to back instead was measured 4-6 % slower at batch 256.)
-        const int step = MODE == 0 ? C : -C;
-        ++is_ti; ++is_s;
-        is_shift += step; is_koffs += C;
-        if (is_s == KW) { is_s = 0; is_shift += step * (W - KW); }
-        if (is_ti == T) {
-            is_ti = 0;
-            is_shift += KT - step * (W * a.KH);
-            is_koffs += KT - T * C;
+        if (PH) {
+            // next tap of the phase's list, then the next slab
+            ++is_ti;
+            if (is_ti == ph_ntap) { is_ti = 0; is_slab += KT; }
+            const int sh = is_ti == 0 ? ph_shift[0] : is_ti == 1 ? ph_shift[1] : is_ti == 2 ? ph_shift[2] : ph_shift[3];
+            const int ko = is_ti == 0 ? ph_koff[0] : is_ti == 1 ? ph_koff[1] : is_ti == 2 ? ph_koff[2] : ph_koff[3];
+            is_shift = sh + is_slab; is_koffs = ko + is_slab;
+        } else {
+            const int step = MODE == 0 ? C : -C;
+            ++is_ti; ++is_s;
+            is_shift += step; is_koffs += C;
+            if (is_s == KW) { is_s = 0; is_shift += step * (W - KW); }
+            if (is_ti == T) {
+                is_ti = 0;
+                is_shift += KT - step * (W * a.KH);
+                is_koffs += KT - T * C;
+            }
         }
         is_buf = (is_buf + 1) & (NBUF - 1);
     };
@@ -503,7 +545,7 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
 #undef LBC_MIX
 
     // ---- epilogue (conv_lds_dma.hpp): affine / bias / residual / ReLU, LDS-staged 16-byte stores, statistics / fused BN-backward reduce
-    lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, mtile);
+    lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, stat_tile0 + mtile, PH ? 2 : 1, oy0, ox0);
 }
 #undef LBC_SG
 
@@ -513,18 +555,32 @@ const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128,
 
 }  // namespace
 
+// the four-phase stride-2 transposed launches (input gradient of the stride-2 3x3 convolutions, ConvTranspose2d forward) that
+// conv_glds2_k<.., PH = 1> serves: all four parity phases in one grid, no residual, no BatchNorm-on-load
+static bool lbc_glds_phased(const IgemmArgs& a, int mode)
+{
+    return mode == 1 && a.nphase == 4 && a.S == 2 && a.ostep == 2 && a.KH == 3 && a.KW == 3 && a.P == 1 && a.H == a.LH && a.W == a.LW &&
+           a.OH == 2 * a.LH && a.OW == 2 * a.LW && a.M == a.N * a.LH * a.LW && !a.resid && !a.bnb_y && !lbc_opt_on(kOptGldsV1) &&
+           !lbc_opt_on(kOptNoGldsPhased);
+}
+
 // Tile configuration for a launch, or -1 when the launch keeps conv_igemm.hip / conv_halo.hip.
 int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
 {
     if (lbc_opt_on(kOptNoGemm256)) return -1;
-    if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
-    if (a.KH != a.KW || (a.KH != 3 && a.KH != 1) || a.P != (a.KH - 1) / 2 || a.C % 64 || (mode != 0 && mode != 1)) return -1;
-    if (a.M != a.N * a.OH * a.OW || (long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return -1;
-    if (a.S == 1) { if (a.H != a.OH || a.W != a.OW) return -1; }
-    else {
-        // stride 2: gather mode of the second-generation kernel only (forward of the stride-2 convolutions and downsamples,
-        // input gradient of the transposed convolutions)
-        if (a.S != 2 || mode != 0 || lbc_opt_on(kOptGldsV1) || a.OH != (a.H + 2 * a.P - a.KH) / 2 + 1 || a.OW != (a.W + 2 * a.P - a.KW) / 2 + 1) return -1;
+    if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || (mode != 0 && mode != 1)) return -1;
+    if ((long long)a.N * a.H * a.W * a.C >= (1ll << 31) || a.C % 64) return -1;
+    const bool phased = lbc_glds_phased(a, mode);
+    if (!phased) {
+        if (a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
+        if (a.KH != a.KW || (a.KH != 3 && a.KH != 1) || a.P != (a.KH - 1) / 2) return -1;
+        if (a.M != a.N * a.OH * a.OW) return -1;
+        if (a.S == 1) { if (a.H != a.OH || a.W != a.OW) return -1; }
+        else {
+            // stride 2: gather mode of the second-generation kernel only (forward of the stride-2 convolutions and downsamples,
+            // input gradient of the transposed convolutions)
+            if (a.S != 2 || mode != 0 || lbc_opt_on(kOptGldsV1) || a.OH != (a.H + 2 * a.P - a.KH) / 2 + 1 || a.OW != (a.W + 2 * a.P - a.KW) / 2 + 1) return -1;
+        }
     }
     // One workgroup per CU: a tile shape qualifies when it fills at least three quarters of the 256 CUs; among the shapes
     // that do, the one with the best (round quantisation x per-shape efficiency) wins.
@@ -536,8 +592,10 @@ int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
         const GldsCfg& c = kGldsCfg[i];
         if (a.K % c.bn) continue;
         if (forced >= 0 && forced != i) continue;
-        if (c.bn == 64 && (a.K != 64 || lbc_opt_on(kOptGldsV1) || forced != i)) continue;   // 64-channel layers: measured, not (yet) the default
-        const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn);
+        // 64 output channels: the stride-1 3x3 layer is better off in conv_halo.hip (0.187 vs 0.126 ms), so this shape is chosen only when
+        // pinned -- or for the phased stride-2 transposed launches (layer 2's first input gradient: 0.173 -> 0.135 ms)
+        if (c.bn == 64 && (a.K != 64 || lbc_opt_on(kOptGldsV1) || (forced != i && !phased))) continue;
+        const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn) * (phased ? 4 : 1);
         if (tiles < fill) continue;
         const double score = c.eff * (double)tiles / (double)(((tiles + 255) / 256) * 256);
         if (score > best_score) { best_score = score; best = i; }
@@ -556,7 +614,8 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const void* zero = nullptr;
     int rc = lbc_zero_page(&zero);
     if (rc) return rc;
-    const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
+    const bool phased = lbc_glds_phased(a, mode);
+    const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn) * (phased ? 4 : 1)));
     // LBC_GLDS_DIAG (timing experiments only, results are wrong): 1 = no DMA stream in the main loop, 2 = every DMA piece from the
     // zero page, 3 = the activation pieces from the zero page
     const int diag = lbc_opt(kOptGldsDiag) > 0 ? (int)lbc_opt(kOptGldsDiag) : 0;
@@ -583,6 +642,16 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
             else if (dg == 2) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 2>), grid, dim3(512), 0, s, a, zero);
             else if (dg == 3) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 3>), grid, dim3(512), 0, s, a, zero);
             else              hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 4>), grid, dim3(512), 0, s, a, zero);
+            return lbc_check_launch("conv_glds2");
+        }
+        if (phased) {
+#define LBC_GLP(BMv, BNv, WMv, WNv) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1>), grid, dim3(512), 0, s, a, zero)
+            if (cfg == kLbcCfgGlds + 0) LBC_GLP(256, 256, 2, 4);
+            else if (cfg == kLbcCfgGlds + 1) LBC_GLP(256, 128, 4, 2);
+            else if (cfg == kLbcCfgGlds + 2) LBC_GLP(128, 256, 2, 4);
+            else if (cfg == kLbcCfgGlds + 3) LBC_GLP(512, 128, 4, 2);
+            else LBC_GLP(512, 64, 8, 1);
+#undef LBC_GLP
             return lbc_check_launch("conv_glds2");
         }
         if (cfg == kLbcCfgGlds + 0) LBC_GL2(256, 256, 2, 4);

@@ -26,7 +26,10 @@ template <int BM, int BN, int WM> constexpr int lds_dma_epilogue_bytes() { retur
 // Epilogue of a 512-thread workgroup whose 8 waves (WM x WN) hold a BM x BN output tile in 32 x 32 MFMA accumulators.
 // Every wave must have left its main loop reads before this is entered (it starts with a barrier); smem is reused from byte 0.
 template <int BM, int BN, int WM, int WN, int MT, int NT>
-__device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&acc)[MT][NT], char* smem, const int m0, const int n0, const int mtile)
+// ostep = 2 (phased stride-2 transposed launches): row m is lattice point (n, ly, lx) of a.LH x a.LW and lands on output pixel
+// (2 ly + oy0, 2 lx + ox0); such launches carry neither a residual nor the fused BatchNorm-backward reduce.
+__device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&acc)[MT][NT], char* smem, const int m0, const int n0, const int mtile,
+                                                 const int ostep = 1, const int oy0 = 0, const int ox0 = 0)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;
     constexpr int OROW = BN * 2 + 16;                           // staged output row: BN bf16 + 16 bytes (rows 4 apart on distinct banks)
@@ -96,9 +99,16 @@ __device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&ac
         for (int idx = tid; idx < BM * SEG; idx += 512) {
             const int row = idx / SEG, sg = idx - row * SEG;
             const int m = m0 + row;
-            if (m < a.M)
-                *reinterpret_cast<bf16x8*>(yout + (size_t)m * (size_t)a.K + (size_t)(n0 + sg * 8)) =
+            if (m < a.M) {
+                size_t pix = (size_t)m;
+                if (ostep == 2) {
+                    const int lx = m % a.LW, t2 = m / a.LW;
+                    const int ly = t2 % a.LH, n = t2 / a.LH;
+                    pix = ((size_t)n * a.OH + (size_t)(2 * ly + oy0)) * a.OW + (size_t)(2 * lx + ox0);
+                }
+                *reinterpret_cast<bf16x8*>(yout + pix * (size_t)a.K + (size_t)(n0 + sg * 8)) =
                     *reinterpret_cast<const bf16x8*>(smem + row * OROW + sg * 16);
+            }
         }
         if (a.stats && tid < BN) {
             float t1 = 0.f, t2 = 0.f;

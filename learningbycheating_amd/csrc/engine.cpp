@@ -447,9 +447,24 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             LBC_TRY(lbc_weight_transpose(P(D.w), W(wt_), D.Cin, 9, D.Cout, s));
             a.w = W(wt_); a.bf16 = 1; wmajor = 1;
         }
-        const int cfg = lbc_igemm_pick(a.M, a.K);
-        const int per = lbc_igemm_rows(a, cfg);
         a.nphase = 4;                       // the four output-parity phases in one launch; statistics rows ph * per + tile
+        int cfg = lbc_igemm_pick(a.M, a.K);
+        if (act_bf16_) {
+            // the LDS-DMA kernel cannot apply the BatchNorm on load: where it would take the launch otherwise, one bn_apply pass
+            // over the (small) decoder input -- into a gradient ping-pong buffer, idle during the forward -- buys it
+            IgemmArgs b = a;
+            b.pre_scale = nullptr; b.pre_shift = nullptr; b.x = W(gF_);
+            const int c2 = lbc_igemm_pick_for(b, 1);
+            if (c2 >= kLbcCfgGlds && D.Cout >= 128) {      // (64 output channels: the gain does not pay for the pass)
+                BnApplyArgs ap;
+                memset(&ap, 0, sizeof(ap));
+                ap.x = din; ap.y = W(gF_); ap.pixels = (long long)N * D.H * D.W; ap.C = D.Cin;
+                ap.scale = W(D.bn.scale); ap.shift = W(D.bn.shift); ap.relu = 0; ap.act_bf16 = 1;
+                LBC_TRY(lbc_bn_apply(ap, s));
+                a = b; cfg = c2;
+            }
+        }
+        const int per = lbc_igemm_rows(a, cfg);
         LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
         const long long opix = (long long)N * 4 * D.H * D.W;
         if (!tr) {
@@ -578,8 +593,8 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     }
     a.LH = c.H / 2; a.LW = c.W / 2; a.ostep = 2;
     a.M = N * a.LH * a.LW;
-    const int cfg = lbc_igemm_pick(a.M, a.K);
     a.nphase = c.k == 1 ? 1 : 4;            // 1x1: only the even-even phase; 3x3: all four parity phases in one launch
+    const int cfg = (wmajor && act_bf16_) ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K);
     return lbc_igemm_launch(a, wmajor, 1, cfg, s);
 }
 

@@ -55,6 +55,7 @@ enum LbcOpt {
     kOptNoHdma,            // LBC_NO_HDMA: 1 = never use the halo-staged LDS-DMA convolution (conv_hdma.hip)
     kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256)
     kOptNoHdma64,          // LBC_NO_HDMA64: 1 = the 64-channel layer keeps conv_halo.hip
+    kOptNoGldsPhased,      // LBC_NO_GLDS_PHASED: 1 = the stride-2 transposed launches keep conv_igemm.hip
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

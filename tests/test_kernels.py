@@ -374,6 +374,30 @@ def test_conv_wgrad_tap_fused(env, cfg):
     assert relerr(dw2, w2.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
 
 
+@pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 1), (1, 12, 14, 128, 256, 2), (3, 8, 10, 64, 256, 0), (2, 6, 34, 128, 128, 3), (1, 4, 6, 192, 128, 1)] +
+                         [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128, -1), (64, 20, 48, 128, 256, -1), (256, 10, 24, 256, 512, -1)]])
+def test_conv_glds_stride2_transposed_phases(env, case, lbc_config):
+    """input gradient of a stride-2 3x3 convolution on the LDS-DMA kernel: the four output-parity phases in one grid (1 / 2 / 2 / 4
+    taps), lattice rows past the border, several images per tile; compared with autograd on the bf16-rounded operands and with the
+    register-staged kernel on the same launch"""
+    dev, _ = env
+    N, H, W, C, K, cfgid = case            # conv C -> K over H x W (even), stride 2: dy is [N, K, H/2, W/2], dx has C channels
+    if cfgid >= 0:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+        lbc_config("LBC_GEMM256_CFG", cfgid)
+    x, w = make((N, H, W, C, K, 3, 2, 1), 390 + C + K)
+    xg = rbf(x).requires_grad_(True)
+    yy = F.conv2d(xg, rbf(w), None, 2, 1)
+    g = torch.Generator().manual_seed(391)
+    dy = rbf(torch.randn(yy.shape, generator=g))
+    yy.backward(dy)
+    dx = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
+    assert relerr(dx, xg.grad) < 1e-4 + OUT_TOL[2]
+    lbc_config("LBC_NO_GLDS_PHASED", 1)
+    dx2 = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
+    assert relerr(dx, dx2) < 2.0 ** -7
+
+
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
 HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64)
 HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
