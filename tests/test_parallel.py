@@ -19,6 +19,37 @@ def _free_port():
     return p
 
 
+def _run_world(target, world, extra=(), results=None, timeout=300):
+    """spawn `world` ranks of `target(rank, world, port, queue, *extra)` and collect `results` queue items (default: one per rank).
+    A rendezvous on a port another process grabbed between _free_port() and init_process_group (or a transient connection
+    reset) is not a property of the code under test: the world is re-created on a fresh port, up to three times."""
+    import queue as queue_mod
+    results = world if results is None else results
+    last = None
+    for attempt in range(3):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port, q) + tuple(extra)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = []
+        try:
+            for _ in range(results):
+                out.append(q.get(timeout=timeout))
+        except queue_mod.Empty as e:
+            last = e
+        for p in procs:
+            p.join(120 if not last else 5)
+            if p.is_alive():
+                p.kill()
+        if last is None and all(p.exitcode == 0 for p in procs):
+            return out
+        last = last or RuntimeError("rank exit codes %s" % [p.exitcode for p in procs])
+        last_err, last = last, None
+    raise last_err
+
+
 def _offsets_for_image_model():
     from learningbycheating_amd.bird_view.models import ImagePolicyModelSS
     net = ImagePolicyModelSS("resnet34")
@@ -73,16 +104,7 @@ def _reduce_worker(rank, world, port, q, grad_dtype=None):
 
 
 def test_staged_allreduce_gloo_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = sorted(_run_world(_reduce_worker, 2), key=lambda t: t[0])
     want = res[0][1] + res[1][1]
     assert torch.allclose(res[0][2], want) and torch.allclose(res[1][2], want)
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])      # broadcast_module
@@ -91,16 +113,7 @@ def test_staged_allreduce_gloo_world2():
 def test_staged_allreduce_bf16_buckets_gloo_world2():
     """compressed buckets: every rank ends with the same values, equal to the sum of the bf16-rounded shards up to one bf16
     rounding of the result"""
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_reduce_worker, args=(r, 2, port, q, torch.bfloat16)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=300) for _ in range(2)], key=lambda t: t[0])
-    for p in procs:
-        p.join(60)
-        assert p.exitcode == 0
+    res = sorted(_run_world(_reduce_worker, 2, extra=(torch.bfloat16,)), key=lambda t: t[0])
     want = res[0][1].bfloat16().float() + res[1][1].bfloat16().float()
     assert torch.equal(res[0][2], res[1][2])
     assert ((res[0][2] - want).abs() <= want.abs() * 2.0 ** -7 + 1e-6).all()
@@ -139,16 +152,7 @@ def test_staged_allreduce_rccl_world2():
     broadcast_module leaves rank 0's weights everywhere.  Skipped on a one-GPU box."""
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_rccl_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=600) for _ in range(2)], key=lambda t: t[0])
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    res = sorted(_run_world(_rccl_worker, 2, timeout=600), key=lambda t: t[0])
     shards = [torch.randn(_offsets_for_image_model()[1], generator=torch.Generator().manual_seed(300 + r))[::50021] for r in range(2)]
     want = shards[0] + shards[1]
     assert torch.allclose(res[0][1], want, rtol=0, atol=1e-6) and torch.equal(res[0][1], res[1][1])
@@ -208,16 +212,7 @@ def _dp_worker(rank, world, port, q):
 
 
 def test_data_parallel_gradients_emulated_gloo_world2():
-    ctx = mp.get_context("spawn")
-    q = ctx.Queue()
-    port = _free_port()
-    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    err, scale = q.get(timeout=600)
-    for p in procs:
-        p.join(120)
-        assert p.exitcode == 0
+    (err, scale), = _run_world(_dp_worker, 2, results=1, timeout=600)
     assert err <= 1e-6 * scale + 1e-12, (err, scale)
 
 
