@@ -240,6 +240,15 @@ def test_staged_allreduce_on_rccl_single_rank():
             red.wait()
         torch.cuda.synchronize()
         assert torch.equal(flat, ref)
+        # compressed buckets on RCCL: cast -> bf16 all-reduce -> cast back, in stream order on the communication stream
+        redb = StageAllReducer(flat, offs, force=True, grad_dtype=torch.bfloat16)
+        assert redb.staging is not None and redb.staging.dtype == torch.bfloat16
+        for st in range(6):
+            flat[redb.ranges[st][0]:redb.ranges[st][1]].mul_(1.0)
+            redb.launch(st)
+        redb.wait()
+        torch.cuda.synchronize()
+        assert torch.equal(flat, ref.bfloat16().float())
         broadcast_module(torch.nn.Linear(4, 4).to(dev))
     finally:
         dist.destroy_process_group()
