@@ -24,7 +24,12 @@ namespace {
 
 #define LBC_SG(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 
-template <int BM, int BN, int WM, int WN, int HRMAX, int NBUFB, int MODE>
+// PRE = 1 (forward only): BatchNorm(+ReLU) of the producer applied to the input (IgemmArgs::pre_*), as an IN-PLACE transform of the
+// staged halo -- once per element and slab instead of once per tap: every thread rewrites its 16-byte slots of slab c + 1 during
+// taps 6-7 of slab c (its channel segment is the same for all of its rows, so the 8 + 8 coefficients sit in registers; they are
+// fetched one tap earlier -- extra VMEM loads in the wave's queue can only make the counted DMA waits stricter, never laxer).
+// Rows from the zero page are rewritten too; they are met only by taps that the border select sends to the zero row, which is excluded.
+template <int BM, int BN, int WM, int WN, int HRMAX, int NBUFB, int MODE, int PRE = 0>
 __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
@@ -45,6 +50,8 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
     constexpr int NBW = BN / 64;                                // 1-KiB weight pieces per wave per K-tile
     constexpr int ATAPS = 9 - NBUFB;                            // taps of a slab whose issue slot may carry halo pieces (see above)
     constexpr int AP = (HPW + ATAPS - 1) / ATAPS;               // halo pieces per such tap
+    static_assert(!PRE || MODE == 0, "conv_hdma: the input transform belongs to the forward");
+    static_assert(!PRE || (HPW + AP - 1) / AP <= 8 - NBUFB, "conv_hdma: the next halo must have landed by the barrier of tap 6");
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -169,7 +176,28 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);                 \
     } while (0)
 
+    // ---- PRE: in-place BatchNorm(+ReLU) of halo buffer slab & 1 (rows [0, BM + 2W + 2): the zero row and the padding rows stay)
+    const int tseg = (tid & 7) ^ (((tid >> 3) >> 1) & 7);       // this thread's channel segment: rows tid / 8 + 64 i share (row >> 1) & 7
+    f32x8 psc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, psh = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const float relu_floor = (PRE && a.pre_relu) ? 0.f : -INFINITY;
+    auto pre_coef = [&](const int slab) {
+        psc = ParamVec<8>::ld(a.pre_scale + slab * 64 + tseg * 8);
+        psh = ParamVec<8>::ld(a.pre_shift + slab * 64 + tseg * 8);
+    };
+    auto pre_apply = [&](const int slab) {
+        char* base = smem + (slab & 1) * ABYTES + (tid & 7) * 16;
+        const int hr_end = BM + 2 * W + 2;
+        for (int row = tid >> 3; row < hr_end; row += 64) {
+            bf16x8* p = reinterpret_cast<bf16x8*>(base + row * 128);
+            f32x8 v = __builtin_convertvector(*p, f32x8);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e] * psc[e] + psh[e], relu_floor);        // as conv_igemm.hip's on-load path
+            *p = __builtin_convertvector(v, bf16x8);
+        }
+    };
+
     // ---- prologue: the halo of slab 0 and up to NBUFB weight tiles in flight; everything of K-tile 0 landed and visible
+    if (PRE) pre_coef(0);
     issue_a(0, 0, HPW);
     const int nk = 9 * nslab;
 #pragma unroll
@@ -177,6 +205,11 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
         if (k < nk) issue_b(0, k, k);        // (nk >= 9 > NBUFB: the first NBUFB K-tiles are taps of slab 0)
     LBC_WAIT_VM((NBUFB - 1) * NBW);
     __builtin_amdgcn_s_barrier();
+    if (PRE) {
+        pre_apply(0);
+        LBC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+    }
     tap_addr(0, 0, abase, axor);
     LBC_RD(0, 0, 0);
 
@@ -216,8 +249,11 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
             LBC_WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
+            if (PRE && !LAST && t == 5) pre_coef(c + 1);                   // (before this tap's DMA issue: older in the queue)
             if (has_next) LBC_RD(nslot, 0, 0);
             LBC_MM((KS - 1) & 1);
+            if (PRE && !LAST && t == 6) pre_apply(c + 1);                  // landed and visible since the barrier above; the barriers of
+                                                                           // taps 7 and 8 (after lgkmcnt(0)) publish the rewrite
             if (!LAST || t + NBUFB < 9) {
                 const int kn = t + NBUFB;                                  // K-tile k + NBUFB -> the ring slot of K-tile k
                 issue_b(kn < 9 ? c : c + 1, kn < 9 ? kn : kn - 9, slot);
@@ -462,7 +498,9 @@ const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{256, 256, 320}, {256, 128, 384}, {128, 
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
 {
     if (lbc_opt_on(kOptNoHdma) || lbc_opt_on(kOptNoGemm256) || lbc_opt_on(kOptGldsV1)) return -1;
-    if (!(a.w_bf16 && a.act_bf16) || a.pre_scale || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
+    if (!(a.w_bf16 && a.act_bf16) || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
+    // BatchNorm-on-load as an in-LDS transform of the halo: forward only, behind LBC_HDMA_PROLOGUE=1 until it is measured
+    if (a.pre_scale && (mode != 0 || !lbc_opt_on(kOptHdmaPrologue) || (a.C == 64 && a.K == 64))) return -1;
     if (a.KH != 3 || a.KW != 3 || a.P != 1 || a.S != 1 || a.C % 64 || (mode != 0 && mode != 1)) return -1;
     if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || (long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return -1;
     if ((long long)a.K * 9 * a.C >= (1ll << 31)) return -1;
@@ -515,7 +553,8 @@ int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
 #define LBC_HD(BMv, BNv, WMv, WNv, HRv, NBv)                                                                                 \
     do {                                                                                                                     \
-        if (mode == 0) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0>), grid, dim3(512), 0, s, a, zero);   \
+        if (mode == 0 && a.pre_scale) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0, 1>), grid, dim3(512), 0, s, a, zero); \
+        else if (mode == 0) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0>), grid, dim3(512), 0, s, a, zero);   \
         else           hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 1>), grid, dim3(512), 0, s, a, zero);   \
     } while (0)
     if (cfg == kLbcCfgHdma + 0) LBC_HD(256, 256, 2, 4, 320, 2);

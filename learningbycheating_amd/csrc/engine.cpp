@@ -115,7 +115,8 @@ Net::Net(const lbc_net_desc& d) : d_(d)
             // z1 = relu(bn1(y1)): applied on load by its three consumers (never written), unless conv2 would then lose the LDS-DMA
             // kernel (conv_glds.hip cannot transform what it stages): there one bn_apply pass (read + write 2 bytes per element)
             // costs less than the register-staged convolution does (batch 256: layer 2 144 -> 95 + 29 us, layer 3 120 -> 72 + 14 us)
-            b.fuse_z1 = fuse_z1_ < 0 ? !conv_takes_glds(b.c2, (int)NB) : fuse_z1_ == 0;
+            // (with LBC_HDMA_PROLOGUE=1 the halo-staged kernel applies bn1 itself: fused again)
+            b.fuse_z1 = fuse_z1_ < 0 ? (!conv_takes_glds(b.c2, (int)NB) || conv_takes_glds(b.c2, (int)NB, true)) : fuse_z1_ == 0;
             b.z1 = b.fuse_z1 ? 0 : alloc_act(NB * oh * ow * planes);
             b.out = alloc_act(NB * oh * ow * planes);
             blocks_.push_back(b);
@@ -255,7 +256,7 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
 }
 
 // would a training forward of this convolution at batch N take conv_glds.hip when its input needs no transform on load?
-bool Net::conv_takes_glds(const Conv& c, int N) const
+bool Net::conv_takes_glds(const Conv& c, int N, bool with_prologue) const
 {
     if (!act_bf16_) return false;
     IgemmArgs a;
@@ -263,6 +264,7 @@ bool Net::conv_takes_glds(const Conv& c, int N) const
     a.N = N; a.H = c.H; a.W = c.W; a.C = c.Cin; a.OH = c.OH; a.OW = c.OW; a.K = c.Cout;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p; a.M = N * c.OH * c.OW; a.LH = c.OH; a.LW = c.OW; a.ostep = 1;
     a.bf16 = 1; a.act_bf16 = 1; a.w_bf16 = 1;
+    if (with_prologue) { a.pre_scale = reinterpret_cast<const float*>(this); a.pre_shift = a.pre_scale; a.pre_relu = 1; }   // (only tested for null)
     return lbc_igemm_pick_for(a, 0) >= kLbcCfgGlds;        // conv_glds.hip or conv_hdma.hip
 }
 

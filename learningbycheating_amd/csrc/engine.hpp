@@ -102,7 +102,7 @@ private:
     bool act_bf16_ = false;  // precision 2: activations and activation gradients are stored as bf16 in HBM
     int fuse_z1_ = -1;       // LBC_NO_FUSE_Z1: 1 = every block writes z1, 0 = no block does, -1 = per block (Net::Net)
     int weight_prep(hipStream_t s);
-    bool conv_takes_glds(const Conv& c, int N) const;
+    bool conv_takes_glds(const Conv& c, int N, bool with_prologue = false) const;
     int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
     // reduced_rows > 0: dz is already masked and partial_ holds that many rows of (sum g, sum g * xhat) (fused into the producer)
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,

@@ -56,6 +56,7 @@ enum LbcOpt {
     kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256)
     kOptNoHdma64,          // LBC_NO_HDMA64: 1 = the 64-channel layer keeps conv_halo.hip
     kOptNoGldsPhased,      // LBC_NO_GLDS_PHASED: 1 = the stride-2 transposed launches keep conv_igemm.hip
+    kOptHdmaPrologue,      // LBC_HDMA_PROLOGUE: 1 = conv_hdma.hip takes forward launches with BatchNorm-on-load (in-LDS transform of the halo)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

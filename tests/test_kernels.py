@@ -445,6 +445,19 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         rr = rbf(torch.randn(x.shape, generator=g))
         dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
         assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
+    # BatchNorm(+ReLU) of the producer on load: an in-place transform of the staged halo (LBC_HDMA_PROLOGUE=1), against the reference
+    # and against the register-staged kernel (same rounding points: f32 affine of the bf16 input, rounded to bf16 once)
+    if not (C == 64 and K == 64):
+        ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        xin = rbf(F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)))
+        refp = F.conv2d(xin, rbf(w), None, 1, 1)
+        lbc_config("LBC_HDMA_PROLOGUE", 1)
+        yp, stp = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
+        assert relerr(yp, refp) < 5e-4 + OUT_TOL[2]      # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
+        assert torch.allclose(stp[:, 0].sum(0), refp.sum((0, 2, 3)), rtol=2e-3, atol=2e-2)
+        lbc_config("LBC_HDMA_PROLOGUE", 0)
+        yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
+        assert relerr(yp, yq) < 2.0 ** -7
     # A/B: the per-tap LDS-DMA kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_HDMA", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, 1, bf16=3)

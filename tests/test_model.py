@@ -491,7 +491,7 @@ def test_bn_backward_reduce_fused_into_dgrad_epilogue(env, kind, backbone, h, w,
     assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
 
 
-@pytest.mark.parametrize("precision", [1, 2, "2-tiles128", "2-glds"])
+@pytest.mark.parametrize("precision", [1, 2, "2-tiles128", "2-glds", "2-hdma-prologue"])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),
                                                  pytest.param("birdview", "resnet18", 192, 192, 8, marks=gpu)])
 def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, lbc_config):
@@ -505,6 +505,11 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, lbc_conf
         # the tile policy of large batches (128-row tiles: the halo-staged layer-1 kernel, 128 x 64 / 128 x 128 igemm tiles)
         # on a test-sized batch
         lbc_config("LBC_FORCE_CFG", 0)
+        precision = 2
+    if precision == "2-hdma-prologue":
+        # as "2-glds", and the halo-staged kernel applies bn1 on load itself (in-LDS transform): conv2 reads y1 again, no z1 pass
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+        lbc_config("LBC_HDMA_PROLOGUE", 1)
         precision = 2
     if precision == "2-glds":
         # the 8-wave LDS-DMA convolution (conv_glds.hip) for every stride-1 3x3 layer with >= 128 output channels, which
