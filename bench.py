@@ -222,6 +222,9 @@ def main():
                          "BatchNorm / soft-argmax / loss / Adam. bf16_mfma: bf16 MFMA operands only, every tensor f32")
     ap.add_argument("--grad-allreduce", choices=["f32", "bf16", "auto"], default="auto",
                     help="dtype of the gradient buckets on the wire (N > 1): auto = bf16 in the bf16 mode (BASELINE config 3), f32 otherwise")
+    ap.add_argument("--sync-bn", action="store_true",
+                    help="N > 1: BatchNorm over the global batch (lbc_net_set_sync_bn; 2 small all-reduces per BatchNorm per step on a "
+                         "communicator of their own). Default: local statistics per rank, like torch DDP without SyncBatchNorm")
     ap.add_argument("--dist-backend", default="nccl",
                     help="nccl (= RCCL over xGMI, one rank per GPU); gloo lets several ranks share one GPU to exercise the N > 1 code "
                          "path on a single-GPU box -- its numbers mean nothing")
@@ -307,12 +310,13 @@ def main():
         pool.prefetch(0); pool.prefetch(1)
         gdt = torch.bfloat16 if (args.grad_allreduce == "bf16" or (args.grad_allreduce == "auto" and dt_name == "bf16")) else None
         if kind == "birdview":
-            tr = NativeTrainer(teacher, None, per_gpu, (7, 192, 192), device, phase="birdview", lr=1e-4, world_size=world, grad_dtype=gdt)
+            tr = NativeTrainer(teacher, None, per_gpu, (7, 192, 192), device, phase="birdview", lr=1e-4, world_size=world, grad_dtype=gdt, sync_bn=args.sync_bn)
         else:
             warm = NativeTrainer(student, None, per_gpu, (3, 160, 384), device, phase="l1_all", lr=1e-3, world_size=world, grad_dtype=gdt)
             run_steps(warm, args.init_steps, "warm")
             del warm
-            tr = NativeTrainer(student, teacher, per_gpu, (3, 160, 384), device, phase=1, lr=1e-4, world_size=world, grad_dtype=gdt)
+            tr = NativeTrainer(student, teacher, per_gpu, (3, 160, 384), device, phase=1, lr=1e-4, world_size=world, grad_dtype=gdt,
+                               sync_bn=args.sync_bn)
         weights = []
         run_steps(tr, warmup, "train", weights)
         torch.cuda.synchronize()
@@ -396,7 +400,8 @@ def main():
                "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": "%s [%s], 160x384 RGB + 7x192x192 bird-view uint8 NHWC frames as the dataset stores them (%s), global batch %d "
-                                      "(%d/GPU), %s, local BatchNorm, %sAdam lr 1e-4" % (wl["what"], args.workload, feed, global_batch, per_gpu, DTYPE_TEXT[dtype],
+                                      "(%d/GPU), %s, %s BatchNorm, %sAdam lr 1e-4" % (wl["what"], args.workload, feed, global_batch, per_gpu, DTYPE_TEXT[dtype],
+                                         "synchronized (global-batch)" if (args.sync_bn and world > 1) else "local",
                                          "" if world == 1 else ("%s gradient buckets over %s, " % ("bf16" if (args.grad_allreduce == "bf16" or (args.grad_allreduce == "auto" and dtype == "bf16")) else "f32", "RCCL" if args.dist_backend == "nccl" else args.dist_backend))),
                           "global_batch": global_batch, "parallelism": "dp%d" % world,
                           "waypoint_tolerance_vs_f32": WAYPOINT_TOLERANCE[{"f32": "fp32"}.get(dtype, dtype)]},

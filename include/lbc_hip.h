@@ -128,6 +128,30 @@ int lbc_net_num_stages(void);
  * increments -- a caller that holds several forward results (autograd) can detect that the workspace has moved on. */
 int lbc_net_last_forward(const lbc_net* net, int* batch, int* train, long long* generation);
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream);
+/* Synchronized BatchNorm for data-parallel training (not in the reference, which is single-device; the equivalent of wrapping
+ * its modules in torch.nn.SyncBatchNorm): every BatchNorm of a training-mode forward normalises with the statistics of the
+ * GLOBAL batch, and its backward uses the global gradient sums -- a per-GPU batch of 32 then trains like the 256-image batch
+ * of BASELINE.json instead of eight 32-image batches.  Before each finalize the net reduces that layer's per-channel sums to
+ * one row of `count` floats in `buf` and calls fn(ctx, buf, count, stream), which must enqueue an in-place SUM all-reduce
+ * over the data-parallel group on `stream` (ncclAllReduce of RCCL takes exactly these arguments) and return 0, or non-zero
+ * to abort the step (LBC_ELAUNCH).  dgamma / dbeta stay local sums, as every other parameter gradient: the caller's gradient
+ * all-reduce completes them.  buf: device memory, buf_floats >= 1536.  fn == NULL switches back to local statistics.
+ * Eval-mode forwards never call fn. */
+typedef int (*lbc_allreduce_fn)(void* ctx, float* buf, int count, lbc_stream_t stream);
+int lbc_net_set_sync_bn(lbc_net* net, lbc_allreduce_fn fn, void* ctx, int world_size, float* buf, int buf_floats);
+/* The RCCL communicator that callback normally is (csrc/comm.cpp): one per process/GPU, built from an id that rank 0 creates and
+ * the host distributes over whatever channel it has (torch.distributed broadcast, MPI, a file).  lbc_comm_create is collective
+ * over the world and binds the calling thread's current HIP device.  lbc_comm_allreduce_f32 is an lbc_allreduce_fn with
+ * ctx = the lbc_comm: ncclAllReduce(buf, buf, count, ncclFloat32, ncclSum) enqueued on `stream`, nothing else.
+ * RCCL is bound at run time (the librccl.so already in the process, else the system one): without it these return
+ * LBC_EINVAL with the reason in lbc_last_error(), the rest of the library is unaffected. */
+#define LBC_COMM_ID_BYTES 128
+typedef struct lbc_comm lbc_comm;
+int lbc_comm_unique_id(unsigned char* id /* [LBC_COMM_ID_BYTES] */);
+int lbc_comm_create(const unsigned char* id, int rank, int world_size, lbc_comm** out);
+void lbc_comm_destroy(lbc_comm* comm);
+int lbc_comm_world_size(const lbc_comm* comm);
+int lbc_comm_allreduce_f32(void* comm, float* buf, int count, lbc_stream_t stream);
 
 /* Losses (forward value per sample + gradient wrt pred), reference training/train_image_phase1.py:35-70,
  * train_image_phase0.py:36-89, train_birdview.py:33-54.  kind: 0 phase-0, 1 phase-1, 2 bird-view L1 (pixel targets), 3 L1 vs normalised targets.

@@ -66,6 +66,12 @@ _SIGNATURES = {
     "lbc_net_num_stages": (c_int, []),
     "lbc_net_last_forward": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong)]),
     "lbc_net_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lbc_net_set_sync_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
+    "lbc_comm_unique_id": (c_int, [c_void_p]),
+    "lbc_comm_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),
+    "lbc_comm_destroy": (None, [c_void_p]),
+    "lbc_comm_world_size": (c_int, [c_void_p]),
+    "lbc_comm_allreduce_f32": (c_int, [c_void_p, c_void_p, c_int, c_void_p]),
     "lbc_loss": (c_int, [c_int, ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "lbc_phase2_weight": (c_int, [ctypes.POINTER(Camera), c_void_p, c_void_p, c_int, c_void_p, c_void_p]),
     "lbc_adam_step": (c_int, [c_void_p, c_int] + [ctypes.c_double] * 5 + [c_int, c_void_p]),

@@ -18,7 +18,8 @@
 namespace {
 
 // ---- partial-row pre-reduction: in[rows][cols] -> out[R][cols] ---------------
-__global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict__ in, int rows, int cols, float* __restrict__ out)
+__global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict__ in, int rows, int cols, float* __restrict__ out,
+                                                        float* __restrict__ copy_lo, float* __restrict__ copy_hi)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
@@ -33,7 +34,11 @@ __global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict_
         s3 += (double)in[(size_t)(r + 3 * step) * cols + c];
     }
     for (; r < rows; r += step) s0 += (double)in[(size_t)r * cols + c];
-    out[(size_t)blockIdx.y * cols + c] = (float)((s0 + s1) + (s2 + s3));
+    const float v = (float)((s0 + s1) + (s2 + s3));
+    out[(size_t)blockIdx.y * cols + c] = v;
+    // one output row of [2][C] sums: the halves are also the local dbeta / dgamma (SyncBN backward, engine.cpp)
+    if (copy_lo && c < cols / 2) copy_lo[c] = v;
+    if (copy_hi && c >= cols / 2) copy_hi[c - cols / 2] = v;
 }
 
 // Sums column c of a [rows][2][C] partial buffer.  The finalize kernels run 1024 threads = 16 channels x 64 row-lanes: lane q
@@ -339,11 +344,12 @@ int lbc_copy_f32(const float* src, float* dst, long long n, hipStream_t s)
     return lbc_check_launch("copy_f32");
 }
 
-int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s)
+int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s, float* copy_lo, float* copy_hi)
 {
+    LBC_REQUIRE((!copy_lo && !copy_hi) || (out_rows == 1 && cols % 2 == 0), "partial_reduce: the copy outputs need one output row");
     dim3 grid((unsigned)lbc_cdiv(cols, 256), (unsigned)out_rows);
     LbcProfScope prof("partial_reduce", 0.0, 4.0 * (double)rows * cols, s);
-    hipLaunchKernelGGL(partial_reduce_k, grid, dim3(256), 0, s, in, rows, cols, out);
+    hipLaunchKernelGGL(partial_reduce_k, grid, dim3(256), 0, s, in, rows, cols, out, copy_lo, copy_hi);
     return lbc_check_launch("partial_reduce");
 }
 

@@ -315,10 +315,41 @@ int Net::bn_eval_prep(hipStream_t s)
     return lbc_bn_eval_prep(a, s);
 }
 
-int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running)
+int Net::set_sync_bn(lbc_allreduce_fn fn, void* ctx, int world, float* buf, int buf_floats)
+{
+    if (!fn) { sync_fn_ = nullptr; sync_ctx_ = nullptr; sync_world_ = 1; sync_buf_ = nullptr; return LBC_OK; }
+    LBC_REQUIRE(world >= 1 && buf && buf_floats >= kSyncFloats, "net.set_sync_bn: world_size >= 1 and a buffer of >= %d floats",
+                kSyncFloats);
+    sync_fn_ = fn; sync_ctx_ = ctx; sync_world_ = world; sync_buf_ = buf;
+    return LBC_OK;
+}
+
+int Net::sync_rows(const float*& part, int& rows, int width, hipStream_t s, float* local_lo, float* local_hi)
+{
+    if (!sync_fn_) return LBC_OK;
+    LBC_REQUIRE(width <= kSyncFloats, "net: %d sums do not fit the SyncBN buffer", width);
+    if (rows > kLbcFinalizeRows) {      // (one thread per column walking thousands of rows would be the longest kernel of the layer)
+        LBC_TRY(lbc_partial_reduce(part, rows, width, W(partial2_), 64, s));
+        part = W(partial2_); rows = 64;
+    }
+    LBC_TRY(lbc_partial_reduce(part, rows, width, sync_buf_, 1, s, local_lo, local_hi));
+    if (sync_fn_(sync_ctx_, sync_buf_, width, s) != 0) {
+        lbc_set_error("net: the SyncBN all-reduce callback failed");
+        return LBC_ELAUNCH;
+    }
+    part = sync_buf_; rows = 1;
+    return LBC_OK;
+}
+
+int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running, const float* synced)
 {
     const float* part = W(partial_);
-    if (train && rows > kLbcFinalizeRows) {
+    if (train && synced) {
+        part = synced; rows = 1; count *= sync_world_;
+    } else if (train && sync_fn_) {
+        LBC_TRY(sync_rows(part, rows, 2 * bn.C, s));
+        count *= sync_world_;
+    } else if (train && rows > kLbcFinalizeRows) {
         LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * bn.C, W(partial2_), 64, s));
         part = W(partial2_);
         rows = 64;
@@ -475,7 +506,10 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             LBC_TRY(bn_finalize(dec_[i + 1].bn, 4 * per, opix, train, s));
         } else {
             // image.py:54-60: the four branch BatchNorms see the same tensor -> same batch statistics
-            for (int b = 0; b < 4; ++b) LBC_TRY(bn_finalize(head_bn_[b], 4 * per, opix, train, s));
+            const float* part = W(partial_);
+            int prow = 4 * per;
+            LBC_TRY(sync_rows(part, prow, 2 * 64, s));     // SyncBN: one all-reduce serves the four finalizes
+            for (int b = 0; b < 4; ++b) LBC_TRY(bn_finalize(head_bn_[b], 4 * per, opix, train, s, true, sync_fn_ ? part : nullptr));
         }
         din = W(D.u);
     }
@@ -500,6 +534,19 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
 }
 
 // ---------------------------------------------------------------------------------------
+// BatchNorm backward finalize.  SyncBN: dgamma / dbeta stay this rank's sums (the gradient all-reduce completes them like
+// every other parameter gradient) -- they are the one-row reduction itself, written on its way into the exchange buffer;
+// the coefficients k1 = sum(g)/n, k2 = sum(g xhat)/n of the input gradient come from the global sums.
+int Net::bn_bwd_finalize(BnBwdFinalizeArgs f, hipStream_t s)
+{
+    if (sync_fn_) {
+        LBC_TRY(sync_rows(f.partial, f.rows, 2 * f.C, s, f.dbeta, f.dgamma));
+        f.count *= sync_world_;
+        f.dgamma = nullptr; f.dbeta = nullptr;
+    }
+    return lbc_bn_bwd_finalize(f, s);
+}
+
 // BatchNorm backward: reduce (sum g, sum g*xhat) -> dgamma/dbeta + coefficients -> dx
 int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
                      float* dx, int Cout, hipStream_t s, const BN* mask_bn, bool join_before_apply, int reduced_rows)
@@ -528,7 +575,7 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
     f.gamma = P(bn.g); f.mean = W(bn.mean); f.invstd = W(bn.invstd); f.train = 1;
     f.dgamma = G(bn.g); f.dbeta = G(bn.b);
     f.coefA = W(bn.cA); f.coefB = W(bn.cB); f.coefD = W(bn.cD);
-    LBC_TRY(lbc_bn_bwd_finalize(f, s));
+    LBC_TRY(bn_bwd_finalize(f, s));
     BnBwdApplyArgs ap;
     memset(&ap, 0, sizeof(ap));
     ap.g = g_out ? g_out : dz; ap.mask = g_out ? nullptr : mask; ap.x = x;
@@ -710,6 +757,11 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
         }
         hf.mean = W(head_bn_[0].mean); hf.invstd = W(head_bn_[0].invstd); hf.chan_coef = W(head_coef_);
         LBC_TRY(lbc_head_bwd_finalize(hf, s));
+        if (sync_fn_) {      // second pass on the global sums: only the per-channel coefficients of the input gradient
+            LBC_TRY(sync_rows(hf.s_partial, hf.rows, 20 * 65, s));
+            hf.count *= sync_world_; hf.coef_only = 1;
+            LBC_TRY(lbc_head_bwd_finalize(hf, s));
+        }
         LBC_TRY(lbc_head_bwd_apply(hb, s));   // E = dU3
 
         // ---- decoder, last to first ----
@@ -794,7 +846,7 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
         f.gamma = P(stem_bn_.g); f.mean = W(stem_bn_.mean); f.invstd = W(stem_bn_.invstd); f.train = 1;
         f.dgamma = G(stem_bn_.g); f.dbeta = G(stem_bn_.b);
         f.coefA = W(stem_bn_.cA); f.coefB = W(stem_bn_.cB); f.coefD = W(stem_bn_.cD);
-        LBC_TRY(lbc_bn_bwd_finalize(f, s));
+        LBC_TRY(bn_bwd_finalize(f, s));
         StemWgradArgs sw;
         memset(&sw, 0, sizeof(sw));
         if (lbc_stem_wgrad_fuses_bn_bwd(d_.in_channels, bf16_)) {
@@ -888,6 +940,11 @@ int lbc_net_last_forward(const lbc_net* net, int* batch, int* train, long long* 
     if (train) *train = net->impl.last_train();
     if (generation) *generation = net->impl.generation();
     return LBC_OK;
+}
+int lbc_net_set_sync_bn(lbc_net* net, lbc_allreduce_fn fn, void* ctx, int world_size, float* buf, int buf_floats)
+{
+    LBC_REQUIRE(net, "net_set_sync_bn: null net");
+    return net->impl.set_sync_bn(fn, ctx, world_size, buf, buf_floats);
 }
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream)
 {

@@ -79,6 +79,11 @@ public:
     int last_batch() const { return lastN_; }
     int last_train() const { return last_train_; }
     long long generation() const { return generation_; }
+    // Synchronized BatchNorm for data parallelism: every BatchNorm's batch sums (forward) and gradient sums (backward) are
+    // all-reduced through `fn` before they are finalized, so the ranks normalise with the statistics of the global batch.
+    // buf: device scratch of >= kSyncFloats floats the callback reduces in place.  fn == nullptr: local BatchNorm.
+    static const int kSyncFloats = 1536;
+    int set_sync_bn(lbc_allreduce_fn fn, void* ctx, int world, float* buf, int buf_floats);
 
 private:
     int add_tensor(const std::string& name, int kind, std::initializer_list<int> shape);
@@ -103,7 +108,17 @@ private:
     int fuse_z1_ = -1;       // LBC_NO_FUSE_Z1: 1 = every block writes z1, 0 = no block does, -1 = per block (Net::Net)
     int weight_prep(hipStream_t s);
     bool conv_takes_glds(const Conv& c, int N, bool with_prologue = false) const;
-    int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true);
+    // synced: partial_ rows were all-reduced already by sync_rows() (several BatchNorms finalized from the same sums)
+    int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true,
+                    const float* synced = nullptr);
+    // SyncBN: part[rows][width] -> one row summed over every rank (in sync_buf_); no-op (returns part) when not enabled
+    // local_lo / local_hi (nullable): the halves of this rank's own row are also written there, before the exchange
+    int sync_rows(const float*& part, int& rows, int width, hipStream_t s, float* local_lo = nullptr, float* local_hi = nullptr);
+    int bn_bwd_finalize(BnBwdFinalizeArgs f, hipStream_t s);
+    lbc_allreduce_fn sync_fn_ = nullptr;
+    void* sync_ctx_ = nullptr;
+    int sync_world_ = 1;
+    float* sync_buf_ = nullptr;
     // reduced_rows > 0: dz is already masked and partial_ holds that many rows of (sum g, sum g * xhat) (fused into the producer)
     int bn_backward(const BN& bn, const float* dz, const float* mask, float* g_out, const float* x, long long pixels,
                     float* dx, int Cout, hipStream_t s, const BN* mask_bn = nullptr, bool join_before_apply = false, int reduced_rows = 0);

@@ -373,9 +373,9 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_k(HeadBwdFinalizeArgs a
     __syncthreads();
     for (int idx = tid; idx < 20 * 64; idx += 256) {
         const int bs = idx >> 6, c = idx & 63, b = bs / 5;
-        a.dw[b][(bs - b * 5) * 64 + c] = a.gamma[b][c] * sS[bs * 65 + c] + a.beta[b][c] * sS[bs * 65 + 64];
+        if (!a.coef_only) a.dw[b][(bs - b * 5) * 64 + c] = a.gamma[b][c] * sS[bs * 65 + c] + a.beta[b][c] * sS[bs * 65 + 64];
     }
-    if (tid < 20) a.dbias[tid / 5][tid % 5] = sS[tid * 65 + 64];
+    if (tid < 20 && !a.coef_only) a.dbias[tid / 5][tid % 5] = sS[tid * 65 + 64];
     {
         const int b = tid >> 6, c = tid & 63;   // 256 threads = 4 x 64
         float dg = 0.f, db = 0.f;
@@ -384,7 +384,7 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_k(HeadBwdFinalizeArgs a
             dg += w * sS[(b * 5 + s) * 65 + c];
             db += w * sS[(b * 5 + s) * 65 + 64];
         }
-        a.dgamma[b][c] = dg; a.dbeta[b][c] = db;
+        if (!a.coef_only) { a.dgamma[b][c] = dg; a.dbeta[b][c] = db; }
         sDG[tid] = dg; sDB[tid] = db;
     }
     __syncthreads();

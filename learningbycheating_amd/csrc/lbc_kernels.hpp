@@ -35,7 +35,9 @@ struct BnEvalArgs {
     float eps;
 };
 int lbc_bn_eval_prep(const BnEvalArgs& a, hipStream_t s);
-int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s);
+// copy_lo / copy_hi (nullable, out_rows == 1 only): the first / second half of the output row is also written there
+int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s, float* copy_lo = nullptr,
+                       float* copy_hi = nullptr);
 int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 
 struct BnApplyArgs {
@@ -185,6 +187,7 @@ struct HeadBwdFinalizeArgs {
     const float* mean; const float* invstd;              // shared batch statistics [64]
     float* dgamma[4]; float* dbeta[4]; float* dw[4]; float* dbias[4];
     float* chan_coef;            // [2][64]: invstd*k1, invstd*k2
+    int coef_only;               // 1: write chan_coef only (SyncBN: second pass over the all-reduced sums)
 };
 int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s);
 int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s);

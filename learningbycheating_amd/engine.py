@@ -7,6 +7,9 @@ from . import _lib
 
 
 GRAD_ALIGN = 64      # elements (256 bytes)
+SYNC_FLOATS = 1536   # Net::kSyncFloats
+COMM_ID_BYTES = 128  # LBC_COMM_ID_BYTES
+ALLREDUCE_FN = ctypes.CFUNCTYPE(ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p)   # lbc_allreduce_fn
 
 
 def _pad(n):
@@ -52,10 +55,12 @@ class PolicyEngine:
         self.grad_flat = None
         self.grad_views = {}
         self._keep = None
+        self._sync = None
 
     def __del__(self):
         try:
             if self.handle:
+                self._release_sync()
                 _lib.get().lbc_net_destroy(self.handle)
                 self.handle = None
         except Exception:
@@ -145,6 +150,62 @@ class PolicyEngine:
                 raise RuntimeError("engine.backward: %s must be a contiguous float32 %s tensor on %s (the last forward ran %d samples), got %s %s on %s"
                                    % (name, shape, self.workspace.device, self.last_batch, t.dtype, tuple(t.shape), t.device))
         _lib.check(_lib.get().lbc_net_backward(self.handle, _lib.ptr(d_sel), _lib.ptr(d_all), stage, _lib.stream_for(ref)), "net_backward")
+
+    # ---- synchronized BatchNorm (data parallelism) ---------------------------------------
+    def set_sync_bn(self, group=None, enable=True, native=None):
+        """Every training-mode BatchNorm uses the statistics of the global batch (lbc_net_set_sync_bn): before each finalize
+        the native executor has one row of per-channel sums all-reduced over the data-parallel group, in stream order.
+        native (default on a GPU): the library's own RCCL communicator (lbc_comm_*) -- its id is created on group rank 0 and
+        broadcast over `group`; each reduction is one ncclAllReduce enqueued from C.  native=False (default on the CPU
+        emulator / gloo): the executor calls back into torch.distributed on `group`; give that a process group of its own,
+        on the gradient buckets' communicator the small reductions of the next backward stage would queue behind a bucket."""
+        import torch.distributed as dist
+        lib = _lib.get()
+        self._release_sync()
+        if not enable:
+            _lib.check(lib.lbc_net_set_sync_bn(self.handle, None, None, 1, None, 0), "net_set_sync_bn")
+            return
+        world = dist.get_world_size(group)
+        dev = self.workspace.device
+        buf = torch.zeros(SYNC_FLOATS, dtype=torch.float32, device=dev)
+        if native is None:
+            native = dev.type == "cuda"
+        if native:
+            ident = torch.zeros(COMM_ID_BYTES, dtype=torch.uint8)
+            rank = dist.get_rank(group)
+            if rank == 0:
+                _lib.check(lib.lbc_comm_unique_id(_lib.ptr(ident)), "comm_unique_id")
+            wire = ident.to(dev) if dist.get_backend(group) == "nccl" else ident
+            dist.broadcast(wire, dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            ident = wire.cpu()
+            comm = ctypes.c_void_p()
+            with torch.cuda.device(dev):       # ncclCommInitRank binds the current device
+                _lib.check(lib.lbc_comm_create(_lib.ptr(ident), rank, world, ctypes.byref(comm)), "comm_create")
+            fn = ctypes.cast(lib.lbc_comm_allreduce_f32, ctypes.c_void_p)
+            _lib.check(lib.lbc_net_set_sync_bn(self.handle, fn, comm, world, _lib.ptr(buf), SYNC_FLOATS), "net_set_sync_bn")
+            self._sync = {"comm": comm, "buf": buf, "error": None}
+            return
+        state = {"buf": buf, "group": group, "error": None}
+
+        def reduce_row(ctx, ptr, count, stream):
+            try:
+                assert ptr == buf.data_ptr() and 0 < count <= SYNC_FLOATS
+                dist.all_reduce(buf[:count], op=dist.ReduceOp.SUM, group=group)    # on the current stream = the executor's
+                return 0
+            except Exception as e:       # must not propagate through the C frames
+                state["error"] = e
+                return 1
+
+        state["fn"] = ALLREDUCE_FN(reduce_row)       # the C side holds this function pointer and the buffer
+        _lib.check(lib.lbc_net_set_sync_bn(self.handle, ctypes.cast(state["fn"], ctypes.c_void_p), None, world, _lib.ptr(buf), SYNC_FLOATS),
+                   "net_set_sync_bn")
+        self._sync = state
+
+    def _release_sync(self):
+        s, self._sync = self._sync, None
+        if s and s.get("comm"):
+            _lib.check(_lib.get().lbc_net_set_sync_bn(self.handle, None, None, 1, None, 0), "net_set_sync_bn")
+            _lib.get().lbc_comm_destroy(s["comm"])
 
     @staticmethod
     def num_stages():

@@ -26,7 +26,8 @@ class NativeTrainer:
     image space), 'birdview' (privileged agent vs ground-truth waypoints), 'l1_all' (all branches vs
     given normalised targets; used to warm-start synthetic benchmarks below the horizon)."""
 
-    def __init__(self, student, teacher, batch, image_shape, device, phase=1, lr=1e-4, world_size=1, group=None, camera=None, grad_dtype=None):
+    def __init__(self, student, teacher, batch, image_shape, device, phase=1, lr=1e-4, world_size=1, group=None, camera=None, grad_dtype=None,
+                 sync_bn=False):
         self.student, self.teacher, self.phase, self.batch, self.world = student, teacher, phase, batch, world_size
         self.device = device
         student.train()
@@ -38,6 +39,11 @@ class NativeTrainer:
         self.cam = camera or camera_struct()
         self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
         self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group, grad_dtype=grad_dtype)   # grad_dtype: see parallel.py
+        if sync_bn and world_size > 1:
+            # BatchNorm over the global batch (not in the reference: it trains 256 images on one device, which is what this
+            # restores for 8 x 32); its reductions get a communicator of their own (see PolicyEngine.set_sync_bn)
+            import torch.distributed as dist
+            self.eng.set_sync_bn(dist.new_group() if group is None else group)
         self.loss = torch.zeros(batch, dtype=torch.float32, device=device)
         self.dpred_all = torch.zeros((batch, 4, 5, 2), dtype=torch.float32, device=device)
         self.dpred_sel = torch.zeros((batch, 5, 2), dtype=torch.float32, device=device)

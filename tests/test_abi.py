@@ -99,3 +99,29 @@ def test_checkpoint_round_trip_with_reference_classes(tmp_path):
         again.load_state_dict(torch.load(str(path2)))
         for k, v in again.state_dict().items():
             assert torch.equal(v, ref.state_dict()[k]), k
+
+
+def test_comm_entry_points_validate_without_a_gpu():
+    """lbc_comm_* (the RCCL communicator of synchronized BatchNorm): RCCL is bound at run time, so without it the calls fail
+    with a message instead of the library failing to load; argument errors are reported before RCCL is touched"""
+    import ctypes
+    from learningbycheating_amd import _lib
+    lib = _lib.get()
+    ident = torch.zeros(128, dtype=torch.uint8)
+    rc = lib.lbc_comm_unique_id(_lib.ptr(ident))
+    if rc == 0:
+        assert int(ident.count_nonzero()) > 0
+    else:
+        assert b"rccl" in lib.lbc_last_error().lower()
+    comm = ctypes.c_void_p()
+    assert lib.lbc_comm_create(_lib.ptr(ident), 2, 2, ctypes.byref(comm)) != 0 and b"rank 2 outside" in lib.lbc_last_error()
+    assert lib.lbc_comm_create(None, 0, 1, ctypes.byref(comm)) != 0
+    assert lib.lbc_comm_allreduce_f32(None, None, 4, None) != 0
+    assert lib.lbc_comm_world_size(None) == 0
+    lib.lbc_comm_destroy(None)
+    # the executor refuses a hook without its scratch row
+    from learningbycheating_amd.engine import PolicyEngine
+    eng = PolicyEngine(18, 3, 32, 64, True, 1, torch.device("cpu"))
+    fn = ctypes.cast(lib.lbc_comm_allreduce_f32, ctypes.c_void_p)
+    assert lib.lbc_net_set_sync_bn(eng.handle, fn, None, 2, None, 0) != 0 and b"1536" in lib.lbc_last_error()
+    assert lib.lbc_net_set_sync_bn(eng.handle, None, None, 1, None, 0) == 0
