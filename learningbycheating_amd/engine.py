@@ -155,7 +155,7 @@ class PolicyEngine:
     def set_sync_bn(self, group=None, enable=True, native=None):
         """Every training-mode BatchNorm uses the statistics of the global batch (lbc_net_set_sync_bn): before each finalize
         the native executor has one row of per-channel sums all-reduced over the data-parallel group, in stream order.
-        native (default on a GPU): the library's own RCCL communicator (lbc_comm_*) -- its id is created on group rank 0 and
+        native (default on a GPU under the nccl backend): the library's own RCCL communicator (lbc_comm_*) -- its id is created on group rank 0 and
         broadcast over `group`; each reduction is one ncclAllReduce enqueued from C.  native=False (default on the CPU
         emulator / gloo): the executor calls back into torch.distributed on `group`; give that a process group of its own,
         on the gradient buckets' communicator the small reductions of the next backward stage would queue behind a bucket."""
@@ -168,8 +168,8 @@ class PolicyEngine:
         world = dist.get_world_size(group)
         dev = self.workspace.device
         buf = torch.zeros(SYNC_FLOATS, dtype=torch.float32, device=dev)
-        if native is None:
-            native = dev.type == "cuda"
+        if native is None:      # (gloo ranks may share one GPU in self-tests: RCCL refuses two ranks on one device)
+            native = dev.type == "cuda" and dist.get_backend(group) == "nccl"
         if native:
             ident = torch.zeros(COMM_ID_BYTES, dtype=torch.uint8)
             rank = dist.get_rank(group)

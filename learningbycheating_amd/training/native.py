@@ -41,9 +41,11 @@ class NativeTrainer:
         self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group, grad_dtype=grad_dtype)   # grad_dtype: see parallel.py
         if sync_bn and world_size > 1:
             # BatchNorm over the global batch (not in the reference: it trains 256 images on one device, which is what this
-            # restores for 8 x 32); its reductions get a communicator of their own (see PolicyEngine.set_sync_bn)
+            # restores for 8 x 32).  On a GPU the reductions run on the library's own RCCL communicator (`group` only carries
+            # its id); the torch.distributed transport of the CPU emulator gets a process group of its own
             import torch.distributed as dist
-            self.eng.set_sync_bn(dist.new_group() if group is None else group)
+            rccl = torch.device(device).type == "cuda" and dist.get_backend(group) == "nccl"
+            self.eng.set_sync_bn(group if (rccl or group is not None) else dist.new_group())
         self.loss = torch.zeros(batch, dtype=torch.float32, device=device)
         self.dpred_all = torch.zeros((batch, 4, 5, 2), dtype=torch.float32, device=device)
         self.dpred_sel = torch.zeros((batch, 5, 2), dtype=torch.float32, device=device)

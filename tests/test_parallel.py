@@ -37,8 +37,8 @@ def _run_world(target, world, extra=(), results=None, timeout=300):
         try:
             for _ in range(results):
                 out.append(q.get(timeout=timeout))
-        except queue_mod.Empty as e:
-            last = e
+        except (queue_mod.Empty, ConnectionError, EOFError, OSError) as e:
+            last = e          # (a tensor in the queue travels as a file descriptor its sender must still be alive to hand over)
         for p in procs:
             p.join(120 if not last else 5)
             if p.is_alive():
@@ -98,13 +98,18 @@ def _reduce_worker(rank, world, port, q, grad_dtype=None):
     broadcast_module(net)
     w = net.conv.layer2[0].conv1.weight.data
     assert not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last)
-    q.put((rank, mine[::100003].clone(), flat[::100003].clone(), w.clone(), net.deconv[1].bias.data.clone()))
+    # numpy: pickled by value (a torch tensor is passed as a shared-memory handle that dies with this process)
+    q.put((rank, mine[::100003].numpy().copy(), flat[::100003].numpy().copy(), w.contiguous().numpy().copy(), net.deconv[1].bias.data.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _as_tensors(res):
+    return [tuple(torch.from_numpy(v) if not isinstance(v, int) else v for v in item) for item in sorted(res, key=lambda t: t[0])]
+
+
 def test_staged_allreduce_gloo_world2():
-    res = sorted(_run_world(_reduce_worker, 2), key=lambda t: t[0])
+    res = _as_tensors(_run_world(_reduce_worker, 2))
     want = res[0][1] + res[1][1]
     assert torch.allclose(res[0][2], want) and torch.allclose(res[1][2], want)
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])      # broadcast_module
@@ -113,7 +118,7 @@ def test_staged_allreduce_gloo_world2():
 def test_staged_allreduce_bf16_buckets_gloo_world2():
     """compressed buckets: every rank ends with the same values, equal to the sum of the bf16-rounded shards up to one bf16
     rounding of the result"""
-    res = sorted(_run_world(_reduce_worker, 2, extra=(torch.bfloat16,)), key=lambda t: t[0])
+    res = _as_tensors(_run_world(_reduce_worker, 2, extra=(torch.bfloat16,)))
     want = res[0][1].bfloat16().float() + res[1][1].bfloat16().float()
     assert torch.equal(res[0][2], res[1][2])
     assert ((res[0][2] - want).abs() <= want.abs() * 2.0 ** -7 + 1e-6).all()
@@ -141,7 +146,7 @@ def _rccl_worker(rank, world, port, q):
         out.append(flat[::50021].cpu())
     lin = torch.nn.Linear(8, 8).to(dev)
     broadcast_module(lin)
-    q.put((rank, out[0], out[1], lin.weight.detach().cpu()))
+    q.put((rank, out[0].numpy().copy(), out[1].numpy().copy(), lin.weight.detach().cpu().numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -152,7 +157,7 @@ def test_staged_allreduce_rccl_world2():
     broadcast_module leaves rank 0's weights everywhere.  Skipped on a one-GPU box."""
     if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
         pytest.skip("needs two GPUs")
-    res = sorted(_run_world(_rccl_worker, 2, timeout=600), key=lambda t: t[0])
+    res = _as_tensors(_run_world(_rccl_worker, 2, timeout=600))
     shards = [torch.randn(_offsets_for_image_model()[1], generator=torch.Generator().manual_seed(300 + r))[::50021] for r in range(2)]
     want = shards[0] + shards[1]
     assert torch.allclose(res[0][1], want, rtol=0, atol=1e-6) and torch.equal(res[0][1], res[1][1])
