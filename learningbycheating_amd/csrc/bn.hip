@@ -44,10 +44,10 @@ __global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict_
 // Sums column c of a [rows][2][C] partial buffer.  The finalize kernels run 1024 threads = 16 channels x 64 row-lanes: lane q
 // takes rows q, q+64, ... with four row pairs in flight, the 64 lanes are combined through LDS in a fixed order
 // (deterministic).  Up to ~1024 rows this is one short launch; larger row counts are pre-reduced by partial_reduce_k.
-constexpr int kFinCh = 16, kFinLanes = 64;
+constexpr int kFinCh = 16, kFinLanes = 64, kFinWaves = kFinCh * kFinLanes / 64;
 __device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int rows, int C, int c, bool valid, double& o1, double& o2)
 {
-    __shared__ double red[2][kFinLanes][kFinCh];
+    __shared__ double red[2][kFinWaves][kFinCh];
     const int cl = threadIdx.x & (kFinCh - 1), q = threadIdx.x / kFinCh;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0, b0 = 0.0, b1 = 0.0, b2 = 0.0, b3 = 0.0;
     if (valid) {
@@ -65,12 +65,18 @@ __device__ __forceinline__ void sum_rows2(const float* __restrict__ partial, int
             b0 += (double)partial[(size_t)r * rs + C + c];
         }
     }
-    red[0][q][cl] = (a0 + a1) + (a2 + a3);
-    red[1][q][cl] = (b0 + b1) + (b2 + b3);
+    // a wave holds 4 row-lanes x 16 channels: fold the row-lanes in registers, one LDS row per wave, 16 rows for the lead lanes
+    // (the 64-step serial LDS walk this replaces was most of the kernel's 8 us)
+    double v1 = (a0 + a1) + (a2 + a3), v2 = (b0 + b1) + (b2 + b3);
+    v1 += __shfl_xor(v1, 16); v2 += __shfl_xor(v2, 16);
+    v1 += __shfl_xor(v1, 32); v2 += __shfl_xor(v2, 32);
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < kFinCh) { red[0][wave][cl] = v1; red[1][wave][cl] = v2; }
     __syncthreads();
     o1 = 0.0; o2 = 0.0;
     if (q == 0) {
-        for (int k = 0; k < kFinLanes; ++k) { o1 += red[0][k][cl]; o2 += red[1][k][cl]; }
+#pragma unroll
+        for (int k = 0; k < kFinWaves; ++k) { o1 += red[0][k][cl]; o2 += red[1][k][cl]; }
     }
 }
 
