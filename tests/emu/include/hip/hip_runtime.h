@@ -28,7 +28,7 @@
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
-#define __shared__ static
+#define __shared__ static thread_local   /* a workgroup runs on one host thread; workgroups run on several (emu_runtime.cpp) */
 #define __launch_bounds__(...)
 #ifndef __restrict__
 #define __restrict__ __restrict
@@ -40,8 +40,8 @@ struct dim3 {
     constexpr dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
 };
 struct emu_uint3 { unsigned x, y, z; };
-extern emu_uint3 threadIdx, blockIdx;
-extern dim3 blockDim, gridDim;
+extern thread_local emu_uint3 threadIdx, blockIdx;
+extern thread_local dim3 blockDim, gridDim;
 
 struct alignas(8) float2 { float x, y; };
 struct alignas(16) float4 { float x, y, z, w; };
