@@ -125,3 +125,28 @@ def test_comm_entry_points_validate_without_a_gpu():
     fn = ctypes.cast(lib.lbc_comm_allreduce_f32, ctypes.c_void_p)
     assert lib.lbc_net_set_sync_bn(eng.handle, fn, None, 2, None, 0) != 0 and b"1536" in lib.lbc_last_error()
     assert lib.lbc_net_set_sync_bn(eng.handle, None, None, 1, None, 0) == 0
+
+
+def test_c99_host_plans_the_network_through_the_header(tmp_path):
+    """include/lbc_hip.h is C (not only C++): gcc -std=c99 -pedantic compiles it, and a C host that dlopens the product
+    library plans ResNet-34 and reads the reference's state_dict names / parameter count from the tensor table"""
+    import subprocess
+    from learningbycheating_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    inc = os.path.join(root, "include")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-pedantic", "-Werror", "-fsyntax-only", "-x", "c", os.path.join(inc, "lbc_hip.h")])
+    exe = str(tmp_path / "host")
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Wextra", "-I", inc, os.path.join(root, "tests", "c_host", "host.c"), "-o", exe, "-ldl"])
+    out = subprocess.check_output([exe, _lib.LIB_PATH], timeout=120).decode()
+    kv = dict(t.split("=", 1) for t in out.split())
+    from learningbycheating_amd.bird_view.models import ImagePolicyModelSS
+    net = ImagePolicyModelSS("resnet34", all_branch=True)
+    sd = net.state_dict()
+    assert kv["backend"] == "hip-gfx950"
+    # (the unused ImageNet classifier `conv.fc.*` of the reference's torchvision trunk is in the state_dict, not in the plan)
+    used = {k: v for k, v in sd.items() if not k.startswith("conv.fc.")}
+    pused = [p for n, p in net.named_parameters() if not n.startswith("conv.fc.")]
+    assert int(kv["tensors"]) == len(used) and kv["first"] in used and kv["last"] in used
+    assert int(kv["params"]) == len(pused)
+    assert int(kv["param_elems"]) == sum(p.numel() for p in pused)
+    assert int(kv["workspace"]) > 0 and int(kv["stages"]) == 6
