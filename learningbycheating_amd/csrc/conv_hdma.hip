@@ -29,7 +29,12 @@ namespace {
 // taps 6-7 of slab c (its channel segment is the same for all of its rows, so the 8 + 8 coefficients sit in registers; they are
 // fetched one tap earlier -- extra VMEM loads in the wave's queue can only make the counted DMA waits stricter, never laxer).
 // Rows from the zero page are rewritten too; they are met only by taps that the border select sends to the zero row, which is excluded.
-template <int BM, int BN, int WM, int WN, int HRMAX, int NBUFB, int MODE, int PRE = 0>
+// EARLY = 1 (LBC_HDMA_EARLY=1; not yet measured): the fragment reads of depth step g + 1 are the FIRST instructions of step g's
+// scheduling region instead of trailing its MFMAs -- their byte offsets are formed one region ahead (ra / rb), so nothing a read
+// needs is computed in its own region.  Static picture of the default code (scripts/isa_mix.py): every step is
+// `s_waitcnt lgkmcnt(0), MFMA x3, read x2, MFMA, read x2`, i.e. the reads a step waits for were issued 0-1 MFMAs (<= 32 cycles)
+// earlier against ~64+ cycles of LDS latency, in all 8 waves at once (they leave each tap's barrier together).
+template <int BM, int BN, int WM, int WN, int HRMAX, int NBUFB, int MODE, int PRE = 0, int EARLY = 0>
 __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
@@ -175,6 +180,38 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                       \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);                 \
     } while (0)
+    int ra[MT], rb[NT];                     // EARLY: byte offsets of the NEXT fragment reads (formed one scheduling region ahead)
+#define LBC_AD(SLOT, G)                                                                                                          \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) ra[i] = abase[i] + (((2 * (G)) ^ axor[i]) << 4);                          \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) rb[j] = (SLOT) * TILE_B + bBase + j * 32 * 128 + (((2 * (G)) ^ bxor) << 4); \
+    } while (0)
+// EARLY reads are inline asm with hand-counted lgkmcnt waits: with LDS-DMA in flight the compiler's own wait insertion falls back
+// to lgkmcnt(0) in front of every depth step (it no longer trusts the return order of the LGKM queue), i.e. it would also wait
+// for the reads just issued for the NEXT step.  The compiler does not see these loads as pending, so each consumer set goes
+// through LBC_USE (an empty asm the MFMAs depend on) placed after the wait that covers it.
+#ifdef LBC_HIP_EMULATED_FOR_TESTS
+#define LBC_RDA(SET)                                                                                                             \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + ra[i]);              \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + rb[j]);              \
+    } while (0)
+#define LBC_USE(SET) do { } while (0)
+#else
+#define LBC_RDA(SET)                                                                                                             \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("ds_read_b128 %0, %1" : "=v"(fa[SET][i]) : "v"(lds0 + ra[i])); \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("ds_read_b128 %0, %1" : "=v"(fb[SET][j]) : "v"(lds0 + rb[j])); \
+    } while (0)
+#define LBC_USE(SET)                                                                                                             \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[SET][i]));                                      \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[SET][j]));                                      \
+    } while (0)
+#endif
+    // all but the MT + NT youngest LDS reads of this wave have returned (in EARLY code LDS reads are the only LGKM traffic of the loop)
+#define LBC_WAIT_OLDER_READS() __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, MT + NT))
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;      // LDS byte offset of smem (its only object: 0)
 
     // ---- PRE: in-place BatchNorm(+ReLU) of halo buffer slab & 1 (rows [0, BM + 2W + 2): the zero row and the padding rows stay)
     const int tseg = (tid & 7) ^ (((tid >> 3) >> 1) & 7);       // this thread's channel segment: rows tid / 8 + 64 i share (row >> 1) & 7
@@ -211,7 +248,9 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
         __builtin_amdgcn_s_barrier();
     }
     tap_addr(0, 0, abase, axor);
-    LBC_RD(0, 0, 0);
+    if constexpr (EARLY) { LBC_AD(0, 0); LBC_RDA(0); LBC_AD(0, 1); }
+    else LBC_RD(0, 0, 0);
+    (void)lds0;
 
     // One slab = nine K-tiles, taps unrolled.  LAST: no slab c + 1 to prefetch, and the weight ring drains.
     auto slab_body = [&](const int c, auto last_tag) {
@@ -228,6 +267,26 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
             const bool has_next = !LAST || t < 8;
 #pragma unroll
             for (int g = 0; g + 1 < KS; ++g) {
+                if constexpr (EARLY) {
+                    LBC_RDA((g + 1) & 1);                            // offsets formed in the previous region
+                    if (g < KS - 2) LBC_AD(slot, g + 2);             // ... and here those of the next region's reads
+                    else if (has_next) {                             // the next K-tile's (tap, slab) and its first step
+                        tap_addr(t < 8 ? t + 1 : 0, t < 8 ? c : c + 1, abase, axor);
+                        LBC_AD(nslot, 0);
+                    }
+                    LBC_WAIT_OLDER_READS();                          // set g & 1 is in: issued a full step (or the tap boundary) ago
+                    LBC_USE(g & 1);
+                    LBC_MM(g & 1);
+                    LBC_SG(0x100, MT + NT);
+#pragma unroll
+                    for (int q = 0; q < MT * NT; ++q) {
+                        LBC_SG(0x008, 1);
+                        if (g < KS - 2) LBC_SG(0x002, 3);
+                        else LBC_SG(0x002, 6);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    continue;
+                }
                 LBC_RD(slot, g + 1, (g + 1) & 1);
                 // the reads of the last depth step are out: the addresses are free for the next K-tile's (tap, slab)
                 if (g == KS - 2 && has_next) tap_addr(t < 8 ? t + 1 : 0, t < 8 ? c : c + 1, abase, axor);
@@ -250,7 +309,12 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
             __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (PRE && !LAST && t == 5) pre_coef(c + 1);                   // (before this tap's DMA issue: older in the queue)
-            if (has_next) LBC_RD(nslot, 0, 0);
+            if constexpr (EARLY) {
+                if (has_next) { LBC_RDA(0); LBC_AD(nslot, 1); }
+                LBC_USE((KS - 1) & 1);                                     // in since the lgkmcnt(0) in front of the barrier
+            } else {
+                if (has_next) LBC_RD(nslot, 0, 0);
+            }
             LBC_MM((KS - 1) & 1);
             if (PRE && !LAST && t == 6) pre_apply(c + 1);                  // landed and visible since the barrier above; the barriers of
                                                                            // taps 7 and 8 (after lgkmcnt(0)) publish the rewrite
@@ -259,10 +323,11 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
                 issue_b(kn < 9 ? c : c + 1, kn < 9 ? kn : kn - 9, slot);
             }
             if (!LAST && t < ATAPS && t * AP < HPW) issue_a(c + 1, t * AP, (t + 1) * AP < HPW ? (t + 1) * AP : HPW);
+            if (EARLY && has_next) LBC_SG(0x100, MT + NT);
 #pragma unroll
             for (int q = 0; q < MT * NT; ++q) {
                 LBC_SG(0x008, 1);
-                if (q < MT + NT) LBC_SG(0x100, 1);
+                if (!EARLY && q < MT + NT) LBC_SG(0x100, 1);
                 LBC_SG(0x036, 8);                                          // VALU | SALU | VMEM: address arithmetic and DMA pieces
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -272,6 +337,10 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
     slab_body(nslab - 1, std::true_type{});
 #undef LBC_RD
 #undef LBC_MM
+#undef LBC_AD
+#undef LBC_RDA
+#undef LBC_USE
+#undef LBC_WAIT_OLDER_READS
 
     // ---- epilogue (conv_lds_dma.hpp)
     lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, mtile);
@@ -551,9 +620,12 @@ int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
         return lbc_check_launch("conv_hdma64");
     }
     const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
+    const bool early = lbc_opt_on(kOptHdmaEarly);
 #define LBC_HD(BMv, BNv, WMv, WNv, HRv, NBv)                                                                                 \
     do {                                                                                                                     \
         if (mode == 0 && a.pre_scale) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0, 1>), grid, dim3(512), 0, s, a, zero); \
+        else if (early && mode == 0) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0, 0, 1>), grid, dim3(512), 0, s, a, zero); \
+        else if (early)     hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 1, 0, 1>), grid, dim3(512), 0, s, a, zero); \
         else if (mode == 0) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0>), grid, dim3(512), 0, s, a, zero);   \
         else           hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 1>), grid, dim3(512), 0, s, a, zero);   \
     } while (0)

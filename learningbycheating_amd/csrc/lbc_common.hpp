@@ -57,6 +57,7 @@ enum LbcOpt {
     kOptNoHdma64,          // LBC_NO_HDMA64: 1 = the 64-channel layer keeps conv_halo.hip
     kOptNoGldsPhased,      // LBC_NO_GLDS_PHASED: 1 = the stride-2 transposed launches keep conv_igemm.hip
     kOptHdmaPrologue,      // LBC_HDMA_PROLOGUE: 1 = conv_hdma.hip takes forward launches with BatchNorm-on-load (in-LDS transform of the halo)
+    kOptHdmaEarly,         // LBC_HDMA_EARLY: 1 = conv_hdma.hip issues each depth step's fragment reads a full step ahead (not yet measured)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

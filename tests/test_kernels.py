@@ -2,6 +2,7 @@
 Small shapes run the kernel sources under the CPU emulator (tests/emu); the gpu-marked cases run the
 real gfx950 library at the layer shapes of SURVEY.md appendix B.1 through the C ABI."""
 import ctypes
+import os
 
 import pytest
 import torch
@@ -458,6 +459,17 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         lbc_config("LBC_HDMA_PROLOGUE", 0)
         yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
         assert relerr(yp, yq) < 2.0 ** -7
+    # LBC_HDMA_EARLY=1 (fragment reads issued a full depth step ahead, hand-counted lgkmcnt waits): the same MFMAs in the same
+    # order -> bit-identical.  On the GPU only when asked for (LBC_TEST_EXPERIMENTAL=1) until the variant has been run on hardware:
+    # the emulator checks its address pipeline, not its wait counts.
+    if cfgid != 3 and (dev.type == "cpu" or os.environ.get("LBC_TEST_EXPERIMENTAL") == "1"):
+        lbc_config("LBC_HDMA_EARLY", 1)
+        ye, ste = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
+        assert torch.equal(ye, y) and torch.equal(ste, st)
+        if K % 64 == 0 and C % 128 == 0:
+            dxe = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
+            assert torch.equal(dxe, dx)
+        lbc_config("LBC_HDMA_EARLY", 0)
     # A/B: the per-tap LDS-DMA kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_HDMA", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, 1, bf16=3)
