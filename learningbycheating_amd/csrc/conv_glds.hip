@@ -283,7 +283,9 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
 // PH = 1 (MODE 1 only): the four output-parity phases of a stride-2 transposed launch in one grid (input gradient of the stride-2
 // 3x3 convolutions, ConvTranspose2d forward): workgroups [ph * n, (ph + 1) * n) serve phase ph = 2 oy0 + ox0, whose output pixels
 // (2 ly + oy0, 2 lx + ox0) gather x at (ly + dy, lx + dx) through the 1 / 2 / 2 / 4 taps with (oy0 + 1 - r, ox0 + 1 - s) even.
-template <int BM, int BN, int WM, int WN, int MODE, int KT, int DIAG = 0, int PH = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
+// EARLY (LBC_HDMA_EARLY=1, not yet measured): fragment reads issued a full depth step ahead with hand-counted waits, as in
+// conv_hdma.hip (see there and conv_lds_dma.hpp)
+template <int BM, int BN, int WM, int WN, int MODE, int KT, int DIAG = 0, int PH = 0, int EARLY = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
 __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
@@ -466,6 +468,27 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);     \
     } while (0)
+    unsigned ra = 0, rb = 0;               // EARLY: smem byte offsets of the next A / B reads (the 32-row blocks are immediates)
+#define LBC_AD(bufoff, G) do { ra = (unsigned)((bufoff) + aBase + koff[G]); rb = (unsigned)((bufoff) + bBase + koff[G]); } while (0)
+#define LBC_RDA(SET)                                                                                                 \
+    do {                                                                                                             \
+        lds_read16_early_n<MT, 32 * ROWB>(fa[SET], smem, ra);                                                        \
+        lds_read16_early_n<NT, 32 * ROWB>(fb[SET], smem, rb);                                                        \
+    } while (0)
+#define LBC_USE(SET) do { lds_frag_use(fa[SET]); lds_frag_use(fb[SET]); } while (0)
+#define LBC_WAIT_OLDER_READS() __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, MT + NT))
+    // EARLY: one depth step of K-tile `ob` (next tile `on`): reads of step g + 1, offsets of the reads after those, MFMAs of step g
+#define LBC_STEP_EARLY(ob, on, g)                                                                                    \
+    do {                                                                                                             \
+        LBC_RDA(((g) + 1) & 1);                                                                                      \
+        if ((g) + 2 < KS) LBC_AD(ob, (g) + 2 < KS ? (g) + 2 : 0);                                                    \
+        else LBC_AD(on, 0);                                                                                          \
+        LBC_WAIT_OLDER_READS();                                                                                      \
+        LBC_USE((g) & 1);                                                                                            \
+        LBC_MM((g) & 1);                                                                                             \
+        LBC_SG(0x100, MT + NT); LBC_SG(0x002, 2); LBC_SG(0x008, MT * NT);                                            \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+    } while (0)
     // one MFMA, one fragment read, ...: the reads of the next depth step between the MFMAs of the current one
 #define LBC_MIX()                                                                                                    \
     do {                                                                                                             \
@@ -486,7 +509,8 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         if (i < nit) issue();
     wait_tiles((nit < NBUF ? nit : NBUF) - 1);
     __builtin_amdgcn_s_barrier();
-    LBC_RD(smem, 0, 0);
+    if constexpr (EARLY) { LBC_AD(0, 0); LBC_RDA(0); LBC_AD(0, KS > 1 ? 1 : 0); }
+    else LBC_RD(smem, 0, 0);
 
     // Synchronisation of K-tile t (buffer t % NBUF), once per tile, in front of its LAST depth step:
     //   s_waitcnt vmcnt: own pieces of tile t + 1 landed (NBUF - 2 younger tiles may stay in flight);  lgkmcnt(0);  s_barrier
@@ -498,10 +522,12 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
     //      arithmetic and the fragment reads spread between the MFMAs
     int t = 0;
     for (; t + NBUF < nit; ++t) {
-        const char* bb = smem + (t & (NBUF - 1)) * BUF;
-        const char* bn = smem + ((t + 1) & (NBUF - 1)) * BUF;
+        const int ob = (t & (NBUF - 1)) * BUF, on = ((t + 1) & (NBUF - 1)) * BUF;
+        const char* bb = smem + ob;
+        const char* bn = smem + on;
 #pragma unroll
         for (int g = 0; g + 1 < KS; ++g) {
+            if constexpr (EARLY) { LBC_STEP_EARLY(ob, on, g); continue; }
             LBC_RD(bb, g + 1, (g + 1) & 1);
             LBC_MM(g & 1);
             LBC_MIX();
@@ -511,23 +537,27 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         LBC_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        LBC_RD(bn, 0, 0);
+        if constexpr (EARLY) { LBC_RDA(0); LBC_AD(on, KS > 1 ? 1 : 0); LBC_USE((KS - 1) & 1); }
+        else LBC_RD(bn, 0, 0);
         LBC_MM((KS - 1) & 1);
         if (DIAG != 1) issue();
+        if (EARLY) LBC_SG(0x100, MT + NT);
 #pragma unroll
         for (int k = 0; k < MT * NT; ++k) {
             LBC_SG(0x008, 1);
-            if (k < MT + NT) LBC_SG(0x100, 1);
+            if (!EARLY && k < MT + NT) LBC_SG(0x100, 1);
             LBC_SG(0x036, 10);                    // VALU | SALU | VMEM: the address arithmetic and DMA pieces of tile t + NBUF
         }
         __builtin_amdgcn_sched_barrier(0);
     }
     // ---- the last (up to) NBUF tiles: nothing left to issue
     for (; t < nit; ++t) {
-        const char* bb = smem + (t & (NBUF - 1)) * BUF;
-        const char* bn = smem + ((t + 1) & (NBUF - 1)) * BUF;
+        const int ob = (t & (NBUF - 1)) * BUF, on = ((t + 1) & (NBUF - 1)) * BUF;
+        const char* bb = smem + ob;
+        const char* bn = smem + on;
 #pragma unroll
         for (int g = 0; g + 1 < KS; ++g) {
+            if constexpr (EARLY) { LBC_STEP_EARLY(ob, on, g); continue; }
             LBC_RD(bb, g + 1, (g + 1) & 1);
             LBC_MM(g & 1);
             LBC_MIX();
@@ -537,12 +567,24 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
         wait_tiles(left < 0 ? 0 : (left > NBUF - 2 ? NBUF - 2 : left));
         LBC_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
-        if (t + 1 < nit) LBC_RD(bn, 0, 0);
+        if constexpr (EARLY) {
+            __builtin_amdgcn_sched_barrier(0);
+            if (t + 1 < nit) { LBC_RDA(0); LBC_AD(on, KS > 1 ? 1 : 0); }
+            LBC_USE((KS - 1) & 1);
+        } else {
+            if (t + 1 < nit) LBC_RD(bn, 0, 0);
+        }
         LBC_MM((KS - 1) & 1);
+        if constexpr (EARLY) __builtin_amdgcn_sched_barrier(0);
     }
 #undef LBC_RD
 #undef LBC_MM
 #undef LBC_MIX
+#undef LBC_AD
+#undef LBC_RDA
+#undef LBC_USE
+#undef LBC_WAIT_OLDER_READS
+#undef LBC_STEP_EARLY
 
     // ---- epilogue (conv_lds_dma.hpp): affine / bias / residual / ReLU, LDS-staged 16-byte stores, statistics / fused BN-backward reduce
     lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, stat_tile0 + mtile, PH ? 2 : 1, oy0, ox0);
@@ -627,7 +669,10 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
         const bool kt64 = lbc_opt(kOptGldsKt) > 0 ? lbc_opt(kOptGldsKt) != 32 : !(cfg == kLbcCfgGlds + 3 && a.C >= 128);
 #define LBC_GL2(BMv, BNv, WMv, WNv)                                                                                          \
     do {                                                                                                                     \
-        if (kt64) {                                                                                                          \
+        if (kt64 && early) {                                                                                                 \
+            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64, 0, 0, 1>), grid, dim3(512), 0, s, a, zero); \
+            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 0, 1>), grid, dim3(512), 0, s, a, zero); \
+        } else if (kt64) {                                                                                                   \
             if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64>), grid, dim3(512), 0, s, a, zero);    \
             else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64>), grid, dim3(512), 0, s, a, zero);    \
         } else {                                                                                                             \
@@ -635,6 +680,7 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
             else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 32>), grid, dim3(512), 0, s, a, zero);    \
         }                                                                                                                    \
     } while (0)
+        const bool early = lbc_opt_on(kOptHdmaEarly);
         const long long dg = lbc_opt(kOptGldsDiag);
         if (dg > 0 && cfg == kLbcCfgGlds + 0 && mode == 0) {        // 1 = no DMA stream in the steady state, 2 = every piece from the zero page
             // 1 = no DMA stream in the steady state, 2 = every piece from the zero page, 3 = activation pieces from the zero page, 4 = weight pieces
@@ -645,7 +691,11 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
             return lbc_check_launch("conv_glds2");
         }
         if (phased) {
-#define LBC_GLP(BMv, BNv, WMv, WNv) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1>), grid, dim3(512), 0, s, a, zero)
+#define LBC_GLP(BMv, BNv, WMv, WNv)                                                                                          \
+    do {                                                                                                                     \
+        if (early) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1, 1>), grid, dim3(512), 0, s, a, zero);   \
+        else       hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1>), grid, dim3(512), 0, s, a, zero);      \
+    } while (0)
             if (cfg == kLbcCfgGlds + 0) LBC_GLP(256, 256, 2, 4);
             else if (cfg == kLbcCfgGlds + 1) LBC_GLP(256, 128, 4, 2);
             else if (cfg == kLbcCfgGlds + 2) LBC_GLP(128, 256, 2, 4);

@@ -394,9 +394,20 @@ def test_conv_glds_stride2_transposed_phases(env, case, lbc_config):
     yy.backward(dy)
     dx = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
     assert relerr(dx, xg.grad) < 1e-4 + OUT_TOL[2]
+    if early_reads_checked(dev):
+        lbc_config("LBC_HDMA_EARLY", 1)
+        assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True), dx)
+        lbc_config("LBC_HDMA_EARLY", 0)
     lbc_config("LBC_NO_GLDS_PHASED", 1)
     dx2 = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
     assert relerr(dx, dx2) < 2.0 ** -7
+
+
+def early_reads_checked(dev):
+    """the LBC_HDMA_EARLY variants (fragment reads a full depth step ahead, hand-counted lgkmcnt waits) are compared bit for bit with
+    the default kernels on the emulator -- which checks their address pipeline, not their wait counts -- and on the GPU only when
+    asked for (LBC_TEST_EXPERIMENTAL=1) until they have been run on hardware"""
+    return dev.type == "cpu" or os.environ.get("LBC_TEST_EXPERIMENTAL") == "1"
 
 
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
@@ -462,7 +473,7 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     # LBC_HDMA_EARLY=1 (fragment reads issued a full depth step ahead, hand-counted lgkmcnt waits): the same MFMAs in the same
     # order -> bit-identical.  On the GPU only when asked for (LBC_TEST_EXPERIMENTAL=1) until the variant has been run on hardware:
     # the emulator checks its address pipeline, not its wait counts.
-    if cfgid != 3 and (dev.type == "cpu" or os.environ.get("LBC_TEST_EXPERIMENTAL") == "1"):
+    if cfgid != 3 and early_reads_checked(dev):
         lbc_config("LBC_HDMA_EARLY", 1)
         ye, ste = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
         assert torch.equal(ye, y) and torch.equal(ste, st)
@@ -498,6 +509,11 @@ def test_conv_glds_stride2_gather(env, case, lbc_config):
     y, st = Conv(dev).fwd(x, w, 2, p, stats=True, bf16=3)
     assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
     assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    if early_reads_checked(dev):
+        lbc_config("LBC_HDMA_EARLY", 1)
+        ye, ste = Conv(dev).fwd(x, w, 2, p, stats=True, bf16=3)
+        assert torch.equal(ye, y) and torch.equal(ste, st)
+        lbc_config("LBC_HDMA_EARLY", 0)
     lbc_config("LBC_NO_GEMM256", 1)
     y3, _ = Conv(dev).fwd(x, w, 2, p, bf16=3)
     assert relerr(y, y3) < 2.0 ** -7
@@ -705,6 +721,13 @@ def test_conv_glds_fwd_dgrad(env, case, gen, lbc_config):
         rr = rbf(torch.randn(x.shape, generator=g))
         dx = Conv(dev).dgrad(dy, w, H, W, 1, p, resid=rr, bf16=3, transposed=True)
         assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
+    if gen == 2 and early_reads_checked(dev):
+        lbc_config("LBC_HDMA_EARLY", 1)
+        ye, ste = Conv(dev).fwd(x, w, 1, p, stats=True, bf16=3)
+        assert torch.equal(ye, y) and torch.equal(ste, st)
+        if C % 128 == 0:
+            assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 1, p, resid=rr, bf16=3, transposed=True), dx)
+        lbc_config("LBC_HDMA_EARLY", 0)
     # 4. A/B: the generic kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_GEMM256", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, p, bf16=3)
