@@ -132,7 +132,11 @@ __global__ __launch_bounds__(256) void bn_eval_prep_k(BnEvalArgs a)
 }
 
 // ---- elementwise apply: y = relu?(x*s + t (+ r [* rs + rt])) ------------------
-template <typename T>
+// The launcher makes the grid stride a whole number of pixels, so a thread stays on one channel group: its coefficient vectors are
+// loaded once (per iteration they were 4 + 4 more 16-byte loads next to the 1 + 1 that carry data), and both data loads of an
+// iteration are issued before either is used (RES is a template flag: a runtime `if (resid)` between them split the loop body and
+// put an `s_waitcnt vmcnt(0)` behind each load -- one memory latency per 16 bytes and wave, ~4.5 TB/s with every wave slot taken).
+template <typename T, bool RES>
 __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
 {
     constexpr int V = Act<T>::kVec;          // 16-byte accesses: 4 f32 or 8 bf16 channels per thread
@@ -143,17 +147,20 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
     T* y = static_cast<T*>(a.y);
     const int cvn = a.C / V;
     const long long total = a.pixels * cvn;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int c = (int)(i % cvn) * V;
+    const long long stride = (long long)gridDim.x * blockDim.x;      // a multiple of cvn (lbc_bn_apply)
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = (int)(i0 % cvn) * V;
+    const vec sc = PV::ld(a.scale + c), sh = PV::ld(a.shift + c);
+    vec rsc = PV::splat(1.f), rsh = PV::splat(0.f);
+    if (RES && a.rscale) { rsc = PV::ld(a.rscale + c); rsh = PV::ld(a.rshift + c); }
+    const bool relu = a.relu != 0;
+    for (long long i = i0; i < total; i += stride) {
         vec v = Act<T>::ldv(x + i * V);
-        v = v * PV::ld(a.scale + c) + PV::ld(a.shift + c);
-        if (resid) {
-            vec r = Act<T>::ldv(resid + i * V);
-            if (a.rscale) r = r * PV::ld(a.rscale + c) + PV::ld(a.rshift + c);
-            v += r;
-        }
-        if (a.relu) {
+        vec r = v;
+        if (RES) r = Act<T>::ldv(resid + i * V);
+        v = v * sc + sh;
+        if (RES) v += r * rsc + rsh;
+        if (relu) {
 #pragma unroll
             for (int e = 0; e < V; ++e) v[e] = fmaxf(v[e], 0.f);
         }
@@ -273,8 +280,13 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
 }
 
 // ---- backward apply: dx = A*(g - k1 - xhat*k2) over the first Cout channels --------
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdApplyArgs a)
+// Same structure as bn_apply_k: grid stride = whole pixels (of the Cout / V output groups), the five coefficient vectors loaded
+// once (they were 10 of the 12 loads of an iteration in the bf16 kernel), no 64-bit division per iteration, and every data load of
+// an iteration issued before the first use (MASK / ACCUM are template flags).
+template <typename T, bool MASK, bool ACCUM>
+__global__ __launch_bounds__(256, (MASK || ACCUM) ? 1 : 8) void bn_bwd_apply_k(BnBwdApplyArgs a)
+// (8 waves per SIMD = at most 64 VGPRs for the plain variant: its bf16 form sits at 66 without the bound and fits without scratch with it;
+// the MASK / ACCUM forms would spill and keep 6-7 waves)
 {
     constexpr int V = Act<T>::kVec;
     using vec = typename Act<T>::vec;
@@ -286,21 +298,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_k(BnBwdApplyArgs a)
     const int cvn = a.C / V;
     const int ovn = a.Cout / V;
     const long long total = a.pixels * ovn;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const long long p = i / ovn;
-        const int cg = (int)(i - p * ovn);
-        const int c = cg * V;
-        const long long j = (p * cvn + cg) * V;
+    const long long stride = (long long)gridDim.x * blockDim.x;      // a multiple of ovn (lbc_bn_bwd_apply)
+    const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    const int cg = (int)(i0 % ovn), c = cg * V;
+    const vec cA = PV::ld(a.coefA + c), k1 = PV::ld(a.coefB + c), k2 = PV::ld(a.coefD + c);
+    const vec mean = PV::ld(a.mean + c), inv = PV::ld(a.invstd + c);
+    long long j = ((i0 / ovn) * cvn + cg) * V;                       // element offset in the C-channel tensors
+    const long long dj = (stride / ovn) * cvn * V;
+    for (long long i = i0; i < total; i += stride, j += dj) {
         vec g = Act<T>::ldv(gp + j);
-        if (mask) {
-            const vec m = Act<T>::ldv(mask + j);
+        const vec v = Act<T>::ldv(xx + j);
+        vec m = g, old = g;
+        if (MASK) m = Act<T>::ldv(mask + j);
+        if (ACCUM) old = Act<T>::ldv(dx + i * V);
+        if (MASK) {
 #pragma unroll
             for (int e = 0; e < V; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
         }
-        const vec v = Act<T>::ldv(xx + j);
-        vec o = PV::ld(a.coefA + c) * (g - PV::ld(a.coefB + c) - (v - PV::ld(a.mean + c)) * PV::ld(a.invstd + c) * PV::ld(a.coefD + c));
-        if (a.accum) o += Act<T>::ldv(dx + i * V);
+        vec o = cA * (g - k1 - (v - mean) * inv * k2);
+        if (ACCUM) o += old;
         Act<T>::stv(dx + i * V, o);
     }
 }
@@ -338,6 +354,19 @@ int grid_for(long long total4)
     long long b = (total4 + 255) / 256;
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
+    return (int)b;
+}
+
+// as grid_for, with grid * 256 a multiple of `groups` (the 16-byte channel groups of a pixel): a thread of a grid-stride loop then
+// stays on one channel group.  groups = 8 .. 64 divide 256; 80 (640 channels) needs a multiple of 5 blocks.
+int grid_for_groups(long long total, int groups)
+{
+    int g = 256, r = groups;
+    while (r) { const int t = g % r; g = r; r = t; }       // g = gcd(256, groups)
+    const int unit = groups / g;
+    long long b = grid_for(total);
+    b = b / unit * unit;
+    if (b < unit) b = unit;
     return (int)b;
 }
 
@@ -379,8 +408,13 @@ int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 8 == 0 && a.pixels > 0, "bn_apply: bad shape");
     LbcProfScope prof("bn_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * a.C * (a.resid ? 3 : 2), s);
-#define LBC_K(T, g) hipLaunchKernelGGL((bn_apply_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
-    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.C / (a.act_bf16 ? 8 : 4))));
+    const int groups = a.C / (a.act_bf16 ? 8 : 4);
+#define LBC_K(T, g)                                                                                              \
+    do {                                                                                                         \
+        if (a.resid) hipLaunchKernelGGL((bn_apply_k<T, true>), dim3((unsigned)(g)), dim3(256), 0, s, a);         \
+        else         hipLaunchKernelGGL((bn_apply_k<T, false>), dim3((unsigned)(g)), dim3(256), 0, s, a);        \
+    } while (0)
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for_groups(a.pixels * groups, groups));
 #undef LBC_K
     return lbc_check_launch("bn_apply");
 }
@@ -426,8 +460,15 @@ int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 8 == 0 && a.Cout % 8 == 0 && a.Cout <= a.C, "bn_bwd_apply: bad channels");
     LbcProfScope prof("bn_bwd_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * (a.C * (a.mask ? 3.0 : 2.0) + a.Cout * (a.accum ? 2.0 : 1.0)), s);
-#define LBC_K(T, g) hipLaunchKernelGGL((bn_bwd_apply_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
-    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for(a.pixels * (a.Cout / (a.act_bf16 ? 8 : 4))));
+    const int groups = a.Cout / (a.act_bf16 ? 8 : 4);
+#define LBC_K(T, g)                                                                                                      \
+    do {                                                                                                                 \
+        if (a.mask && a.accum)  hipLaunchKernelGGL((bn_bwd_apply_k<T, true, true>), dim3((unsigned)(g)), dim3(256), 0, s, a);   \
+        else if (a.mask)        hipLaunchKernelGGL((bn_bwd_apply_k<T, true, false>), dim3((unsigned)(g)), dim3(256), 0, s, a);  \
+        else if (a.accum)       hipLaunchKernelGGL((bn_bwd_apply_k<T, false, true>), dim3((unsigned)(g)), dim3(256), 0, s, a);  \
+        else                    hipLaunchKernelGGL((bn_bwd_apply_k<T, false, false>), dim3((unsigned)(g)), dim3(256), 0, s, a); \
+    } while (0)
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for_groups(a.pixels * groups, groups));
 #undef LBC_K
     return lbc_check_launch("bn_bwd_apply");
 }
