@@ -172,7 +172,9 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
 // Block layout: 256 threads = (C/4 channel groups) x RL pixel lanes (RL = 256/(C/4),
 // C/4 <= 256).  Each block owns a contiguous pixel range and writes one partial row
 // [2][C]:  row0 = sum g, row1 = sum g*q  where the meaning of g, q depends on the op.
-template <int OP, typename T>
+// MASK / HASX / GOUT (which of a.mask, a.x, a.g_out are present) are template flags: as runtime null checks they sat between the
+// loads of a batch and the compiler answered each with a branch and an `s_waitcnt vmcnt(1)` -- the batch was loaded one pair at a time.
+template <int OP, typename T, bool MASK, bool HASX, bool GOUT>
 __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
 {
     constexpr int V = Act<T>::kVec;
@@ -204,14 +206,14 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
                 s1 += v;
                 s2 += v * v;
             } else {                  // backward: g = dz * (mask > 0); sum g, sum g * xhat
-                if (mask) {
-                    if (a.mask_scale) m = m * msc + msh;
+                if (MASK) {
+                    m = m * msc + msh;                 // (1, 0) without a mask transform: exact
 #pragma unroll
                     for (int e = 0; e < V; ++e) g[e] = m[e] > 0.f ? g[e] : 0.f;
                 }
-                if (g_out) Act<T>::stv(g_out + i, g);
+                if (GOUT) Act<T>::stv(g_out + i, g);
                 s1 += g;
-                if (xx) s2 += g * (v - mean) * inv;
+                if (HASX) s2 += g * (v - mean) * inv;
             }
         };
         long long p = p0 + pl;
@@ -223,8 +225,8 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
                 if (OP == 0) { v[u] = Act<T>::ldr(xx + i); g[u] = v[u]; m[u] = v[u]; }
                 else {
                     g[u] = Act<T>::ldr(dz + i);
-                    m[u] = mask ? Act<T>::ldr(mask + i) : g[u];
-                    v[u] = xx ? Act<T>::ldr(xx + i) : g[u];
+                    m[u] = MASK ? Act<T>::ldr(mask + i) : g[u];
+                    v[u] = HASX ? Act<T>::ldr(xx + i) : g[u];
                 }
             }
 #pragma unroll
@@ -235,7 +237,7 @@ __global__ __launch_bounds__(256) void channel_reduce_k(ChanReduceArgs a)
             if (OP == 0) { const vec v = Act<T>::ldv(xx + i); one(i, v, v, v); }
             else {
                 const vec g = Act<T>::ldv(dz + i);
-                one(i, g, mask ? Act<T>::ldv(mask + i) : g, xx ? Act<T>::ldv(xx + i) : g);
+                one(i, g, MASK ? Act<T>::ldv(mask + i) : g, HASX ? Act<T>::ldv(xx + i) : g);
             }
         }
     }
@@ -442,10 +444,30 @@ int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
     a.pix_per_block = (a.pixels + rows - 1) / rows;
     LbcProfScope prof(op == 0 ? "channel_stats" : "bn_bwd_reduce", 0.0,
                       (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * a.C * (op == 0 ? 1 : (1 + (a.mask ? 1 : 0) + (a.x ? 1 : 0) + (a.g_out ? 1 : 0))), s);
-#define LBC_K(T, OPV) hipLaunchKernelGGL((channel_reduce_k<OPV, T>), dim3((unsigned)rows), dim3(256), 0, s, a)
-    if (op == 0) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 0);
-    else         LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 1);
+#define LBC_KF(T, OPV, M, X, G) hipLaunchKernelGGL((channel_reduce_k<OPV, T, M, X, G>), dim3((unsigned)rows), dim3(256), 0, s, a)
+#define LBC_K(T, OPV)                                                                                    \
+    do {                                                                                                 \
+        const int f = OPV == 0 ? 2 : (a.mask ? 4 : 0) | (a.x ? 2 : 0) | (a.g_out ? 1 : 0);              \
+        switch (f) {                                                                                     \
+        case 0: LBC_KF(T, OPV, false, false, false); break;                                              \
+        case 1: LBC_KF(T, OPV, false, false, true); break;                                               \
+        case 2: LBC_KF(T, OPV, false, true, false); break;                                               \
+        case 3: LBC_KF(T, OPV, false, true, true); break;                                                \
+        case 4: LBC_KF(T, OPV, true, false, false); break;                                               \
+        case 5: LBC_KF(T, OPV, true, false, true); break;                                                \
+        case 6: LBC_KF(T, OPV, true, true, false); break;                                                \
+        default: LBC_KF(T, OPV, true, true, true); break;                                                \
+        }                                                                                                \
+    } while (0)
+    if (op == 0) {
+        LBC_REQUIRE(a.x, "channel_stats: null input");
+        if (a.act_bf16) LBC_KF(__bf16, 0, false, true, false);
+        else            LBC_KF(float, 0, false, true, false);
+    } else {
+        LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 1);
+    }
 #undef LBC_K
+#undef LBC_KF
     return lbc_check_launch("channel_reduce");
 }
 
