@@ -10,7 +10,7 @@
 
 namespace {
 
-template <typename T>
+template <typename T, typename IDX>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
 {
     constexpr int V = Act<T>::kVec;          // 16-byte accesses: 4 f32 or 8 bf16 channels per thread
@@ -20,36 +20,48 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
     T* pout = static_cast<T*>(a.p);
     const int OH = a.H / 2, OW = a.W / 2;
     const int cvn = a.C / V;
-    const long long total = (long long)a.N * OH * OW * cvn;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int cg = (int)(i % cvn);
-        long long t = i / cvn;
-        const int ox = (int)(t % OW); t /= OW;
-        const int oy = (int)(t % OH);
-        const int n = (int)(t / OH);
+    // IDX = unsigned when every index of the launch fits 32 bits (lbc_bn_relu_maxpool_fwd): four 64-bit divisions per element otherwise
+    const IDX total = (IDX)((long long)a.N * OH * OW * cvn);
+    const IDX stride = (IDX)gridDim.x * (IDX)blockDim.x;
+    for (IDX i = (IDX)blockIdx.x * (IDX)blockDim.x + (IDX)threadIdx.x; i < total; i += stride) {
+        IDX t = i;
+        const int cg = (int)(t % (IDX)cvn); t /= (IDX)cvn;
+        const int ox = (int)(t % (IDX)OW); t /= (IDX)OW;
+        const int oy = (int)(t % (IDX)OH);
+        const int n = (int)(t / (IDX)OH);
         const int c = cg * V;
         const vec sc = PV::ld(a.scale + c), sh = PV::ld(a.shift + c);
         vec best = PV::splat(-INFINITY);
         int bi[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) bi[e] = 0;
+        // all nine taps are requested before the first is used (border taps from a clamped, always valid address; they are
+        // dropped below): with `continue` on the border tests every load sat in a block of its own behind an s_waitcnt vmcnt(0)
+        // -- nine memory latencies in a row per output element
+        typename Act<T>::raw raw[9];
+        bool ok[9];
 #pragma unroll
         for (int r = 0; r < 3; ++r) {
             const int iy = 2 * oy - 1 + r;
-            if ((unsigned)iy >= (unsigned)a.H) continue;
+            const bool oky = (unsigned)iy < (unsigned)a.H;
+            const int cy = oky ? iy : oy * 2;
 #pragma unroll
             for (int s = 0; s < 3; ++s) {
                 const int ix = 2 * ox - 1 + s;
-                if ((unsigned)ix >= (unsigned)a.W) continue;
-                vec v = Act<T>::ldv(y + ((size_t)(n * a.H + iy) * a.W + (size_t)ix) * a.C + c);
-                v = v * sc + sh;
-                const int tap = r * 3 + s;
+                const bool okx = (unsigned)ix < (unsigned)a.W;
+                const int cx = okx ? ix : ox * 2;
+                ok[r * 3 + s] = oky && okx;
+                raw[r * 3 + s] = Act<T>::ldr(y + ((size_t)(n * a.H + cy) * a.W + (size_t)cx) * a.C + c);
+            }
+        }
 #pragma unroll
-                for (int e = 0; e < V; ++e) {
-                    const float z = fmaxf(v[e], 0.f);
-                    if (z > best[e]) { best[e] = z; bi[e] = tap; }
-                }
+        for (int tap = 0; tap < 9; ++tap) {
+            vec v = Act<T>::cvt(raw[tap]);
+            v = v * sc + sh;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float z = ok[tap] ? fmaxf(v[e], 0.f) : -INFINITY;      // (-inf never beats the running maximum)
+                if (z > best[e]) { best[e] = z; bi[e] = tap; }
             }
         }
         Act<T>::stv(pout + i * V, best);
@@ -66,7 +78,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
 
 // Backward: for every stem-output element gather the pooled gradients whose arg-max
 // is this element, apply the ReLU mask, store g and reduce (sum g, sum g*xhat).
-template <typename T>
+template <typename T, typename IDX>      // IDX = unsigned when the pixel index fits 32 bits (three 64-bit divisions per pixel otherwise)
 __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
 {
     constexpr int V = Act<T>::kVec;
@@ -91,33 +103,44 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
         long long p1 = p0 + a.pix_per_block;
         if (p1 > pixels) p1 = pixels;
         for (long long p = p0 + pl; p < p1; p += rl) {
-            const int x = (int)(p % a.W);
-            const long long t = p / a.W;
-            const int yy = (int)(t % a.H);
-            const int n = (int)(t / a.H);
+            const IDX pi = (IDX)p;
+            const int x = (int)(pi % (IDX)a.W);
+            const IDX t = pi / (IDX)a.W;
+            const int yy = (int)(t % (IDX)a.H);
+            const int n = (int)(t / (IDX)a.H);
             vec g = PV::splat(0.f);
             const int oy0 = yy >> 1, oy1 = (yy + 1) >> 1;   // windows covering row y (equal when y is even)
             const int ox0 = x >> 1, ox1 = (x + 1) >> 1;
-            for (int oy = oy0; oy <= oy1; ++oy) {
-                if (oy >= OH) continue;
-                const int r = yy - (2 * oy - 1);
-                for (int ox = ox0; ox <= ox1; ++ox) {
-                    if (ox >= OW) continue;
-                    const int s = x - (2 * ox - 1);
-                    const int tap = r * 3 + s;
-                    const size_t o = ((size_t)(n * OH + oy) * OW + (size_t)ox) * cvn + cg;
-                    const vec d = Act<T>::ldv(dp + o * V);
+            // the (up to) 2 x 2 windows as a fixed set with validity flags, every load requested before the first use (row / column 0
+            // always exist: oy0 <= OH - 1; the second exists when it differs and lies inside) -- the data-dependent loops with
+            // `continue` put each window's two loads behind the previous window's wait
+            const bool rok = oy1 != oy0 && oy1 < OH, cok = ox1 != ox0 && ox1 < OW;
+            const int oyw[2] = {oy0, rok ? oy1 : oy0}, oxw[2] = {ox0, cok ? ox1 : ox0};
+            typename Act<T>::raw draw[4];
+            uchar4 uraw[4][V / 4];
 #pragma unroll
-                    for (int q = 0; q < V / 4; ++q) {
-                        const uchar4 u = reinterpret_cast<const uchar4*>(a.idx)[o * (V / 4) + q];
-                        if (u.x == tap) g[4 * q] += d[4 * q];
-                        if (u.y == tap) g[4 * q + 1] += d[4 * q + 1];
-                        if (u.z == tap) g[4 * q + 2] += d[4 * q + 2];
-                        if (u.w == tap) g[4 * q + 3] += d[4 * q + 3];
-                    }
+            for (int wv = 0; wv < 4; ++wv) {
+                const size_t o = ((size_t)(n * OH + oyw[wv >> 1]) * OW + (size_t)oxw[wv & 1]) * cvn + cg;
+                draw[wv] = Act<T>::ldr(dp + o * V);
+#pragma unroll
+                for (int q = 0; q < V / 4; ++q) uraw[wv][q] = reinterpret_cast<const uchar4*>(a.idx)[o * (V / 4) + q];
+            }
+            const typename Act<T>::raw yraw = Act<T>::ldr(y + (p * cvn + cg) * V);
+#pragma unroll
+            for (int wv = 0; wv < 4; ++wv) {                // same order as the loops it replaces: (oy0, ox0), (oy0, ox1), (oy1, ox0), (oy1, ox1)
+                const bool okw = ((wv >> 1) == 0 || rok) && ((wv & 1) == 0 || cok);
+                const int tap = okw ? (yy - (2 * oyw[wv >> 1] - 1)) * 3 + (x - (2 * oxw[wv & 1] - 1)) : 255;     // 255: no arg-max index matches
+                const vec d = Act<T>::cvt(draw[wv]);
+#pragma unroll
+                for (int q = 0; q < V / 4; ++q) {
+                    const uchar4 u = uraw[wv][q];
+                    if (u.x == tap) g[4 * q] += d[4 * q];
+                    if (u.y == tap) g[4 * q + 1] += d[4 * q + 1];
+                    if (u.z == tap) g[4 * q + 2] += d[4 * q + 2];
+                    if (u.w == tap) g[4 * q + 3] += d[4 * q + 3];
                 }
             }
-            const vec v = Act<T>::ldv(y + (p * cvn + cg) * V);
+            const vec v = Act<T>::cvt(yraw);
             const vec z = v * sc + sh;
 #pragma unroll
             for (int e = 0; e < V; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
@@ -150,7 +173,12 @@ int lbc_bn_relu_maxpool_fwd(const PoolFwdArgs& a, hipStream_t s)
     long long blocks = (total / (a.act_bf16 ? 2 : 1) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     LbcProfScope prof("bn_relu_maxpool_fwd", 0.0, (a.act_bf16 ? 2.0 : 4.0) * total * 4 * (4.0 + 1.0) + total * 4.0, s);
-#define LBC_K(T, g) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
+    const bool small = total + blocks * 256 < (1ll << 31);       // (the loop index passes `total` by less than one grid stride)
+#define LBC_K(T, g)                                                                                                          \
+    do {                                                                                                                     \
+        if (small) hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<T, unsigned>), dim3((unsigned)(g)), dim3(256), 0, s, a);        \
+        else       hipLaunchKernelGGL((bn_relu_maxpool_fwd_k<T, long long>), dim3((unsigned)(g)), dim3(256), 0, s, a);       \
+    } while (0)
     LBC_DISPATCH_ACT(a.act_bf16, LBC_K, blocks);
 #undef LBC_K
     return lbc_check_launch("bn_relu_maxpool_fwd");
@@ -165,7 +193,12 @@ int lbc_maxpool_relu_bwd_reduce(PoolBwdArgs a, hipStream_t s)
     const int rows = lbc_pool_bwd_rows(a.N, a.H, a.W, a.C);
     a.pix_per_block = (pixels + rows - 1) / rows;
     LbcProfScope prof("maxpool_relu_bwd_reduce", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)pixels * a.C * (2.0 + 0.25) + (double)pixels * a.C * 0.25, s);
-#define LBC_K(T, g) hipLaunchKernelGGL((maxpool_relu_bwd_reduce_k<T>), dim3((unsigned)(g)), dim3(256), 0, s, a)
+    const bool small = pixels < (1ll << 31);
+#define LBC_K(T, g)                                                                                                              \
+    do {                                                                                                                         \
+        if (small) hipLaunchKernelGGL((maxpool_relu_bwd_reduce_k<T, unsigned>), dim3((unsigned)(g)), dim3(256), 0, s, a);        \
+        else       hipLaunchKernelGGL((maxpool_relu_bwd_reduce_k<T, long long>), dim3((unsigned)(g)), dim3(256), 0, s, a);       \
+    } while (0)
     LBC_DISPATCH_ACT(a.act_bf16, LBC_K, rows);
 #undef LBC_K
     return lbc_check_launch("maxpool_relu_bwd_reduce");

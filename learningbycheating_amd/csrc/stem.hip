@@ -48,29 +48,37 @@ __global__ __launch_bounds__(256) void prep_input_k(const float* __restrict__ im
 
 // uint8 NHWC frames (what the LMDB dataset stores: reference bird_view/utils/datasets/image_lmdb.py:128-222 decodes them to
 // f32 CHW on the host): /255, ImageNet normalisation and the zero border in one pass, 4x fewer input bytes
-template <typename XT>
+// CIN = 3 / 7 (the two networks) unrolls the channel loop with every byte load in front of the first use (with the channel count
+// a runtime value each 1-byte load was followed by its own s_waitcnt vmcnt(0)); CIN = 0: any C <= 8.  IDX = unsigned when the
+// padded pixel index fits 32 bits.
+template <typename XT, int CIN, typename IDX>
 __global__ __launch_bounds__(256) void prep_input_u8_k(const unsigned char* __restrict__ img, XT* __restrict__ xp, int N, int C,
                                                        int H, int W, NormConst nc)
 {
     const int Hp = H + 6, Wp = W + 6;
-    const long long total = (long long)N * Hp * Wp;
-    const long long stride = (long long)gridDim.x * blockDim.x;
-    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
-        const int xq = (int)(i % Wp);
-        const long long t = i / Wp;
-        const int yq = (int)(t % Hp);
-        const int n = (int)(t / Hp);
+    const int Cc = CIN ? CIN : C;
+    const IDX total = (IDX)((long long)N * Hp * Wp);
+    const IDX stride = (IDX)gridDim.x * (IDX)blockDim.x;
+    for (IDX i = (IDX)blockIdx.x * (IDX)blockDim.x + (IDX)threadIdx.x; i < total; i += stride) {
+        const int xq = (int)(i % (IDX)Wp);
+        const IDX t = i / (IDX)Wp;
+        const int yq = (int)(t % (IDX)Hp);
+        const int n = (int)(t / (IDX)Hp);
         const int x = xq - 3, y = yq - 3;
         const bool in = (unsigned)x < (unsigned)W && (unsigned)y < (unsigned)H;
-        XT* dst = xp + (size_t)i * C;
-        const unsigned char* src = img + ((size_t)(n * H + (in ? y : 0)) * W + (size_t)(in ? x : 0)) * C;
-        for (int c = 0; c < C; ++c) {
-            float v = 0.f;
-            if (in) {
-                v = (float)src[c] / 255.0f;        // torchvision ToTensor
-                if (nc.enabled) v = (v - nc.mean[c]) / nc.stdv[c];
-            }
-            dst[c] = (XT)v;
+        XT* dst = xp + (size_t)i * Cc;
+        const unsigned char* src = img + ((size_t)(n * H + (in ? y : 0)) * W + (size_t)(in ? x : 0)) * Cc;
+        unsigned char b[CIN ? CIN : 8];
+#pragma unroll
+        for (int c = 0; c < (CIN ? CIN : 8); ++c) b[c] = c < Cc ? src[c] : (unsigned char)0;
+#pragma unroll
+        for (int c = 0; c < (CIN ? CIN : 8); ++c) {
+            if (c >= Cc) break;
+            // selects instead of branches: the loads above stay in front, border lanes (clamped address) discard what they read
+            const float u = (float)b[c] / 255.0f;                  // torchvision ToTensor
+            const float w = (u - nc.mean[c]) / nc.stdv[c];         // (discarded, possibly inf / nan, when normalisation is off)
+            const float v = nc.enabled ? w : u;
+            dst[c] = (XT)(in ? v : 0.f);
         }
     }
 }
@@ -918,8 +926,22 @@ int lbc_prep_input_u8(const unsigned char* img_nhwc, void* xp, int xp_bf16, int 
     long long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     LbcProfScope prof("prep_input", 0.0, 1.0 * N * H * (double)W * C + (xp_bf16 ? 2.0 : 4.0) * (double)total * C, s);
-    if (xp_bf16) hipLaunchKernelGGL(prep_input_u8_k<__bf16>, dim3((unsigned)blocks), dim3(256), 0, s, img_nhwc, static_cast<__bf16*>(xp), N, C, H, W, nc);
-    else         hipLaunchKernelGGL(prep_input_u8_k<float>, dim3((unsigned)blocks), dim3(256), 0, s, img_nhwc, static_cast<float*>(xp), N, C, H, W, nc);
+    const bool small = total + blocks * 256 < (1ll << 31);
+#define LBC_PU(XT, CINv)                                                                                                                 \
+    do {                                                                                                                                 \
+        if (small) hipLaunchKernelGGL((prep_input_u8_k<XT, CINv, unsigned>), dim3((unsigned)blocks), dim3(256), 0, s, img_nhwc, static_cast<XT*>(xp), N, C, H, W, nc);  \
+        else       hipLaunchKernelGGL((prep_input_u8_k<XT, CINv, long long>), dim3((unsigned)blocks), dim3(256), 0, s, img_nhwc, static_cast<XT*>(xp), N, C, H, W, nc); \
+    } while (0)
+#define LBC_PUC(XT)                                                                                                                      \
+    do {                                                                                                                                 \
+        if (C == 3) LBC_PU(XT, 3);                                                                                                       \
+        else if (C == 7) LBC_PU(XT, 7);                                                                                                  \
+        else LBC_PU(XT, 0);                                                                                                              \
+    } while (0)
+    if (xp_bf16) LBC_PUC(__bf16);
+    else         LBC_PUC(float);
+#undef LBC_PUC
+#undef LBC_PU
     return lbc_check_launch("prep_input_u8");
 }
 
