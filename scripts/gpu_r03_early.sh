@@ -28,3 +28,9 @@ PY
 timeout 120 python scripts/bench_ops.py 256 2 fwd,dgrad > $R/early_ops_default.log 2>&1
 LBC_HDMA_EARLY=1 timeout 120 python scripts/bench_ops.py 256 2 fwd,dgrad > $R/early_ops_on.log 2>&1
 paste <(grep -E "layer|fwd|dgrad" $R/early_ops_default.log | head -40) <(grep -E "layer|fwd|dgrad" $R/early_ops_on.log | head -40) | cut -c1-220
+# 4. layer 1 (64 -> 64 channels, 2.4 ms of the step in conv3x3_c64_k): the 512 x 64 per-tap LDS-DMA shape lost to the halo kernel
+#    in round 2 (0.187 vs 0.126 ms); with read-ahead it may not (LBC_NO_HALO=1 hands layer 1 to conv_glds, cfg 4 pinned)
+timeout 100 python scripts/bench_ops.py 256 2 fwd,dgrad layer1 > $R/early_l1_halo.log 2>&1
+LBC_NO_HALO=1 LBC_NO_HDMA=1 LBC_GEMM256_CFG=4 LBC_GEMM256_MIN_TILES=1 timeout 100 python scripts/bench_ops.py 256 2 fwd,dgrad layer1 > $R/early_l1_glds.log 2>&1
+LBC_NO_HALO=1 LBC_NO_HDMA=1 LBC_GEMM256_CFG=4 LBC_GEMM256_MIN_TILES=1 LBC_HDMA_EARLY=1 timeout 100 python scripts/bench_ops.py 256 2 fwd,dgrad layer1 > $R/early_l1_glds_early.log 2>&1
+for f in early_l1_halo early_l1_glds early_l1_glds_early; do echo "== $f"; grep -E "layer1" $R/$f.log | head -6 | cut -c1-160; done
