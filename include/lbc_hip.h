@@ -103,6 +103,15 @@ int lbc_net_num_tensors(const lbc_net* net);
 /* kind: 0 = parameter (fp32), 1 = buffer fp32, 2 = buffer int64.  name = state_dict key. */
 int lbc_net_tensor_info(const lbc_net* net, int i, char* name, int name_cap, int* kind, int* ndim, int* shape4);
 size_t lbc_net_workspace_bytes(const lbc_net* net);
+/* Introspection for parity tests: where the activations of the last training-mode forward lie in the workspace (NHWC
+ * [N][H][W][C] from offset_bytes; elem_bytes 4 = f32, 2 = bf16 (precision 2), 1 = uint8).  Names follow the reference's module
+ * paths: "conv.conv1" (raw stem output), "conv.maxpool", "conv.maxpool.idx" (arg-max tap 3 r + s of MaxPool2d(3,2,1), resnet.py:106),
+ * "conv.layerL.B.conv1" / ".conv2" / ".downsample.0" (raw convolution outputs, resnet.py:41-49), "conv.layerL.B" (block output,
+ * resnet.py:51-52), "conv.layerL.B.bn1.scale" / ".shift" ([C] f32 vectors, H = W = 1: bn1 with the batch statistics folded, so that
+ * relu(bn1(.)) is positive exactly where conv1 * scale + shift > 0), "deconv.2" / ".5" / ".8" (decoder ReLU outputs, image.py:40,43,46).  A float64 checker that freezes the ReLU
+ * masks and pooling choices read from here differentiates the same piecewise-linear function as lbc_net_backward. */
+int lbc_net_num_activations(const lbc_net* net);
+int lbc_net_activation_info(const lbc_net* net, int i, char* name, int name_cap, size_t* offset_bytes, int* hwc3, int* elem_bytes);
 /* tensor_ptrs[i] / grad_ptrs[i] in lbc_net_tensor_info order; grad_ptrs may be NULL (inference only)
  * and its entries for buffers are ignored.  4-D weights must be in channels_last memory order. */
 int lbc_net_bind(lbc_net* net, void* workspace, void* const* tensor_ptrs, float* const* grad_ptrs);

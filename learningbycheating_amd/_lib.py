@@ -60,6 +60,8 @@ _SIGNATURES = {
     "lbc_net_num_tensors": (c_int, [c_void_p]),
     "lbc_net_tensor_info": (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "lbc_net_workspace_bytes": (c_size_t, [c_void_p]),
+    "lbc_net_num_activations": (c_int, [c_void_p]),
+    "lbc_net_activation_info": (c_int, [c_void_p, c_int, c_char_p, c_int, ctypes.POINTER(c_size_t), ctypes.POINTER(c_int), ctypes.POINTER(c_int)]),
     "lbc_net_bind": (c_int, [c_void_p, c_void_p, ctypes.POINTER(c_void_p), ctypes.POINTER(c_void_p)]),
     "lbc_net_forward": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),
     "lbc_net_forward_u8": (c_int, [c_void_p, c_int, c_int] + [c_void_p] * 6),

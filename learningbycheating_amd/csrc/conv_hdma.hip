@@ -34,7 +34,7 @@ namespace {
 // needs is computed in its own region.  Static picture of the default code (scripts/isa_mix.py): every step is
 // `s_waitcnt lgkmcnt(0), MFMA x3, read x2, MFMA, read x2`, i.e. the reads a step waits for were issued 0-1 MFMAs (<= 32 cycles)
 // earlier against ~64+ cycles of LDS latency, in all 8 waves at once (they leave each tap's barrier together).
-template <int BM, int BN, int WM, int WN, int HRMAX, int NBUFB, int MODE, int PRE = 0, int EARLY = 0>
+template <int BM, int BN, int WM, int WN, int HRMAX, int NBUFB, int MODE, int PRE = 0, int EARLY = 0, int DIAG = 0>
 __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
@@ -174,6 +174,15 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
             fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + bBase + j * 32 * 128 + (((2 * (G)) ^ bxor) << 4));             \
     } while (0)
+#ifdef LBC_HIP_EMULATED_FOR_TESTS
+#define LBC_KEEP(SET) do { } while (0)
+#else
+#define LBC_KEEP(SET)                                                                                                            \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" :: "v"(fa[SET][i]));                                     \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" :: "v"(fb[SET][j]));                                     \
+    } while (0)
+#endif
 #define LBC_MM(SET)                                                                                                              \
     do {                                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
@@ -287,10 +296,10 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
                     __builtin_amdgcn_sched_barrier(0);
                     continue;
                 }
-                LBC_RD(slot, g + 1, (g + 1) & 1);
+                if (!(DIAG & 2)) LBC_RD(slot, g + 1, (g + 1) & 1);
                 // the reads of the last depth step are out: the addresses are free for the next K-tile's (tap, slab)
                 if (g == KS - 2 && has_next) tap_addr(t < 8 ? t + 1 : 0, t < 8 ? c : c + 1, abase, axor);
-                LBC_MM(g & 1);
+                if (!(DIAG & 16)) LBC_MM(g & 1); else LBC_KEEP(g & 1);
 #pragma unroll
                 for (int q = 0; q < MT + NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); LBC_SG(0x002, 3); }
                 if (MT * NT > MT + NT) LBC_SG(0x008, MT * NT - (MT + NT));
@@ -306,23 +315,23 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
                 else LBC_WAIT_VM(0);
             }
             LBC_WAIT_LGKM0();
-            __builtin_amdgcn_s_barrier();
+            if (!(DIAG & 4)) __builtin_amdgcn_s_barrier();
             __builtin_amdgcn_sched_barrier(0);
             if (PRE && !LAST && t == 5) pre_coef(c + 1);                   // (before this tap's DMA issue: older in the queue)
             if constexpr (EARLY) {
                 if (has_next) { LBC_RDA(0); LBC_AD(nslot, 1); }
                 LBC_USE((KS - 1) & 1);                                     // in since the lgkmcnt(0) in front of the barrier
             } else {
-                if (has_next) LBC_RD(nslot, 0, 0);
+                if (has_next && !(DIAG & 2)) LBC_RD(nslot, 0, 0);
             }
-            LBC_MM((KS - 1) & 1);
+            if (!(DIAG & 16)) LBC_MM((KS - 1) & 1); else LBC_KEEP((KS - 1) & 1);
             if (PRE && !LAST && t == 6) pre_apply(c + 1);                  // landed and visible since the barrier above; the barriers of
                                                                            // taps 7 and 8 (after lgkmcnt(0)) publish the rewrite
-            if (!LAST || t + NBUFB < 9) {
+            if (!(DIAG & 1) && (!LAST || t + NBUFB < 9)) {
                 const int kn = t + NBUFB;                                  // K-tile k + NBUFB -> the ring slot of K-tile k
                 issue_b(kn < 9 ? c : c + 1, kn < 9 ? kn : kn - 9, slot);
             }
-            if (!LAST && t < ATAPS && t * AP < HPW) issue_a(c + 1, t * AP, (t + 1) * AP < HPW ? (t + 1) * AP : HPW);
+            if (!(DIAG & 1) && !LAST && t < ATAPS && t * AP < HPW) issue_a(c + 1, t * AP, (t + 1) * AP < HPW ? (t + 1) * AP : HPW);
             if (EARLY && has_next) LBC_SG(0x100, MT + NT);
 #pragma unroll
             for (int q = 0; q < MT * NT; ++q) {
@@ -337,12 +346,23 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
     slab_body(nslab - 1, std::true_type{});
 #undef LBC_RD
 #undef LBC_MM
+#undef LBC_KEEP
 #undef LBC_AD
 #undef LBC_RDA
 #undef LBC_USE
 #undef LBC_WAIT_OLDER_READS
 
     // ---- epilogue (conv_lds_dma.hpp)
+    if constexpr (DIAG & 8) {
+        float t = 0.f;
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) t += acc[i][j][r];
+        if (t == 123.456f) static_cast<__bf16*>(a.y)[tid] = (__bf16)t;
+    } else
     lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, mtile);
 }
 #undef LBC_SG
@@ -621,6 +641,23 @@ int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     }
     const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
     const bool early = lbc_opt_on(kOptHdmaEarly);
+    const long long diag = lbc_opt(kOptHdmaDiag);
+    if (diag > 0 && mode == 0 && !a.pre_scale && cfg == kLbcCfgHdma + 1) {     // timing experiments (wrong results)
+#define LBC_HDD(D) case D: hipLaunchKernelGGL((conv_hdma_k<256, 128, 4, 2, 384, 4, 0, 0, 0, D>), grid, dim3(512), 0, s, a, zero); return lbc_check_launch("conv_hdma")
+        switch (diag) {
+            LBC_HDD(1); LBC_HDD(2); LBC_HDD(8); LBC_HDD(16); LBC_HDD(15);
+            default: break;
+        }
+#undef LBC_HDD
+    }
+    if (diag > 0 && mode == 0 && !a.pre_scale && cfg == kLbcCfgHdma + 0) {
+#define LBC_HDD(D) case D: hipLaunchKernelGGL((conv_hdma_k<256, 256, 2, 4, 320, 2, 0, 0, 0, D>), grid, dim3(512), 0, s, a, zero); return lbc_check_launch("conv_hdma")
+        switch (diag) {
+            LBC_HDD(1); LBC_HDD(2); LBC_HDD(8); LBC_HDD(16); LBC_HDD(15);
+            default: break;
+        }
+#undef LBC_HDD
+    }
 #define LBC_HD(BMv, BNv, WMv, WNv, HRv, NBv)                                                                                 \
     do {                                                                                                                     \
         if (mode == 0 && a.pre_scale) hipLaunchKernelGGL((conv_hdma_k<BMv, BNv, WMv, WNv, HRv, NBv, 0, 1>), grid, dim3(512), 0, s, a, zero); \

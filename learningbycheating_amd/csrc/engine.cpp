@@ -194,6 +194,32 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     g0_ = alloc_act(NB * (H0 / 2) * (W0 / 2) * 64);
 }
 
+std::vector<Net::ActInfo> Net::activations() const
+{
+    std::vector<ActInfo> v;
+    const int ae = act_bf16_ ? 2 : 4;
+    auto add = [&](const std::string& name, size_t off_floats, int H, int W, int C, int elem) {
+        v.push_back(ActInfo{name, off_floats * sizeof(float), H, W, C, elem});
+    };
+    add("conv.conv1", y0_, d_.H / 2, d_.W / 2, 64, ae);                       // raw stem output (pre-BN)
+    add("conv.maxpool", p0_, H1_, W1_, 64, ae);                               // maxpool(relu(bn1(.)))
+    add("conv.maxpool.idx", idx_, H1_, W1_, 64, 1);                           // arg-max tap 3 r + s: input pixel (2 oy - 1 + r, 2 ox - 1 + s)
+    int li = 0;
+    for (size_t i = 0; i < blocks_.size(); ++i) {
+        while (li + 1 < (int)stage_first_block_.size() && (int)i >= stage_first_block_[li + 1]) ++li;
+        const Block& b = blocks_[i];
+        const std::string p = "conv.layer" + std::to_string(li + 1) + "." + std::to_string((int)i - stage_first_block_[li]);
+        add(p + ".conv1", b.c1.y, b.c1.OH, b.c1.OW, b.c1.Cout, ae);           // raw conv outputs (pre-BN)
+        add(p + ".bn1.scale", b.b1.scale, 1, 1, b.b1.C, 4);                   // z1 = relu(conv1 * scale + shift) (batch statistics folded)
+        add(p + ".bn1.shift", b.b1.shift, 1, 1, b.b1.C, 4);
+        add(p + ".conv2", b.c2.y, b.c2.OH, b.c2.OW, b.c2.Cout, ae);
+        if (b.has_ds) add(p + ".downsample.0", b.ds.y, b.ds.OH, b.ds.OW, b.ds.Cout, ae);
+        add(p, b.out, b.c2.OH, b.c2.OW, b.c2.Cout, ae);                       // block output relu(bn2(.) + identity)
+    }
+    for (int i = 0; i < 3; ++i) add("deconv." + std::to_string(3 * i + 2), dec_[i].u, 2 * dec_[i].H, 2 * dec_[i].W, dec_[i].Cout, ae);
+    return v;
+}
+
 Net::~Net()
 {
     if (side_) (void)hipStreamDestroy(side_);
@@ -909,6 +935,19 @@ int lbc_net_tensor_info(const lbc_net* net, int i, char* name, int name_cap, int
     return LBC_OK;
 }
 size_t lbc_net_workspace_bytes(const lbc_net* net) { return net ? net->impl.workspace_bytes() : 0; }
+int lbc_net_num_activations(const lbc_net* net) { return net ? (int)net->impl.activations().size() : 0; }
+int lbc_net_activation_info(const lbc_net* net, int i, char* name, int name_cap, size_t* offset_bytes, int* hwc3, int* elem_bytes)
+{
+    LBC_REQUIRE(net, "activation_info: null net");
+    const auto acts = net->impl.activations();
+    LBC_REQUIRE(i >= 0 && i < (int)acts.size(), "activation_info: index %d out of range", i);
+    const auto& a = acts[(size_t)i];
+    if (name && name_cap > 0) { strncpy(name, a.name.c_str(), (size_t)name_cap - 1); name[name_cap - 1] = 0; }
+    if (offset_bytes) *offset_bytes = a.offset_bytes;
+    if (hwc3) { hwc3[0] = a.H; hwc3[1] = a.W; hwc3[2] = a.C; }
+    if (elem_bytes) *elem_bytes = a.elem;
+    return LBC_OK;
+}
 int lbc_net_bind(lbc_net* net, void* workspace, void* const* tensor_ptrs, float* const* grad_ptrs)
 {
     LBC_REQUIRE(net && workspace && tensor_ptrs, "net_bind: null argument");

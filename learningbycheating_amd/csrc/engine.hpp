@@ -75,6 +75,11 @@ public:
     // stage: -1 = everything; otherwise 0 = head+decoder, 1..4 = layer4..layer1, 5 = stem (call in order)
     int backward(const float* d_sel, const float* d_all, int stage, hipStream_t s);
     static const int kNumStages = 6;
+    // Activations of the last training-mode forward as they lie in the workspace (introspection for parity tests: the masks a
+    // float64 checker must freeze to differentiate the same piecewise-linear function).  NHWC [max_batch rows used: N][H][W][C];
+    // elem: 4 = f32, 2 = bf16 (precision 2), 1 = uint8 (max-pool arg-max taps)
+    struct ActInfo { std::string name; size_t offset_bytes; int H, W, C, elem; };
+    std::vector<ActInfo> activations() const;
     // what backward() would differentiate: batch size and mode of the last forward, and how many forwards ran before it
     int last_batch() const { return lastN_; }
     int last_train() const { return last_train_; }

@@ -58,6 +58,7 @@ enum LbcOpt {
     kOptNoGldsPhased,      // LBC_NO_GLDS_PHASED: 1 = the stride-2 transposed launches keep conv_igemm.hip
     kOptHdmaPrologue,      // LBC_HDMA_PROLOGUE: 1 = conv_hdma.hip takes forward launches with BatchNorm-on-load (in-LDS transform of the halo)
     kOptHdmaEarly,         // LBC_HDMA_EARLY: 1 = conv_hdma.hip issues each depth step's fragment reads a full step ahead (not yet measured)
+    kOptHdmaDiag,          // LBC_HDMA_DIAG: timing experiments on conv_hdma.hip (bit mask of parts left out; wrong results)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

@@ -151,6 +151,24 @@ class PolicyEngine:
                                    % (name, shape, self.workspace.device, self.last_batch, t.dtype, tuple(t.shape), t.device))
         _lib.check(_lib.get().lbc_net_backward(self.handle, _lib.ptr(d_sel), _lib.ptr(d_all), stage, _lib.stream_for(ref)), "net_backward")
 
+    # ---- introspection (parity tests) ------------------------------------------------------
+    def activations(self):
+        """{name: tensor view} of the activations the last training-mode forward left in the workspace (lbc_net_activation_info):
+        (N, H, W, C) views in the stored element type (float32, bfloat16 in precision 2, uint8 for the max-pool arg-max taps)."""
+        lib = _lib.get()
+        out = {}
+        buf = ctypes.create_string_buffer(256)
+        off, hwc, eb = ctypes.c_size_t(), (ctypes.c_int * 3)(), ctypes.c_int()
+        n = self.last_batch
+        for i in range(lib.lbc_net_num_activations(self.handle)):
+            _lib.check(lib.lbc_net_activation_info(self.handle, i, buf, 256, ctypes.byref(off), hwc, ctypes.byref(eb)), "activation_info")
+            dt = {4: torch.float32, 2: torch.bfloat16, 1: torch.uint8}[eb.value]
+            rows = 1 if (hwc[0] == 1 and hwc[1] == 1) else n          # per-channel vectors ("...bn1.scale") have no batch axis
+            numel = rows * hwc[0] * hwc[1] * hwc[2]
+            raw = self.workspace[off.value: off.value + numel * eb.value]
+            out[buf.value.decode()] = raw.view(dt).view(rows, hwc[0], hwc[1], hwc[2])
+        return out
+
     # ---- synchronized BatchNorm (data parallelism) ---------------------------------------
     def set_sync_bn(self, group=None, enable=True, native=None):
         """Every training-mode BatchNorm uses the statistics of the global batch (lbc_net_set_sync_bn): before each finalize

@@ -209,11 +209,30 @@ def calibrate_running_stats(sd, kind, backbone, x, velocity, command):
     return sd
 
 
-def trunk(sd, backbone, x, train, taps=None):
+def _relu(x, frozen, key):
+    """nn.ReLU -- or, with `frozen` masks, the linear map the implementation under test applied at this site"""
+    return F.relu(x) if frozen is None else x * frozen[key].to(x.dtype)
+
+
+def _relu_maxpool(x, frozen):
+    """relu -> MaxPool2d(3, 2, 1) (resnet.py:150-152).  Frozen: out[n,c,oy,ox] = x[n,c,iy,ix] * positive[n,c,oy,ox] with the window
+    element (iy, ix) = (2 oy - 1 + tap // 3, 2 ox - 1 + tap % 3) chosen by frozen["conv.maxpool.idx"] (relu and max commute)."""
+    if frozen is None:
+        return F.max_pool2d(F.relu(x), 3, 2, 1)
+    tap = frozen["conv.maxpool.idx"].long()
+    n, c, oh, ow = tap.shape
+    oy = torch.arange(oh).view(1, 1, oh, 1)
+    ox = torch.arange(ow).view(1, 1, 1, ow)
+    iy, ix = 2 * oy - 1 + tap // 3, 2 * ox - 1 + tap % 3
+    assert int(iy.min()) >= 0 and int(ix.min()) >= 0 and int(iy.max()) < x.shape[2] and int(ix.max()) < x.shape[3]
+    picked = torch.gather(x.reshape(n, c, -1), 2, (iy * x.shape[3] + ix).reshape(n, c, -1)).reshape(n, c, oh, ow)
+    return picked * frozen["conv.maxpool"].to(x.dtype)
+
+
+def trunk(sd, backbone, x, train, taps=None, frozen=None):
     """ResNet.forward (resnet.py:148-159) with BasicBlock.forward (resnet.py:38-54)."""
     x = _st(_conv(x, sd["conv.conv1.weight"], None, 2, 3))
-    x = F.relu(_bn(sd, "conv.bn1", x, train))
-    x = _st(F.max_pool2d(x, 3, 2, 1))
+    x = _st(_relu_maxpool(_bn(sd, "conv.bn1", x, train), frozen))
     if taps is not None:
         taps["pool"] = x
     inpl = 64
@@ -224,12 +243,12 @@ def trunk(sd, backbone, x, train, taps=None):
             stride = 2 if (li > 0 and bi == 0) else 1
             identity = x
             out = _st(_conv(x, sd[p + ".conv1.weight"], None, stride, 1))
-            out = F.relu(_bn(sd, p + ".bn1", out, train))
+            out = _relu(_bn(sd, p + ".bn1", out, train), frozen, p + ".bn1")
             out = _st(_conv(out, sd[p + ".conv2.weight"], None, 1, 1))
             out = _bn(sd, p + ".bn2", out, train)
             if stride != 1 or inpl != planes:
                 identity = _bn(sd, p + ".downsample.1", _st(_conv(x, sd[p + ".downsample.0.weight"], None, stride, 0)), train)
-            x = _st(F.relu(out + identity))
+            x = _st(_relu(out + identity, frozen, p))
             inpl = planes
         if taps is not None:
             taps["layer%d" % (li + 1)] = x
@@ -239,6 +258,8 @@ def trunk(sd, backbone, x, train, taps=None):
 def spatial_softmax(feature, pos_x, pos_y):
     """SpatialSoftmax.forward (common.py:136-152), data_format NCHW, temperature 1."""
     n, c, h, w = feature.shape
+    if feature.dtype == torch.bfloat16:      # only under the autocast comparator of the tests: CUDA autocast runs softmax in float32
+        feature = feature.float()
     weight = F.softmax(feature.reshape(-1, h * w), dim=-1)
     ex = torch.sum(pos_x * weight, dim=1, keepdim=True)
     ey = torch.sum(pos_y * weight, dim=1, keepdim=True)
@@ -250,21 +271,27 @@ def select_branch(branches, one_hot):
     return torch.sum(one_hot[:, :, None, None] * branches, dim=1)
 
 
-def policy_forward(sd, kind, backbone, x, velocity, command, train, taps=None):
+def policy_forward(sd, kind, backbone, x, velocity, command, train, taps=None, frozen=None):
     """ImagePolicyModelSS.forward (image.py:64-89) / BirdViewPolicyModelSS.forward (birdview.py:62-79).
-    Returns (location_pred (N,5,2), location_preds (N,4,5,2))."""
+    Returns (location_pred (N,5,2), location_preds (N,4,5,2)).
+
+    frozen (test device, not in the reference): {site: 0/1 mask (N,C,H,W)} for every ReLU ("conv.layerL.B.bn1", "conv.layerL.B",
+    "deconv.2/5/8") plus "conv.maxpool" (positive mask of the pooled map) and "conv.maxpool.idx" (chosen window tap) -- the
+    branch decisions of an implementation under test.  The network is piecewise linear in its activations; with the decisions
+    frozen, this function and that implementation differentiate the SAME smooth function, so their gradients may be compared
+    at round-off level instead of "up to the occasional kink flip" (tests/test_model.py::_frozen_gradient_check)."""
     if kind == "image":
         mean = torch.tensor([0.485, 0.456, 0.406]).view(1, 3, 1, 1)
         std = torch.tensor([0.229, 0.224, 0.225]).view(1, 3, 1, 1)
         x = (x - mean) / std                                                     # common.py:108-109
-    h = trunk(sd, backbone, x, train, taps)
+    h = trunk(sd, backbone, x, train, taps, frozen)
     b, c, kh, kw = h.shape
     vel = velocity[..., None, None, None].repeat((1, 128, kh, kw))              # image.py:77
     h = _st(torch.cat((h, vel), dim=1))
     for i in range(3):                                                          # image.py:37-47
         h = _bn(sd, "deconv.%d" % (3 * i), h, train)
         h = _deconv(h, sd["deconv.%d.weight" % (3 * i + 1)], sd["deconv.%d.bias" % (3 * i + 1)])
-        h = _st(F.relu(h))
+        h = _st(_relu(h, frozen, "deconv.%d" % (3 * i + 2)))
     if taps is not None:
         taps["decoder"] = h
     preds = []

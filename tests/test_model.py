@@ -144,6 +144,97 @@ def _fwd_bwd_check(dev, kind, backbone, h, w, n, fwd_tol, grad_tol, calibrated=T
     return es[-1]
 
 
+def frozen_decisions(eng):
+    """The branch decisions of the executor's last training-mode forward, read back from its workspace (lbc_net_activation_info):
+    {site: 0/1 mask in NCHW} for every ReLU, the positive mask and chosen window tap of the fused relu + max-pool -- the
+    `frozen` argument of oracle.policy_forward."""
+    acts = eng.activations()
+    to = lambda t: t.permute(0, 3, 1, 2).cpu()
+    fz = {"conv.maxpool": to(acts["conv.maxpool"]).float() > 0, "conv.maxpool.idx": to(acts["conv.maxpool.idx"])}
+    for name, t in acts.items():
+        if name.endswith(".conv1") and name != "conv.conv1":
+            p = name[:-len(".conv1")]
+            sc, sh = acts[p + ".bn1.scale"].reshape(1, -1, 1, 1).cpu(), acts[p + ".bn1.shift"].reshape(1, -1, 1, 1).cpu()
+            # the executor evaluates relu(y1 * scale + shift) on the STORED y1 in float32 -- on gfx950 as one fused multiply-add
+            # (in float64 the product of two floats is exact, so the sign of the float64 sum is the sign of the fma), under the CPU
+            # emulator (x86-64 without FMA contraction) as a rounded product plus a rounded sum, like torch's float32 ops.  One
+            # element whose |z| ~ 1e-9 decides differently between the two moves layer-1 bias gradients by 7e-3 at test sizes.
+            y1 = to(t).float()
+            fz[p + ".bn1"] = ((y1.double() * sc.double() + sh.double()) > 0) if eng.workspace.device.type == "cuda" else ((y1 * sc + sh) > 0)
+            fz[p] = to(acts[p]).float() > 0
+        elif name.startswith("deconv."):
+            fz[name] = to(t).float() > 0
+    return fz
+
+
+def _frozen_gradient_check(dev, kind, backbone, h, w, n, precision, tol, head_tol=None, seed=3):
+    """Gradient parity with the branch decisions frozen.  The float64 oracle is run with the ReLU masks and max-pool choices
+    the executor's own forward took (frozen_decisions), so both sides differentiate the SAME piecewise-linear function and the
+    comparison is not blurred by kink flips (two float32 evaluations of a 34-layer ReLU network take different branches for a
+    few of ~1e8 elements; each flip moves rel-to-max gradient entries by 1e-3..1e-2).  A mis-scaled term in any of the
+    BatchNorm / convolution / pooling backward kernels shows up as an O(1e-2..1) error in the tensors upstream of it.
+    Returns the sorted per-tensor errors (max |g - g64| / max |g64|)."""
+    sd = O.make_state_dict(kind, backbone, seed, h, w)
+    x, speed, cmd = _inputs(kind, n, h, w, seed + 1)
+    O.calibrate_running_stats(sd, kind, backbone, x, speed, cmd)
+    eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
+    ps, pa = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
+    fz = frozen_decisions(eng)           # (before the backward pass reuses any buffer)
+    g = torch.Generator().manual_seed(seed + 2)
+    d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g), torch.randn((n, 5, 2), generator=g)
+    eng.backward(d_sel.to(dev), d_all.to(dev))
+    sp = O.as_params({k: (v.double() if v.dtype.is_floating_point else v.clone()) for k, v in sd.items()})
+    # precision 2: the float64 oracle also rounds where the executor rounds (MFMA operands and stored activations / activation
+    # gradients to bf16, oracle flags MFMA_BF16 / ACT_BF16) -- same decisions, same rounding points, float64 in between
+    O.MFMA_BF16 = O.ACT_BF16 = (precision == 2)
+    try:
+        ops, opa = O.policy_forward(sp, kind, backbone, x.double(), speed.double(), cmd.double(), True, frozen=fz)
+        ((opa * d_all.double()).sum() + (ops * d_sel.double()).sum()).backward()
+    finally:
+        O.MFMA_BF16 = O.ACT_BF16 = False
+    fwd = max((pa.cpu().double() - opa.detach()).abs().max().item(), (ps.cpu().double() - ops.detach()).abs().max().item())
+    errs = []
+    for k, v in eng.grad_views.items():
+        ref = sp[k].grad
+        if k.startswith("location_pred") and k.endswith("bias"):
+            # analytically zero (a per-channel offset cancels in the softmax, SURVEY appendix B.2): absolute check
+            assert v.abs().max().item() < 1e-4 * max(1.0, float(d_all.abs().max())), (k, v.abs().max().item())
+            continue
+        errs.append((relerr(v.cpu().double(), ref), k))
+    errs.sort()
+    es = [e for e, _ in errs]
+    _diag(dev, "frozen-decision gradient check, precision %d %s %s %dx%d N=%d: forward |pred - frozen float64 oracle| %.2e; gradients "
+               "rel-to-max over %d tensors: median %.2e p90 %.2e max %.2e (%s)"
+          % (precision, kind, backbone, h, w, n, fwd, len(es), es[len(es) // 2], es[int(len(es) * 0.9)], es[-1], errs[-1][1]))
+    for e, k in errs:
+        t = head_tol if (head_tol is not None and k.startswith("location_pred")) else tol
+        assert e < t, ("frozen-decision gradient", k, e, t)
+    return es
+
+
+@pytest.mark.parametrize("precision,tol", [(0, 1e-4), (2, 0.35)])
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("birdview", "resnet18", 64, 64, 4), ("image", "resnet18", 32, 64, 5)])
+def test_gradients_with_frozen_decisions_emulated(env, kind, backbone, h, w, n, precision, tol):
+    """exact-f32 path: every gradient within 1e-4 rel-to-max of the float64 oracle (measured 2.5e-5).  bf16 path at these sizes
+    (2 x 2 maps in layer 4, BatchNorm over 16 values, an untrained network): two bf16 evaluations with the same rounding points
+    already differ by 7e-2 in the waypoints (torch's own bf16 autocast of the oracle: 8e-2), so the bound only catches wiring
+    errors here; the full-size bound is asserted on the GPU."""
+    dev, _ = env
+    _frozen_gradient_check(dev, kind, backbone, h, w, n, precision, tol)
+
+
+@gpu
+@pytest.mark.parametrize("precision,tol", [(0, 1e-4), (2, 2e-2)])
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet34", 160, 384, 4), ("image", "resnet34", 160, 384, 32),
+                                                 ("birdview", "resnet18", 192, 192, 4)])
+def test_gradients_with_frozen_decisions_full_size(env, kind, backbone, h, w, n, precision, tol):
+    """all 136 (r34) / 72 (r18) parameter gradients of the reference-sized networks vs the float64 oracle on the executor's own
+    branch decisions: <= 1e-4 rel-to-max per tensor on the exact-f32 path, <= 2e-2 on the bf16 path (SURVEY appendix C asks 1e-3
+    without freezing, which no float32 implementation -- torch-CPU included -- can meet: see _fwd_bwd_check)."""
+    dev, _ = env
+    _frozen_gradient_check(dev, kind, backbone, h, w, n, precision, tol)
+
+
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("birdview", "resnet18", 64, 64, 4), ("image", "resnet18", 32, 64, 5)])
 def test_engine_small_emulated(env, kind, backbone, h, w, n):
     dev, _ = env
@@ -572,10 +663,12 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, lbc_conf
 def test_bf16_mode_declared_accuracy(env):
     """The shipped mixed-precision mode (bench default, BASELINE.json config 3) on a trained-like network: the student is
     warm-started exactly as bench.py does it (L1 steps towards below-horizon targets, f32), then
-      (1) eval- and training-mode waypoints of the bf16 executor stay within WAYPOINT_TOLERANCE['bf16'] (max 3e-2, mean 4e-3)
-          of the f32 executor on the same weights -- and the f32 executor within 1e-4 of the f32 oracle;
-      (2) training from that checkpoint in f32 and in bf16 follows the same loss curve: 50 steps of the warm start's L1 objective
-          and the first 25 steps of the phase-1 objective, every step within 10 %."""
+      (1) eval- and training-mode waypoints of the bf16 executor stay within WAYPOINT_TOLERANCE['bf16'] of the f32 executor on the
+          same weights, the f32 executor within 1e-4 of the f32 oracle, and the bf16 executor deviates from f32 no more than
+          the oracle does under torch's own bf16 autocast (the reference run the way BASELINE.json config 3 would run it: bf16
+          convolutions and activations, f32 BatchNorm statistics / softmax) -- i.e. the mode is as accurate as the reference in bf16;
+      (2) training from that checkpoint follows the f32 loss curve as closely as an f32 run whose INPUT is perturbed by 1e-3
+          does: 50 steps of the warm start's L1 objective (every step within 10 %) and 200 steps of the phase-1 objective."""
     import learningbycheating_amd as pkg
     from learningbycheating_amd.bird_view.models import ImagePolicyModelSS, BirdViewPolicyModelSS
     from learningbycheating_amd.training.native import NativeTrainer
@@ -620,41 +713,64 @@ def test_bf16_mode_declared_accuracy(env):
     for train in (False, True):
         with torch.no_grad():
             _, oa = O.policy_forward({k: v.clone() for k, v in ckpt.items()}, "image", "resnet34", x2, s2, oh2, train)
+            with torch.autocast("cpu", dtype=torch.bfloat16):
+                _, oc = O.policy_forward({k: v.clone() for k, v in ckpt.items()}, "image", "resnet34", x2, s2, oh2, train)
         e32 = (outs[("fp32", train)] - oa).abs().max().item()
         d = (outs[("bf16", train)] - outs[("fp32", train)]).abs()
-        _diag(dev, "bf16 vs f32 executor, warm-started r34 N=%d train=%s: |dwaypoint| max %.3e mean %.3e (bound %.0e); f32 executor vs f32 oracle max %.2e"
-              % (n, train, d.max().item(), d.mean().item(), tol, e32))
+        dc = (oc.float() - oa).abs()
+        _diag(dev, "bf16 vs f32 executor, warm-started r34 N=%d train=%s: |dwaypoint| max %.3e mean %.3e (bound %.0e); the oracle under torch "
+                   "bf16 autocast vs its own f32: max %.3e mean %.3e; f32 executor vs f32 oracle max %.2e"
+              % (n, train, d.max().item(), d.mean().item(), tol, dc.max().item(), dc.mean().item(), e32))
         assert e32 < 1e-4, e32
         assert d.max().item() <= tol and d.mean().item() <= pkg.WAYPOINT_MEAN_TOLERANCE["bf16"], ("bf16 waypoint deviation", train, d.max().item(), d.mean().item())
-    # (2) loss curves from the common checkpoint, same data every step.  (a) the warm start's own objective (L1 towards
-    # below-horizon targets in camera space: well conditioned) for 50 steps; (b) the phase-1 objective for its first 25 steps.
-    # Phase 1 unprojects with 1/y (train_image_phase1.py:43-64): once training has pulled the far waypoints towards the horizon
-    # (y ~ 0.08, d map_y / d y ~ 27) the bf16 forward's ~1e-2 waypoint noise is amplified into loss spikes that the f32 run does not
-    # have (measured: the two curves agree within 3 % for 31 steps, then bf16 spikes to 5.7 and recovers) -- a property of that
-    # loss on this synthetic teacher, documented in DESIGN.md; the comparison stops before it.
+        # as accurate as the reference under bf16 autocast (mean deviation: the max over 1280 coordinates is a noisy statistic)
+        assert d.mean().item() <= 1.5 * dc.mean().item() + 5e-4, ("bf16 executor vs autocast oracle", train, d.mean().item(), dc.mean().item())
+    # (2) loss curves from the common checkpoint, same data every step.  (a) the warm start's own objective (L1 towards below-horizon
+    # targets in camera space: well conditioned) for 50 steps: every step within 10 %.  (b) the phase-1 objective for 200 steps.  Phase 1
+    # unprojects with 1/y (train_image_phase1.py:43-64); on this synthetic teacher training drives far waypoints to the horizon
+    # (y -> 0.05) and around step 32 the trajectory bifurcates: ANY rounding-sized perturbation decides which way it goes -- the f32
+    # executor fed rgb + 1e-3 * U(-1, 1) leaves the unperturbed f32 curve at step 32 (by up to 6x), exactly where the bf16 run leaves it
+    # (profiles/r03_run2_bf16_curves.*, scripts/diag_bf16_curve.py).  So the yardstick for "bf16 follows f32" after that point is that
+    # control: same departure step, same loss level, no spike the control does not have.
+    noise = (torch.rand(rgb.shape, generator=torch.Generator().manual_seed(47)) * 2 - 1).to(dev) * 1e-3
+    steps_b = 200
     curves = {}
-    for prec in ("fp32", "bf16"):
-        m = fresh(prec)
-        tr = NativeTrainer(m, None, n, (3, 160, 384), dev, phase="l1_all", lr=1e-4)
-        ca = torch.stack([tr.step(rgb, speed, onehot, target=tgt.to(dev)).mean() for _ in range(50)]).cpu()
-        del tr
+    for arm, prec, x in (("fp32", "fp32", rgb), ("fp32_eps", "fp32", (rgb + noise).clamp(0, 1)), ("bf16", "bf16", rgb)):
+        ca = None
+        if arm != "fp32_eps":
+            m = fresh(prec)
+            tr = NativeTrainer(m, None, n, (3, 160, 384), dev, phase="l1_all", lr=1e-4)
+            ca = torch.stack([tr.step(rgb, speed, onehot, target=tgt.to(dev)).mean() for _ in range(50)]).cpu()
+            del tr
         m = fresh(prec)
         t = BirdViewPolicyModelSS("resnet18", all_branch=True)
         t.load_state_dict(teacher.state_dict())
         t.precision = prec
         t.to(dev)
         tr = NativeTrainer(m, t, n, (3, 160, 384), dev, phase=1, lr=1e-4)
-        cb = torch.stack([tr.step(rgb, speed, onehot, birdview=bv).mean() for _ in range(25)]).cpu()
+        cb = torch.stack([tr.step(x, speed, onehot, birdview=bv).mean() for _ in range(steps_b)]).cpu()
         del tr
-        curves[prec] = (ca, cb)
-    for name, k in (("warm-start L1 objective, 50 steps", 0), ("phase-1 objective, 25 steps", 1)):
-        a, b = curves["fp32"][k], curves["bf16"][k]
-        rel = ((a - b).abs() / a.abs().clamp_min(1e-6)).max().item()
-        _diag(dev, "%s from the warm start: f32 first/last %.4f/%.4f, bf16 %.4f/%.4f; max relative per-step difference %.3f"
-              % (name, a[0], a[-1], b[0], b[-1], rel))
-        assert torch.isfinite(a).all() and torch.isfinite(b).all()
-        assert rel < 0.10, (name, rel)
-        assert a[-5:].mean() < a[:5].mean() and b[-5:].mean() < b[:5].mean()     # both descend
+        curves[arm] = (ca, cb)
+    a, b = curves["fp32"][0], curves["bf16"][0]
+    rel = ((a - b).abs() / a.abs().clamp_min(1e-6)).max().item()
+    _diag(dev, "warm-start L1 objective, 50 steps from the warm start: f32 first/last %.4f/%.4f, bf16 %.4f/%.4f; max relative per-step difference %.3f"
+          % (a[0], a[-1], b[0], b[-1], rel))
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and rel < 0.10, rel
+    assert a[-5:].mean() < a[:5].mean() and b[-5:].mean() < b[:5].mean()
+    f, c, h = curves["fp32"][1], curves["fp32_eps"][1], curves["bf16"][1]
+    assert torch.isfinite(f).all() and torch.isfinite(c).all() and torch.isfinite(h).all()
+
+    def departs(x):        # first step more than 10 % away from the f32 curve
+        bad = ((x - f).abs() / f.abs().clamp_min(1e-6) > 0.10).nonzero()
+        return int(bad[0]) if len(bad) else steps_b
+    t_c, t_h = departs(c), departs(h)
+    tail = lambda x: x[-50:].median().item()
+    _diag(dev, "phase-1 objective, %d steps from the warm start: f32 %.4f -> %.4f (median of the last 50), f32 with 1e-3 input noise -> %.4f, bf16 -> %.4f; "
+               "first step > 10 %% off the f32 curve: control %d, bf16 %d; largest step loss after step 30: f32 %.3f control %.3f bf16 %.3f"
+          % (steps_b, f[0], tail(f), tail(c), tail(h), t_c, t_h, f[30:].max(), c[30:].max(), h[30:].max()))
+    assert t_h >= min(t_c, 25) - 3, ("bf16 leaves the f32 curve earlier than a 1e-3 input perturbation does", t_h, t_c)
+    assert h[30:].max().item() <= 2.0 * max(f[30:].max().item(), c[30:].max().item()), "loss spike that neither f32 run has"
+    assert tail(h) <= 3.0 * max(tail(f), tail(c)) and tail(h) < 0.2 * h[:5].mean().item(), ("bf16 does not reach the f32 loss level", tail(h), tail(f), tail(c))
 
 
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])
