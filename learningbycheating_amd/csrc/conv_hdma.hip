@@ -641,6 +641,7 @@ int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     }
     const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
     const bool early = lbc_opt_on(kOptHdmaEarly);
+    if (!early && lbc_opt(kOptHdmaDiag) <= 0 && lbc_conv_hdmap_eligible(a, mode, cfg)) return lbc_conv_hdmap_launch(a, mode, cfg, s);
     const long long diag = lbc_opt(kOptHdmaDiag);
     if (diag > 0 && mode == 0 && !a.pre_scale && cfg == kLbcCfgHdma + 1) {     // timing experiments (wrong results)
 #define LBC_HDD(D) case D: hipLaunchKernelGGL((conv_hdma_k<256, 128, 4, 2, 384, 4, 0, 0, 0, D>), grid, dim3(512), 0, s, a, zero); return lbc_check_launch("conv_hdma")

@@ -1,0 +1,431 @@
+// PERSISTENT form of the halo-staged LDS-DMA convolution (conv_hdma.hip explains the staging): 3x3 / stride-1 / pad-1 forward and
+// input gradient on bf16 tensors, reference arithmetic bird_view/models/resnet.py:15-22,38-54 (BasicBlock conv1 / conv2) and autograd.
+//
+// Why (round-3 ablations of conv_hdma_k on the layer-3 shape at batch 256, profiles/r03_run2_hdma_ablation.log, r03_run3_hdma_pmc_ablation.log):
+// MFMA-only 45 us, everything-but-MFMA 45 us, together 72 us.  The workgroups of a launch run in lock-step rounds (one per CU, 160 KB of
+// LDS): every round opens with all 256 CUs fetching their first halo + weight tiles at once (14 MB, no MFMA can run) and closes with all
+// of them storing their output tiles at once (16 MB, the workgroup cannot retire before its stores have), plus two workgroup-wide
+// barriers and 64 two-byte LDS writes per lane in the copy-out.  That is ~7 us of HBM bursts per round in a 36 us round.  Here
+//   * a workgroup walks `tpw` consecutive output tiles (same M-tile first: the second tile's halo comes from L2) as ONE continuous
+//     stream of K-tiles: the halo of the next tile's first slab and its first two weight tiles are requested during the last slab
+//     of the current tile (DMA roles are recomputed per piece from the tile origin: no per-tile address arrays);
+//   * the epilogue is WAVE-PRIVATE: each wave stages 16 rows x 64 columns of its own accumulators in 2.3 KB of LDS that belongs to
+//     nothing else (not the halo buffers, not the weight ring: both already hold the next tile), reads them back as 16-byte chunks
+//     and stores them -- no barrier, and the stores stay in flight under the next tile's K-tiles (vmcnt retires in order on gfx950:
+//     the first K-tile of the next tile waits with vmcnt(#stores), i.e. for the DMA pieces issued BEFORE the stores only);
+//   * statistics rows / the fused BatchNorm-backward sums go through a small [WM][2][BN] LDS array and one barrier per tile.
+// Ring depth NB = 3 weight tiles where LDS allows (slot = tap % 3: a compile-time constant, since 9 taps per slab), else 2 (slot =
+// parity of the running K-tile count).  Every K-tile waits with a counted vmcnt for its successor's weight tile: what this wave
+// requested after that tile (one halo piece + the weight tile after it, the previous tile's stores) stays in flight.
+#pragma once
+#include "lbc_common.hpp"
+#include "lbc_act.hpp"
+#include "conv_lds_dma.hpp"
+
+namespace {
+
+#define LBC_SG(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
+
+// EPI: 0 = plain epilogue (affine / bias / ReLU / statistics), 1 = + residual, 2 = fused BatchNorm-backward reduce (IgemmArgs::bnb_*).
+// One instantiation per form: the residual prefetch (64 registers) and the BatchNorm-backward operands (64) never coexist.
+template <int BM, int BN, int WM, int WN, int HRMAX, int NB, int MODE, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw)
+{
+    constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
+    constexpr int MT = WTM / 32, NT = WTN / 32;
+    static_assert(WM * WN == 8 && NT == 2 && MT == 2, "conv_hdmap: wave tiling");
+    static_assert(HRMAX % 64 == 0 && BN % 64 == 0 && (NB == 2 || NB == 3), "conv_hdmap: staging");
+    constexpr int KS = 4;                                       // depth steps of 16 channels per K-tile
+    constexpr int ABYTES = HRMAX * 128;                         // one halo buffer: HRMAX rows x 64 channels
+    constexpr int TILE_B = BN * 128;
+    constexpr int BRING = 2 * ABYTES;                           // ring of NB weight tiles behind the two halo buffers
+    constexpr int SROWS = 16, SROW_B = WTN * 2 + 16;            // staged rows per step and their LDS pitch (64 bf16 + 16 bytes)
+    constexpr int STG = BRING + NB * TILE_B;                    // wave-private staging: 8 x SROWS x SROW_B
+    constexpr int RED = STG + 8 * SROWS * SROW_B;               // [WM][2][BN] floats
+    constexpr int SMEM = RED + WM * 2 * BN * 4;
+    constexpr int ZROW = (HRMAX - 1) * 128;                     // last row of either halo buffer: beyond the halo, filled from the zero page
+    static_assert(SMEM <= 160 * 1024, "conv_hdmap: LDS");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
+    constexpr int HPW = HRMAX / 64;                             // 1-KiB halo pieces (8 rows) per wave per slab
+    constexpr int NBW = BN / 64;                                // 1-KiB weight pieces per wave per K-tile
+    constexpr int ATAPS = 7;                                    // taps of a slab whose issue slot may carry halo pieces of the next slab
+    static_assert(HPW <= ATAPS, "conv_hdmap: one halo piece per tap");
+    constexpr int NSTEP = WTM / SROWS;                          // copy-out steps per wave and tile
+    constexpr int NST = NSTEP * 2;                              // 16-byte store instructions per wave and tile
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int W = a.W, H = a.H, C = a.C;
+    const int ntn = a.K / BN;
+    const int nslab = C / 64;
+
+    // this workgroup's tiles: [first, first + cnt), consecutive ids share the M-tile
+    int first, cnt;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        const int p = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+        first = p * tpw;
+        cnt = ntiles - first < tpw ? ntiles - first : tpw;
+    }
+    if (cnt <= 0) return;
+
+    const __bf16* xin = static_cast<const __bf16*>(a.x);
+    const __bf16* win = static_cast<const __bf16*>(a.w);
+    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 7) * 8;
+    const int prow = lane >> 3, pseg = lane & 7;
+
+    // ---- DMA roles, recomputed per piece.  Halo row hr of a tile with origin m0 holds input pixel m0 - (W + 1) + hr; rows outside the
+    //      tensor and the buffer rows past the halo come from the zero page (the last of them is the ZERO ROW of the border select)
+    auto issue_a = [&](const int m0x, const int slab, const int buf, const int j) {
+        const int row = (wave * HPW + j) * 8 + prow;
+        const int q = m0x - (W + 1) + row;
+        const bool ok = q >= 0 && q < a.M && row < BM + 2 * W + 2;
+        const __bf16* src = ok ? xin + ((size_t)q * C + (size_t)(slab * 64 + (pseg ^ ((row >> 1) & 7)) * 8)) : zero;
+        lds_dma16(src, smem + buf * ABYTES + (wave * HPW + j) * 1024);
+    };
+    // weight tile (slab, tap) of the tile with column origin n0x into ring slot `slot`
+    auto issue_b = [&](const int n0x, const int slab, const int tap, const int slot) {
+        char* base = smem + BRING + slot * TILE_B;
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) {
+            const int row = (wave * NBW + j) * 8 + prow;
+            lds_dma16(win + ((size_t)(n0x + row) * (size_t)(9 * C) + (size_t)(tap * C + slab * 64 + (pseg ^ ((row >> 1) & 7)) * 8)),
+                      base + (wave * NBW + j) * 1024);
+        }
+    };
+    // ---- fragment roles.  Weights: row l31 of a 32-row block, slot (2g + kh) ^ ((l31 >> 1) & 7).  Activations: halo row of the
+    //      centre tap per 32-row block (the same for every tile) + per-lane tap validity (per tile)
+    const int bxor = kh ^ ((l31 >> 1) & 7);
+    const int bBase = BRING + (wn * WTN + l31) * 128;
+    int rowc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rowc[i] = W + 1 + wm * WTM + i * 32 + l31;
+    auto tap_mask = [&](const int m0x, int (&mask)[MT]) {
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0x + wm * WTM + i * 32 + l31;
+            int bits = 0;
+            if (m < a.M) {
+                const int x = m % W;
+                const int y = (m / W) % H;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int r = t / 3, s = t - 3 * r;
+                    const int dy = MODE == 0 ? r - 1 : 1 - r;
+                    const int dx = MODE == 0 ? s - 1 : 1 - s;
+                    if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
+                }
+            }
+            mask[i] = bits;
+        }
+    };
+    int amask[MT], amaskn[MT];
+
+    f32x16 acc[MT][NT];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    };
+    zero_acc();
+
+    // per (tap, 32-row block): byte offset of the lane's halo row in buffer `buf` (or of its zero row) and the XOR term of its slot
+    int abase[MT], axor[MT];
+    auto tap_addr = [&](const int tap, const int buf, const int (&mask)[MT]) {
+        const int r = tap / 3, s = tap - 3 * r;
+        const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
+        const int abuf = buf * ABYTES;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int hr = rowc[i] + off;
+            const bool ok = (mask[i] >> tap) & 1;
+            abase[i] = abuf + (ok ? (hr << 7) : ZROW);
+            axor[i] = ok ? (kh ^ ((hr >> 1) & 7)) : kh;          // slot (2g + kh) ^ f(hr) = 2g ^ (kh ^ f(hr))
+        }
+    };
+
+    bf16x8 fa[2][MT], fb[2][NT];            // two register sets: depth step g computes from set g & 1 while set (g + 1) & 1 is read
+#define LBC_RD(SLOT, G, SET)                                                                                                     \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
+            fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + (((2 * (G)) ^ axor[i]) << 4));                       \
+        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
+            fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + bBase + j * 32 * 128 + (((2 * (G)) ^ bxor) << 4)); \
+    } while (0)
+#define LBC_MM(SET)                                                                                                              \
+    do {                                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                       \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);                 \
+    } while (0)
+
+    // s_waitcnt vmcnt(n) for the handful of counts the stream produces (the immediate must be a constant)
+    auto wait_vm = [&](const int n) {
+        if (n == 0) LBC_WAIT_VM(0);
+        else if (n == NBW) LBC_WAIT_VM(NBW);
+        else if (n == NBW + 1) LBC_WAIT_VM(NBW + 1);
+        else if (n == NST) LBC_WAIT_VM(NST);
+        else if (n == NBW + NST) LBC_WAIT_VM(NBW + NST);
+        else if (n == NBW + NST + 1) LBC_WAIT_VM(NBW + NST + 1);
+        else LBC_WAIT_VM(0);
+    };
+
+    // ---- the tile stream
+    int tile = first;
+    int mtile = tile / ntn, n0 = (tile - mtile * ntn) * BN, m0 = mtile * BM;
+    int sg = 0;                             // slabs consumed so far: halo buffer sg & 1; weight slot of K-tile (slab, tap): tap % 3 (NB = 3), (sg + tap) & 1 (NB = 2)
+    tap_mask(m0, amask);
+
+    // prologue: the halo of slab 0 and the first two weight tiles in flight; everything of K-tile 0 landed and visible
+#pragma unroll
+    for (int j = 0; j < HPW; ++j) issue_a(m0, 0, 0, j);
+#pragma unroll
+    for (int k = 0; k < NB; ++k) issue_b(n0, 0, k, k);
+    LBC_WAIT_VM((NB - 1) * NBW);
+    __builtin_amdgcn_s_barrier();
+    tap_addr(0, 0, amask);
+    LBC_RD(0, 0, 0);
+    bool stores_pending = false;            // the previous tile's output stores may still be in this wave's VMEM queue
+
+    for (int it = 0; it < cnt; ++it) {
+        const bool more = it + 1 < cnt;
+        const int tilen = tile + 1;
+        const int mtilen = tilen / ntn, n0n = (tilen - mtilen * ntn) * BN, m0n = mtilen * BM;
+        if (more) tap_mask(m0n, amaskn);
+
+        // One slab = nine K-tiles, taps unrolled.  LAST: the tile's last slab -- what follows in the stream is the next tile (if any).
+        auto slab_body = [&](const int c, auto last_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;
+            const bool follows = !LAST || more;                 // another slab follows this one in the stream
+            // (row base, XOR term) of a tap do not depend on the slab: left alone, the compiler hoists all 9 x MT pairs out of the loops
+#pragma unroll
+            for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rowc[i]), "+v"(amask[i]));
+            const int buf = sg & 1;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int slot = NB == 3 ? t % 3 : (sg + t) & 1, nslot = NB == 3 ? (t + 1) % 3 : slot ^ 1;
+                const bool has_next = t < 8 || follows;
+#pragma unroll
+                for (int g = 0; g + 1 < KS; ++g) {
+                    LBC_RD(slot, g + 1, (g + 1) & 1);
+                    // the reads of the last depth step are out: the addresses are free for the next K-tile's (tap, slab, tile)
+                    if (g == KS - 2 && has_next) {
+                        if (t < 8) tap_addr(t + 1, buf, amask);
+                        else if (!LAST) tap_addr(0, buf ^ 1, amask);
+                        else tap_addr(0, buf ^ 1, amaskn);
+                    }
+                    LBC_MM(g & 1);
+#pragma unroll
+                    for (int q = 0; q < MT + NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); LBC_SG(0x002, 3); }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                // The weight tile of K-tile k + 1 has landed (this wave's pieces).  Requested after it, allowed to stay in flight:
+                // NB = 3: the halo piece + weight tile of the previous K-tile's issue slot; and, right behind a tile boundary, the
+                // previous tile's stores (NST, younger than every DMA piece requested before the epilogue)
+                {
+                    const bool at_boundary = c == 0 && stores_pending;
+                    int n = 0;
+                    if (NB == 3) {
+                        const bool w2 = t + 2 < 9 || follows;                  // K-tile k + 2 exists: its weights were requested one K-tile ago
+                        const bool hp = t >= 1 && t - 1 < HPW && follows;      // ... in front of them a halo piece of the next slab
+                        n = w2 ? NBW + (hp ? 1 : 0) : 0;
+                        if (at_boundary && t < 2) n += NST;
+                    } else {
+                        if (at_boundary && t < 1) n = NST;
+                    }
+                    wait_vm(n);
+                }
+                LBC_WAIT_LGKM0();
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                if (has_next) LBC_RD(nslot, 0, 0);
+                LBC_MM((KS - 1) & 1);
+                // one halo piece of the next slab per tap, then K-tile k + NB -> the ring slot of K-tile k
+                if (t < HPW) {
+                    if (!LAST) issue_a(m0, c + 1, buf ^ 1, t);
+                    else if (more) issue_a(m0n, 0, buf ^ 1, t);
+                }
+                if (t + NB < 9) issue_b(n0, c, t + NB, slot);
+                else if (!LAST) issue_b(n0, c + 1, t + NB - 9, slot);
+                else if (more) issue_b(n0n, 0, t + NB - 9, slot);
+#pragma unroll
+                for (int q = 0; q < MT * NT; ++q) {
+                    LBC_SG(0x008, 1);
+                    if (q < MT + NT) LBC_SG(0x100, 1);
+                    LBC_SG(0x036, 8);                                          // VALU | SALU | VMEM: address arithmetic and DMA pieces
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            ++sg;
+        };
+        for (int c = 0; c + 1 < nslab; ++c) slab_body(c, std::false_type{});
+        slab_body(nslab - 1, std::true_type{});
+
+        // ---- wave-private epilogue: affine / bias / residual / ReLU on the accumulators, 16 rows at a time through this wave's own
+        //      staging rows, 16-byte stores; statistics (or the fused BatchNorm-backward sums) per tile
+        {
+            char* stg = smem + STG + wave * (SROWS * SROW_B);
+            float* red = reinterpret_cast<float*>(smem + RED);
+            __bf16* yout = static_cast<__bf16*>(a.y);
+            const __bf16* resid = EPI == 1 ? static_cast<const __bf16*>(a.resid) : nullptr;
+            const __bf16* by = EPI == 2 ? static_cast<const __bf16*>(a.bnb_y) : nullptr;
+            const int colw = n0 + wn * WTN;                     // first column of this wave
+            const int crow = lane >> 3, cseg = lane & 7;        // copy-out role: chunk lane + 64 q = (row crow + 8 q, segment cseg)
+            float psc[NT], psh[NT], bia[NT];
+#pragma unroll
+            for (int nj = 0; nj < NT; ++nj) {
+                const int col = colw + nj * 32 + l31;
+                psc[nj] = a.post_scale ? a.post_scale[col] : 1.f;
+                psh[nj] = a.post_scale ? a.post_shift[col] : 0.f;
+                bia[nj] = a.bias ? a.bias[col] : 0.f;
+            }
+            // every load of the epilogue is requested before its first store (a load behind a store would wait for the store)
+            float rv[EPI == 1 ? MT : 1][16][NT];
+            if constexpr (EPI == 1) {
+#pragma unroll
+                for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        // (32-bit element offsets from a uniform base -- M * K < 2^31 is part of the launch's eligibility: one address
+                        //  register per gather instead of a 64-bit pair)
+                        const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                        const unsigned ob = (unsigned)(m < a.M ? m : 0) * (unsigned)a.K + (unsigned)(colw + l31);
+#pragma unroll
+                        for (int nj = 0; nj < NT; ++nj) rv[mi][r][nj] = (float)resid[ob + (unsigned)(nj * 32)];
+                    }
+            }
+            bf16x8 yv[EPI == 2 ? NSTEP : 1][2];
+            f32x8 bsc, bsh, bmu, biv;
+            f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
+            if constexpr (EPI == 2) {
+                const int c0 = colw + cseg * 8;
+                bsc = ParamVec<8>::ld(a.bnb_scale + c0); bsh = ParamVec<8>::ld(a.bnb_shift + c0);
+                bmu = ParamVec<8>::ld(a.bnb_mean + c0); biv = ParamVec<8>::ld(a.bnb_invstd + c0);
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        const int m = m0 + wm * WTM + s * SROWS + crow + 8 * q;
+                        yv[s][q] = *reinterpret_cast<const bf16x8*>(by + ((unsigned)(m < a.M ? m : 0) * (unsigned)a.K + (unsigned)(colw + cseg * 8)));
+                    }
+            }
+            float s1[NT], s2[NT];
+#pragma unroll
+            for (int nj = 0; nj < NT; ++nj) { s1[nj] = 0.f; s2[nj] = 0.f; }
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int mi = s >> 1;
+#pragma unroll
+                for (int r8 = 0; r8 < 8; ++r8) {
+                    const int r = (s & 1) * 8 + r8;
+                    const int lr = (r & 3) + 4 * kh + 8 * ((r >> 2) & 1);             // row inside the 16-row step
+                    const bool live = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < a.M;
+#pragma unroll
+                    for (int nj = 0; nj < NT; ++nj) {
+                        float v = acc[mi][nj][r];
+                        if (a.post_scale) v = v * psc[nj] + psh[nj];
+                        if (a.bias) v += bia[nj];
+                        if constexpr (EPI == 1) v += rv[mi][r][nj];
+                        if (a.relu) v = fmaxf(v, 0.f);
+                        *reinterpret_cast<__bf16*>(stg + lr * SROW_B + (nj * 32 + l31) * 2) = (__bf16)v;
+                        if (EPI != 2 && live) { s1[nj] += v; s2[nj] += v * v; }
+                    }
+                }
+                // (LDS operations of one wave execute in order: its reads below see its writes above, and the next step's writes
+                //  cannot overtake these reads.  wave_barrier emits nothing; it pins the order for the compiler -- and for the
+                //  CPU emulator, whose lanes are fibers)
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const int row = crow + 8 * q;
+                    const int m = m0 + wm * WTM + s * SROWS + row;
+                    bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + row * SROW_B + cseg * 16);
+                    if constexpr (EPI == 2) {
+                        // fused BatchNorm-backward reduce (IgemmArgs::bnb_*): mask the stored gradient with bn(y) > 0, sum (g, g * xhat)
+                        const f32x8 yf = __builtin_convertvector(yv[s][q], f32x8);
+                        f32x8 g = __builtin_convertvector(ch, f32x8);
+                        const f32x8 z = yf * bsc + bsh;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+                        ch = __builtin_convertvector(g, bf16x8);
+                        if (m < a.M) { t1 += g; t2 += g * (yf - bmu) * biv; }
+                    }
+                    if (m < a.M) *reinterpret_cast<bf16x8*>(yout + ((unsigned)m * (unsigned)a.K + (unsigned)(colw + cseg * 8))) = ch;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (a.stats) {
+                if constexpr (EPI == 2) {
+                    // lanes with the same segment (lane & 7) hold partial sums of the same 8 channels: combine over lane >> 3
+#pragma unroll
+                    for (int off = 8; off < 64; off <<= 1)
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) { t1[e] += __shfl_xor(t1[e], off); t2[e] += __shfl_xor(t2[e], off); }
+                    if (lane < 8) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            red[(wm * 2 + 0) * BN + wn * WTN + lane * 8 + e] = t1[e];
+                            red[(wm * 2 + 1) * BN + wn * WTN + lane * 8 + e] = t2[e];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int nj = 0; nj < NT; ++nj) {
+                        s1[nj] += __shfl_xor(s1[nj], 32);
+                        s2[nj] += __shfl_xor(s2[nj], 32);
+                    }
+                    if (kh == 0) {
+#pragma unroll
+                        for (int nj = 0; nj < NT; ++nj) {
+                            red[(wm * 2 + 0) * BN + wn * WTN + nj * 32 + l31] = s1[nj];
+                            red[(wm * 2 + 1) * BN + wn * WTN + nj * 32 + l31] = s2[nj];
+                        }
+                    }
+                }
+                LBC_WAIT_LGKM0();
+                __builtin_amdgcn_s_barrier();
+                if (tid < BN) {
+                    float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+                    for (int w2 = 0; w2 < WM; ++w2) { u1 += red[(w2 * 2 + 0) * BN + tid]; u2 += red[(w2 * 2 + 1) * BN + tid]; }
+                    float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+                    dst[n0 + tid] = u1;
+                    dst[a.K + n0 + tid] = u2;
+                }
+                // (the next write of `red` lies behind at least the nine K-tile barriers of the next tile)
+            }
+        }
+        zero_acc();
+        stores_pending = true;
+        tile = tilen; mtile = mtilen; n0 = n0n; m0 = m0n;
+#pragma unroll
+        for (int i = 0; i < MT; ++i) amask[i] = amaskn[i];
+    }
+#undef LBC_RD
+#undef LBC_MM
+}
+#undef LBC_SG
+
+// launches the instantiation for (mode, epilogue form) of one tile shape
+template <int BM, int BN, int WM, int WN, int HRMAX, int NB>
+int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, dim3 grid, hipStream_t s)
+{
+    const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
+#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, NB, MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw)
+    if (mode == 0) {
+        LBC_REQUIRE(epi != 2, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
+        if (epi == 1) LBC_HP(0, 1); else LBC_HP(0, 0);
+    } else {
+        if (epi == 2) LBC_HP(1, 2); else if (epi == 1) LBC_HP(1, 1); else LBC_HP(1, 0);
+    }
+#undef LBC_HP
+    return lbc_check_launch("conv_hdmap");
+}
+
+}  // namespace

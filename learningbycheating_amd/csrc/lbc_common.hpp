@@ -59,6 +59,8 @@ enum LbcOpt {
     kOptHdmaPrologue,      // LBC_HDMA_PROLOGUE: 1 = conv_hdma.hip takes forward launches with BatchNorm-on-load (in-LDS transform of the halo)
     kOptHdmaEarly,         // LBC_HDMA_EARLY: 1 = conv_hdma.hip issues each depth step's fragment reads a full step ahead (not yet measured)
     kOptHdmaDiag,          // LBC_HDMA_DIAG: timing experiments on conv_hdma.hip (bit mask of parts left out; wrong results)
+    kOptNoHdmaPersist,     // LBC_NO_HDMA_PERSIST: 1 = the halo-staged convolution keeps its one-tile-per-workgroup form (conv_hdma_k)
+    kOptHdmaPersistWgs,    // LBC_HDMA_PERSIST_WGS: cap on the persistent workgroups of conv_hdmap.hip (default 256 = one per CU; tests: fewer)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
@@ -157,6 +159,8 @@ constexpr int kLbcHdmaCfgs = 4;
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
+bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg);       // conv_hdmap.hip: persistent form of cfg 1 / 2
+int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64} or -1
 int lbc_conv_glds_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);

@@ -262,5 +262,7 @@ static inline void emu_global_load_lds(const void* g, void* lds_wave_base, unsig
 }
 #define __builtin_amdgcn_global_load_lds(g, l, size, off, aux) emu_global_load_lds((const void*)(g), (void*)(l), (size))
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+// wave-private LDS hand-offs (a wave's lanes are fibers here: make them meet where hardware lanes run in lock-step)
+#define __builtin_amdgcn_wave_barrier() emu::wave_rendezvous()
 #define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __builtin_amdgcn_readfirstlane(v) emu_wave_read((v), 0)

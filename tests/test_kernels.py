@@ -413,7 +413,7 @@ def early_reads_checked(dev):
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
 HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64)
 HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
-              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2),
+              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2),
               (2, 9, 17, 64, 64, 3), (5, 12, 40, 64, 64, 3), (1, 7, 96, 64, 64, 3)]       # the last three: several tiles per persistent workgroup needs LBC_HALO_BLOCKS-like forcing on the GPU only
 HDMA_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, -1), (64, 10, 24, 256, 256, -1), (256, 5, 12, 512, 512, -1),
                                                    (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 0),
@@ -481,6 +481,21 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
             dxe = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
             assert torch.equal(dxe, dx)
         lbc_config("LBC_HDMA_EARLY", 0)
+    # cfg 1 / 2 run the PERSISTENT form (conv_hdmap.hpp) by default.  One / two workgroups for the whole launch: a workgroup walks
+    # several tiles (halo and weight prefetch across the tile boundary, wave-private copy-out, stores in flight under the next
+    # tile) -- and the one-tile-per-workgroup kernel (conv_hdma_k): same MFMAs in the same order, same order of the statistics
+    # sums -> bit-identical outputs and statistics rows
+    if cfgid in (1, 2):
+        have_dx = K % 64 == 0 and C % 128 == 0
+        for opt, val in (("LBC_HDMA_PERSIST_WGS", 1), ("LBC_HDMA_PERSIST_WGS", 2), ("LBC_NO_HDMA_PERSIST", 1)):
+            lbc_config(opt, val)
+            yb, stb = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
+            assert torch.equal(yb, y) and torch.equal(stb, st), (opt, val)
+            y2b, _ = Conv(dev).fwd(x, w, 1, 1, resid=r, relu=1, bf16=3)
+            assert torch.equal(y2b, y2), (opt, val)
+            if have_dx:
+                assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True), dx), (opt, val)
+            lbc_config(opt, -1)
     # A/B: the per-tap LDS-DMA kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_HDMA", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, 1, bf16=3)
