@@ -12,8 +12,10 @@ bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg)
 {
     if (lbc_opt_on(kOptNoHdmaPersist) || a.pre_scale || (mode != 0 && mode != 1)) return false;
     if (a.bnb_y && (mode != 1 || a.resid)) return false;
-    if (cfg == kLbcCfgHdma + 1) return 256 + 2 * a.W + 2 < 384;
-    if (cfg == kLbcCfgHdma + 2) return 128 + 2 * a.W + 2 < 192;
+    // the halo (BM + 2W + 2 rows) must end at least 8 rows before its LDS buffer does: the last 8-row DMA piece then comes from the
+    // zero page as a whole and holds the zero row of the border select
+    if (cfg == kLbcCfgHdma + 1) return 256 + 2 * a.W + 2 <= 384 - 8;
+    if (cfg == kLbcCfgHdma + 2) return 128 + 2 * a.W + 2 <= 192 - 8;
     return false;
 }
 
@@ -31,7 +33,7 @@ int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const int tpw = lbc_cdiv(ntiles, cap);
     const unsigned grid = (unsigned)lbc_cdiv(ntiles, tpw);
     if (cfg == kLbcCfgHdma + 1) {
-        if (256 + 2 * a.W + 2 < 320) return lbc_conv_hdmap_launch_256x128_320(a, mode, zero, ntiles, tpw, grid, s);   // W <= 30: layers 3 / 4
+        if (256 + 2 * a.W + 2 <= 320 - 8) return lbc_conv_hdmap_launch_256x128_320(a, mode, zero, ntiles, tpw, grid, s);   // W <= 30: layers 3 / 4
         return lbc_conv_hdmap_launch_256x128_384(a, mode, zero, ntiles, tpw, grid, s);
     }
     return lbc_conv_hdmap_launch_128x256_192(a, mode, zero, ntiles, tpw, grid, s);

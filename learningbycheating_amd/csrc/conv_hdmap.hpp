@@ -14,9 +14,10 @@
 //     and stores them -- no barrier, and the stores stay in flight under the next tile's K-tiles (vmcnt retires in order on gfx950:
 //     the first K-tile of the next tile waits with vmcnt(#stores), i.e. for the DMA pieces issued BEFORE the stores only);
 //   * statistics rows / the fused BatchNorm-backward sums go through a small [WM][2][BN] LDS array and one barrier per tile.
-// Ring depth NB = 3 weight tiles where LDS allows (slot = tap % 3: a compile-time constant, since 9 taps per slab), else 2 (slot =
-// parity of the running K-tile count).  Every K-tile waits with a counted vmcnt for its successor's weight tile: what this wave
-// requested after that tile (one halo piece + the weight tile after it, the previous tile's stores) stays in flight.
+// Weight ring: 3 tiles (slot = tap % 3: a compile-time constant, since 9 taps per slab).  K-tile k requests the weight tile of K-tile
+// k + 2 and one halo piece of the next slab, spread over its first three depth steps (a burst of 24 DMA instructions from 8 waves
+// right after the barrier stalled every wave's issue: profiles/r03_run6_hdmap_prof.log); every K-tile waits with a counted vmcnt for its
+// successor's weight tile: what this wave requested after that tile stays in flight, the previous tile's stores included.
 #pragma once
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
@@ -26,20 +27,34 @@ namespace {
 
 #define LBC_SG(mask, n) __builtin_amdgcn_sched_group_barrier((mask), (n), 0)
 
+// A wave-uniform pointer the compiler must keep in scalar registers: the DMA source is then (SGPR base, 32-bit VGPR offset) instead
+// of a per-thread 64-bit pointer that is re-formed with two-instruction 64-bit adds per piece
+__device__ __forceinline__ const char* uniform_ptr(const char* p)
+{
+    const unsigned long long v = (unsigned long long)(size_t)p;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<const char*>((size_t)(((unsigned long long)hi << 32) | lo));
+}
+
 // EPI: 0 = plain epilogue (affine / bias / ReLU / statistics), 1 = + residual, 2 = fused BatchNorm-backward reduce (IgemmArgs::bnb_*).
 // One instantiation per form: the residual prefetch (64 registers) and the BatchNorm-backward operands (64) never coexist.
-template <int BM, int BN, int WM, int WN, int HRMAX, int NB, int MODE, int EPI>
-__global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw)
+// PROF (diagnostic builds, LBC_HDMAP_PROF = device address of 8 x u64 per wave): s_memtime stamps around the waits of every K-tile;
+// per wave: [0] K-tiles, [1] cycles in the three leading depth steps, [2] in the vmcnt wait, [3] in lgkmcnt(0) + barrier, [4] in the
+// tail (step-0 reads of the next K-tile, last depth step, DMA issue), [5] in epilogues, [6] whole stream, [7] tiles
+template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, bool PROF = false, int VAR = 0>
+__global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
     static_assert(WM * WN == 8 && NT == 2 && MT == 2, "conv_hdmap: wave tiling");
-    static_assert(HRMAX % 64 == 0 && BN % 64 == 0 && (NB == 2 || NB == 3), "conv_hdmap: staging");
+    static_assert(HRMAX % 64 == 0 && BN % 64 == 0 && (SROWS == 8 || SROWS == 16), "conv_hdmap: staging");
+    constexpr int NB = 3;                                       // weight ring depth: slot of K-tile (slab, tap) = tap % 3 (9 taps per slab)
+    constexpr bool PRIO = (VAR & 1) != 0;                       // A/B variants: 1 = priority alternation, 2 = DMA pieces in the tail (one burst), 4 = reads interleaved with the MFMAs
     constexpr int KS = 4;                                       // depth steps of 16 channels per K-tile
     constexpr int ABYTES = HRMAX * 128;                         // one halo buffer: HRMAX rows x 64 channels
     constexpr int TILE_B = BN * 128;
     constexpr int BRING = 2 * ABYTES;                           // ring of NB weight tiles behind the two halo buffers
-    constexpr int SROWS = 16, SROW_B = WTN * 2 + 16;            // staged rows per step and their LDS pitch (64 bf16 + 16 bytes)
+    constexpr int SROW_B = WTN * 2 + 16;                        // LDS pitch of a staged row (64 bf16 + 16 bytes); SROWS rows per copy-out step
     constexpr int STG = BRING + NB * TILE_B;                    // wave-private staging: 8 x SROWS x SROW_B
     constexpr int RED = STG + 8 * SROWS * SROW_B;               // [WM][2][BN] floats
     constexpr int SMEM = RED + WM * 2 * BN * 4;
@@ -51,11 +66,13 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
     constexpr int ATAPS = 7;                                    // taps of a slab whose issue slot may carry halo pieces of the next slab
     static_assert(HPW <= ATAPS, "conv_hdmap: one halo piece per tap");
     constexpr int NSTEP = WTM / SROWS;                          // copy-out steps per wave and tile
-    constexpr int NST = NSTEP * 2;                              // 16-byte store instructions per wave and tile
+    constexpr int CPL = SROWS / 8;                              // 16-byte chunks per lane and step
+    constexpr int NST = NSTEP * CPL;                            // 16-byte store instructions per wave and tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    const int upper = wave >> 2;            // waves 4-7: the younger wave of each SIMD
     const int l31 = lane & 31, kh = lane >> 5;
     const int W = a.W, H = a.H, C = a.C;
     const int ntn = a.K / BN;
@@ -74,32 +91,46 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
 
     const __bf16* xin = static_cast<const __bf16*>(a.x);
     const __bf16* win = static_cast<const __bf16*>(a.w);
-    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 7) * 8;
     const int prow = lane >> 3, pseg = lane & 7;
 
-    // ---- DMA roles, recomputed per piece.  Halo row hr of a tile with origin m0 holds input pixel m0 - (W + 1) + hr; rows outside the
-    //      tensor and the buffer rows past the halo come from the zero page (the last of them is the ZERO ROW of the border select)
+    // ---- DMA roles: per-thread constants + a wave-uniform origin per piece (the issue slots sit next to MFMAs that leave room
+    //      for ~5 other instructions each: every VALU counts).  Halo row hr of a tile with origin m0 holds input pixel
+    //      m0 - (W + 1) + hr.  Rows outside the tensor read a clamped pixel (they are only ever met by taps that the border select
+    //      sends to the zero row); pieces that lie entirely past the halo (8 p >= BM + 2W + 2: the launcher guarantees that the
+    //      last piece, which holds the ZERO ROW, is one of them) come from the zero page
+    const int HR = BM + 2 * W + 2;
+    const int arow0 = wave * HPW * 8 + prow;                                   // halo row of piece j: arow0 + 8 j
+    const unsigned aswz[2] = {(unsigned)((pseg ^ ((arow0 >> 1) & 7)) * 16), (unsigned)((pseg ^ (((arow0 >> 1) + 4) & 7)) * 16)};   // j even / odd
+    const unsigned zoff = (unsigned)((lane & 7) * 16);
+    const char* xbytes = reinterpret_cast<const char*>(xin);
+    const char* zbytes = static_cast<const char*>(zero_page);
     auto issue_a = [&](const int m0x, const int slab, const int buf, const int j) {
-        const int row = (wave * HPW + j) * 8 + prow;
-        const int q = m0x - (W + 1) + row;
-        const bool ok = q >= 0 && q < a.M && row < BM + 2 * W + 2;
-        const __bf16* src = ok ? xin + ((size_t)q * C + (size_t)(slab * 64 + (pseg ^ ((row >> 1) & 7)) * 8)) : zero;
-        lds_dma16(src, smem + buf * ABYTES + (wave * HPW + j) * 1024);
+        const bool pad = (wave * HPW + j) * 8 >= HR;                           // wave-uniform
+        int q = m0x - (W + 1) + arow0 + 8 * j;
+        q = q < 0 ? 0 : (q >= a.M ? a.M - 1 : q);
+        const unsigned off = (unsigned)q * (unsigned)(2 * C) + aswz[j & 1];
+        const char* sbase = uniform_ptr(pad ? zbytes : xbytes + (size_t)(slab * 128));
+        lds_dma16(sbase + (pad ? zoff : off), smem + buf * ABYTES + (wave * HPW + j) * 1024);
     };
-    // weight tile (slab, tap) of the tile with column origin n0x into ring slot `slot`
-    auto issue_b = [&](const int n0x, const int slab, const int tap, const int slot) {
-        char* base = smem + BRING + slot * TILE_B;
+    // weight tile (slab, tap) of the tile with column origin n0x into ring slot `slot`: uniform base + per-thread byte offset
+    unsigned voffb[NBW];
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) {
-            const int row = (wave * NBW + j) * 8 + prow;
-            lds_dma16(win + ((size_t)(n0x + row) * (size_t)(9 * C) + (size_t)(tap * C + slab * 64 + (pseg ^ ((row >> 1) & 7)) * 8)),
-                      base + (wave * NBW + j) * 1024);
-        }
+    for (int j = 0; j < NBW; ++j) {
+        const int row = (wave * NBW + j) * 8 + prow;
+        voffb[j] = (unsigned)row * (unsigned)(18 * C) + (unsigned)((pseg ^ ((row >> 1) & 7)) * 16);
+    }
+    const char* wbytes = reinterpret_cast<const char*>(win);
+    auto issue_b = [&](const int n0x, const int slab, const int tap, const int slot, const int j0, const int j1) {
+        char* base = smem + BRING + slot * TILE_B;
+        const char* wsrc = uniform_ptr(wbytes + ((size_t)n0x * (size_t)(18 * C) + (size_t)(2 * (tap * C + slab * 64))));
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+            if (j >= j0 && j < j1) lds_dma16(wsrc + voffb[j], base + (wave * NBW + j) * 1024);
     };
-    // ---- fragment roles.  Weights: row l31 of a 32-row block, slot (2g + kh) ^ ((l31 >> 1) & 7).  Activations: halo row of the
-    //      centre tap per 32-row block (the same for every tile) + per-lane tap validity (per tile)
-    const int bxor = kh ^ ((l31 >> 1) & 7);
-    const int bBase = BRING + (wn * WTN + l31) * 128;
+    // ---- fragment roles.  A fragment of depth step g sits in 16-byte slot (2g + kh) ^ f(row) of its 128-byte LDS row, f(row) =
+    //      (row >> 1) & 7 (the swizzle of the DMA source).  With the row base a multiple of 128:  address = (base | (kh ^ f) << 4) ^ 32 g
+    //      -- one v_xor per read, everything else is formed once per tap (activations) or once per kernel (weights)
+    const int baddr = (BRING + (wn * WTN + l31) * 128) | ((kh ^ ((l31 >> 1) & 7)) << 4);
     int rowc[MT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) rowc[i] = W + 1 + wm * WTM + i * 32 + l31;
@@ -135,8 +166,8 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
     };
     zero_acc();
 
-    // per (tap, 32-row block): byte offset of the lane's halo row in buffer `buf` (or of its zero row) and the XOR term of its slot
-    int abase[MT], axor[MT];
+    // per (tap, 32-row block): LDS address of the lane's depth-step-0 fragment in halo buffer `buf` (its halo row, or the zero row)
+    int aaddr[MT];
     auto tap_addr = [&](const int tap, const int buf, const int (&mask)[MT]) {
         const int r = tap / 3, s = tap - 3 * r;
         const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
@@ -144,9 +175,9 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int hr = rowc[i] + off;
-            const bool ok = (mask[i] >> tap) & 1;
-            abase[i] = abuf + (ok ? (hr << 7) : ZROW);
-            axor[i] = ok ? (kh ^ ((hr >> 1) & 7)) : kh;          // slot (2g + kh) ^ f(hr) = 2g ^ (kh ^ f(hr))
+            const int val = (hr << 7) | ((kh ^ ((hr >> 1) & 7)) << 4), zval = ZROW | (kh << 4);
+            const int m = -((mask[i] >> tap) & 1);               // all ones when the tap is inside the image (written as a bit
+            aaddr[i] = abuf + (((val ^ zval) & m) ^ zval);       // select: as `ok ? val : zval` the compiler branches over exec)
         }
     };
 
@@ -154,9 +185,9 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
 #define LBC_RD(SLOT, G, SET)                                                                                                     \
     do {                                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
-            fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + (((2 * (G)) ^ axor[i]) << 4));                       \
+            fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + (aaddr[i] ^ (32 * (G))));                                       \
         _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
-            fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + bBase + j * 32 * 128 + (((2 * (G)) ^ bxor) << 4)); \
+            fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + j * 32 * 128 + (baddr ^ (32 * (G))));         \
     } while (0)
 #define LBC_MM(SET)                                                                                                              \
     do {                                                                                                                         \
@@ -170,6 +201,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
         if (n == 0) LBC_WAIT_VM(0);
         else if (n == NBW) LBC_WAIT_VM(NBW);
         else if (n == NBW + 1) LBC_WAIT_VM(NBW + 1);
+        else if (n == NBW + 2) LBC_WAIT_VM(NBW + 2);
         else if (n == NST) LBC_WAIT_VM(NST);
         else if (n == NBW + NST) LBC_WAIT_VM(NBW + NST);
         else if (n == NBW + NST + 1) LBC_WAIT_VM(NBW + NST + 1);
@@ -179,19 +211,26 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
     // ---- the tile stream
     int tile = first;
     int mtile = tile / ntn, n0 = (tile - mtile * ntn) * BN, m0 = mtile * BM;
-    int sg = 0;                             // slabs consumed so far: halo buffer sg & 1; weight slot of K-tile (slab, tap): tap % 3 (NB = 3), (sg + tap) & 1 (NB = 2)
+    int sg = 0;                             // slabs consumed so far: halo buffer sg & 1
     tap_mask(m0, amask);
 
     // prologue: the halo of slab 0 and the first two weight tiles in flight; everything of K-tile 0 landed and visible
 #pragma unroll
     for (int j = 0; j < HPW; ++j) issue_a(m0, 0, 0, j);
-#pragma unroll
-    for (int k = 0; k < NB; ++k) issue_b(n0, 0, k, k);
-    LBC_WAIT_VM((NB - 1) * NBW);
+    issue_b(n0, 0, 0, 0, 0, NBW);
+    issue_b(n0, 0, 1, 1, 0, NBW);
+    LBC_WAIT_VM(NBW);
     __builtin_amdgcn_s_barrier();
     tap_addr(0, 0, amask);
     LBC_RD(0, 0, 0);
     bool stores_pending = false;            // the previous tile's output stores may still be in this wave's VMEM queue
+    unsigned long long pf_steps = 0, pf_vm = 0, pf_bar = 0, pf_tail = 0, pf_epi = 0, pf_kt = 0, pf_t0 = 0, pf_prev = 0;
+#ifdef LBC_HIP_EMULATED_FOR_TESTS
+#define LBC_NOW() 0ull
+#else
+#define LBC_NOW() __builtin_amdgcn_s_memtime()
+#endif
+    if (PROF) { pf_t0 = LBC_NOW(); pf_prev = pf_t0; }
 
     for (int it = 0; it < cnt; ++it) {
         const bool more = it + 1 < cnt;
@@ -209,10 +248,30 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
             const int buf = sg & 1;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                const int slot = NB == 3 ? t % 3 : (sg + t) & 1, nslot = NB == 3 ? (t + 1) % 3 : slot ^ 1;
+                constexpr int dummy = 0; (void)dummy;
+                const int slot = t % 3, nslot = (t + 1) % 3, islot = (t + 2) % 3;
                 const bool has_next = t < 8 || follows;
+                const bool w2 = t + 2 < 9 || follows;                          // K-tile k + 2 exists
+                const bool hp = t < HPW && follows;                            // this K-tile requests a halo piece of the next slab
+                // DMA requests of this K-tile: K-tile k + 2's weight tile -> ring slot (t + 2) % 3 (read last by K-tile k - 1: free since
+                // that K-tile's barrier), piece by piece; then the halo piece
+                auto issue_w = [&](const int j0, const int j1) {
+                    if (!w2) return;
+                    const int tt = t + 2 < 9 ? t + 2 : t - 7;
+                    const int cc = t + 2 < 9 ? c : (LAST ? 0 : c + 1);
+                    const int nn = (t + 2 < 9 || !LAST) ? n0 : n0n;
+                    issue_b(nn, cc, tt, islot, j0, j1);
+                };
+                auto issue_h = [&]() {
+                    if (!hp) return;
+                    if (!LAST) issue_a(m0, c + 1, buf ^ 1, t);
+                    else issue_a(m0n, 0, buf ^ 1, t);
+                };
 #pragma unroll
                 for (int g = 0; g + 1 < KS; ++g) {
+                    if (PRIO) {     // the two waves of a SIMD take turns at the matrix pipe (equal priority = the older wave always wins)
+                        if ((g & 1) == upper) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                    }
                     LBC_RD(slot, g + 1, (g + 1) & 1);
                     // the reads of the last depth step are out: the addresses are free for the next K-tile's (tap, slab, tile)
                     if (g == KS - 2 && has_next) {
@@ -220,47 +279,62 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
                         else if (!LAST) tap_addr(0, buf ^ 1, amask);
                         else tap_addr(0, buf ^ 1, amaskn);
                     }
+                    if (!(VAR & 2)) {
+                        if (g == 0) issue_w(0, NBW / 2);
+                        else if (g == 1) issue_w(NBW / 2, NBW);
+                        else issue_h();
+                    }
                     LBC_MM(g & 1);
+                    if (VAR & 4) {
 #pragma unroll
-                    for (int q = 0; q < MT + NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); LBC_SG(0x002, 3); }
+                        for (int q = 0; q < MT + NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); LBC_SG(0x036, 4); }
+                    } else {
+                        // the step's fragment reads first: a full step of MFMAs (128 cycles of this wave's own, 256 with its SIMD
+                        // partner) between a read and the wait that needs it -- a wave that runs alone no longer stalls on LDS latency
+                        LBC_SG(0x100, MT + NT);
+#pragma unroll
+                        for (int q = 0; q < MT * NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x036, 5); }
+                    }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                // The weight tile of K-tile k + 1 has landed (this wave's pieces).  Requested after it, allowed to stay in flight:
-                // NB = 3: the halo piece + weight tile of the previous K-tile's issue slot; and, right behind a tile boundary, the
-                // previous tile's stores (NST, younger than every DMA piece requested before the epilogue)
+                unsigned long long pf_a = 0, pf_b = 0, pf_c = 0;
+                if (PROF) { LBC_WAIT_LGKM0(); pf_a = LBC_NOW(); }
+                // The weight tile of K-tile k + 1 (requested during K-tile k - 1) has landed, this wave's pieces.  Requested after it and
+                // allowed to stay in flight: the halo piece of K-tile k - 1, this K-tile's weight tile and halo piece -- and, in the first
+                // K-tile behind a tile boundary, the previous tile's stores (they sit between K-tile k - 1's requests and this one's)
                 {
-                    const bool at_boundary = c == 0 && stores_pending;
                     int n = 0;
-                    if (NB == 3) {
-                        const bool w2 = t + 2 < 9 || follows;                  // K-tile k + 2 exists: its weights were requested one K-tile ago
-                        const bool hp = t >= 1 && t - 1 < HPW && follows;      // ... in front of them a halo piece of the next slab
-                        n = w2 ? NBW + (hp ? 1 : 0) : 0;
-                        if (at_boundary && t < 2) n += NST;
-                    } else {
-                        if (at_boundary && t < 1) n = NST;
+                    if (VAR & 2) {      // burst variant: the requests of K-tile k - 1 came after its wait: [halo piece][weight tile k + 1] -> all landed
+                        n = (c == 0 && t == 0 && stores_pending) ? NST : 0;
+                    } else if (w2) {
+                        const bool hp_prev = t >= 1 && t - 1 < HPW && follows;
+                        n = NBW + (hp_prev ? 1 : 0) + (hp ? 1 : 0);
+                        if (c == 0 && t == 0 && stores_pending) n += NST;
                     }
                     wait_vm(n);
                 }
+                if (PROF) pf_b = LBC_NOW();
                 LBC_WAIT_LGKM0();
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+                if (PROF) pf_c = LBC_NOW();
+                if (PRIO) {
+                    if (((KS - 1) & 1) == upper) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+                }
                 if (has_next) LBC_RD(nslot, 0, 0);
                 LBC_MM((KS - 1) & 1);
-                // one halo piece of the next slab per tap, then K-tile k + NB -> the ring slot of K-tile k
-                if (t < HPW) {
-                    if (!LAST) issue_a(m0, c + 1, buf ^ 1, t);
-                    else if (more) issue_a(m0n, 0, buf ^ 1, t);
+                if (VAR & 2) {          // everything in one burst behind the barrier: K-tile k + 1's successor is K-tile k + 2 -> slot (t + 2) % 3
+                    issue_h();
+                    issue_w(0, NBW);
                 }
-                if (t + NB < 9) issue_b(n0, c, t + NB, slot);
-                else if (!LAST) issue_b(n0, c + 1, t + NB - 9, slot);
-                else if (more) issue_b(n0n, 0, t + NB - 9, slot);
+                LBC_SG(0x100, MT + NT);
 #pragma unroll
-                for (int q = 0; q < MT * NT; ++q) {
-                    LBC_SG(0x008, 1);
-                    if (q < MT + NT) LBC_SG(0x100, 1);
-                    LBC_SG(0x036, 8);                                          // VALU | SALU | VMEM: address arithmetic and DMA pieces
-                }
+                for (int q = 0; q < MT * NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x036, 6); }
                 __builtin_amdgcn_sched_barrier(0);
+                if (PROF) {
+                    const unsigned long long pf_d = LBC_NOW();
+                    pf_steps += pf_a - pf_prev; pf_vm += pf_b - pf_a; pf_bar += pf_c - pf_b; pf_tail += pf_d - pf_c; pf_prev = pf_d; ++pf_kt;
+                }
             }
             ++sg;
         };
@@ -300,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
                         for (int nj = 0; nj < NT; ++nj) rv[mi][r][nj] = (float)resid[ob + (unsigned)(nj * 32)];
                     }
             }
-            bf16x8 yv[EPI == 2 ? NSTEP : 1][2];
+            bf16x8 yv[EPI == 2 ? NSTEP : 1][CPL];
             f32x8 bsc, bsh, bmu, biv;
             f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
             if constexpr (EPI == 2) {
@@ -310,7 +384,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
 #pragma unroll
                 for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
-                    for (int q = 0; q < 2; ++q) {
+                    for (int q = 0; q < CPL; ++q) {
                         const int m = m0 + wm * WTM + s * SROWS + crow + 8 * q;
                         yv[s][q] = *reinterpret_cast<const bf16x8*>(by + ((unsigned)(m < a.M ? m : 0) * (unsigned)a.K + (unsigned)(colw + cseg * 8)));
                     }
@@ -320,11 +394,12 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
             for (int nj = 0; nj < NT; ++nj) { s1[nj] = 0.f; s2[nj] = 0.f; }
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
-                const int mi = s >> 1;
+                constexpr int SPB = 32 / SROWS, RPS = SROWS / 2;                      // steps per 32-row block, accumulator registers per step
+                const int mi = s / SPB;
 #pragma unroll
-                for (int r8 = 0; r8 < 8; ++r8) {
-                    const int r = (s & 1) * 8 + r8;
-                    const int lr = (r & 3) + 4 * kh + 8 * ((r >> 2) & 1);             // row inside the 16-row step
+                for (int r8 = 0; r8 < RPS; ++r8) {
+                    const int r = (s % SPB) * RPS + r8;
+                    const int lr = (r & 3) + 4 * kh + 8 * ((r >> 2) % (SROWS / 8));   // row inside the step
                     const bool live = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < a.M;
 #pragma unroll
                     for (int nj = 0; nj < NT; ++nj) {
@@ -342,7 +417,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
                 //  CPU emulator, whose lanes are fibers)
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
-                for (int q = 0; q < 2; ++q) {
+                for (int q = 0; q < CPL; ++q) {
                     const int row = crow + 8 * q;
                     const int m = m0 + wm * WTM + s * SROWS + row;
                     bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + row * SROW_B + cseg * 16);
@@ -402,22 +477,37 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
             }
         }
         zero_acc();
+        if (PROF) { const unsigned long long t = LBC_NOW(); pf_epi += t - pf_prev; pf_prev = t; }
         stores_pending = true;
         tile = tilen; mtile = mtilen; n0 = n0n; m0 = m0n;
 #pragma unroll
         for (int i = 0; i < MT; ++i) amask[i] = amaskn[i];
     }
+    if (PROF && prof && lane == 0) {
+        unsigned long long* o = prof + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = pf_kt; o[1] = pf_steps; o[2] = pf_vm; o[3] = pf_bar; o[4] = pf_tail; o[5] = pf_epi; o[6] = LBC_NOW() - pf_t0; o[7] = (unsigned long long)cnt;
+    }
+#undef LBC_NOW
 #undef LBC_RD
 #undef LBC_MM
 }
 #undef LBC_SG
 
 // launches the instantiation for (mode, epilogue form) of one tile shape
-template <int BM, int BN, int WM, int WN, int HRMAX, int NB>
+template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
 int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, dim3 grid, hipStream_t s)
 {
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
-#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, NB, MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw)
+    const long long var = lbc_opt(kOptHdmapVar) > 0 ? lbc_opt(kOptHdmapVar) : 0;       // A/B variants (plain forward only)
+    unsigned long long* prof = lbc_opt(kOptHdmapProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptHdmapProf)) : nullptr;
+    if ((prof || var) && mode == 0 && epi == 0) {
+#define LBC_HV(PROFv, VARv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, PROFv, VARv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof)
+        if (prof) { if (var == 1) LBC_HV(true, 1); else if (var == 2) LBC_HV(true, 2); else if (var == 4) LBC_HV(true, 4); else if (var == 6) LBC_HV(true, 6); else LBC_HV(true, 0); }
+        else      { if (var == 1) LBC_HV(false, 1); else if (var == 2) LBC_HV(false, 2); else if (var == 4) LBC_HV(false, 4); else if (var == 6) LBC_HV(false, 6); else LBC_HV(false, 0); }
+#undef LBC_HV
+        return lbc_check_launch("conv_hdmap");
+    }
+#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr)
     if (mode == 0) {
         LBC_REQUIRE(epi != 2, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
         if (epi == 1) LBC_HP(0, 1); else LBC_HP(0, 0);

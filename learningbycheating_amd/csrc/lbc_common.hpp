@@ -61,6 +61,8 @@ enum LbcOpt {
     kOptHdmaDiag,          // LBC_HDMA_DIAG: timing experiments on conv_hdma.hip (bit mask of parts left out; wrong results)
     kOptNoHdmaPersist,     // LBC_NO_HDMA_PERSIST: 1 = the halo-staged convolution keeps its one-tile-per-workgroup form (conv_hdma_k)
     kOptHdmaPersistWgs,    // LBC_HDMA_PERSIST_WGS: cap on the persistent workgroups of conv_hdmap.hip (default 256 = one per CU; tests: fewer)
+    kOptHdmapProf,         // LBC_HDMAP_PROF: device address of a u64[grid][8 waves][8] buffer -> the s_memtime-stamped build of conv_hdmap_k (diagnostic)
+    kOptHdmapVar,          // LBC_HDMAP_VAR: A/B variants of conv_hdmap_k's plain forward (1 priority alternation, 2 DMA burst in the tail, 4 reads interleaved with MFMAs)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

@@ -65,6 +65,33 @@ def test_lmdb_meta_page_layout(tmp_path):
     assert flags == 0x02 and lower == 16 + 4                                         # a leaf with two node pointers
 
 
+def test_lmdb_reader_on_hand_assembled_environment():
+    """tests/golden/lmdb_handmade/data.mdb was NOT written by write_lmdb: tests/golden/make_lmdb_fixture.py lays its bytes out from the
+    LMDB 0.9 structure definitions with what a real two-transaction environment has and our writer never produces -- the current meta
+    page is page 0 (txnid 2; page 1 still points at the first transaction's stale root), a populated free DB, a branch root whose first
+    key is empty, leaf bodies in insertion order under sorted pointers, one value on three overflow pages.  (python-lmdb is not in this
+    image and the reference ships no recorded episode, so a file from data_collector.py:234-252 itself cannot be had.)"""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_lmdb_fixture", os.path.join(here, "golden", "make_lmdb_fixture.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    path = os.path.join(here, "golden", "lmdb_handmade")
+    assert open(os.path.join(path, "data.mdb"), "rb").read() == mk.build()       # the committed bytes are what the script assembles
+    rec = mk.records()
+    r = LmdbReader(path)
+    assert (r.psize, r.root, r.depth, r.entries) == (4096, 8, 2, 13)             # meta page 0 (txnid 2) wins over page 1 (txnid 1)
+    assert r.keys() == sorted(rec)
+    for k, v in rec.items():
+        assert bytes(r.get(k)) == v, k
+    assert bytes(r.get("len")) == b"3"                                           # not the stale b"0" of the first transaction
+    assert len(r.get("birdview_0000")) == 9000                                   # overflow pages
+    assert np.allclose(np.frombuffer(r.get("measurements_0002"), np.float32), [2 + 0.25 * j for j in range(17)])
+    for missing in ("", "a", "birdview_0003", "control", "lem", "rgb_0003", "zzz"):     # before / between / after every leaf
+        assert r.get(missing) is None, missing
+    r.close()
+
+
 # ---- dataset -------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def dataset_dir(tmp_path_factory):
@@ -100,8 +127,12 @@ def test_image_dataset_sample_contract(dataset_dir):
     assert abs(speed2 - np.linalg.norm(m[5:8])) < 1e-6 and cmd2 == m[11]
 
 
-def test_device_loader_batches_crop_and_batch_aug(env, dataset_dir):
+@pytest.mark.parametrize("where", ["emulator", pytest.param("mi355x", marks=gpu)])
+def test_device_loader_batches_crop_and_batch_aug(env, dataset_dir, where):
+    """frames at the reference's sizes (160 x 384 RGB, 320 x 320 x 7 bird-view cropped to 192 x 192 on the device): the crop kernel
+    and the staging path run on the CPU emulator and, marked gpu, on the MI355X"""
     dev, _ = env
+    assert (dev.type == "cuda") == (where == "mi355x")
     ds = D.ImageDataset(os.path.join(dataset_dir, "train"))
     ld = D.DeviceLoader(ds, batch_size=3, samples=2, device=dev, seed=5)
     ref_rng = np.random.RandomState(5 * 9973)
@@ -216,10 +247,11 @@ def test_augmentation_kernels_match_the_numpy_twin(env, shape):
     assert all(np.mean(got[i] != imgs[i]) > 0.5 for i in range(N))
 
 
-def test_augmentation_single_operators_are_exact(env):
+@pytest.mark.parametrize("hw", [(12, 20), pytest.param((160, 384), marks=gpu)])
+def test_augmentation_single_operators_are_exact(env, hw):
     dev, _ = env
     rng = np.random.RandomState(13)
-    img = rng.randint(0, 256, (2, 12, 20, 3), dtype=np.uint8)
+    img = rng.randint(0, 256, (2, hw[0], hw[1], 3), dtype=np.uint8)
     for op in (A.COARSE_DROPOUT, A.DROPOUT, A.ADD, A.MULTIPLY, A.CONTRAST):
         arr = (_lib.AugParams * 2)()
         for i in range(2):
