@@ -1,0 +1,275 @@
+// 3x3 / stride-1 / pad-1 convolution with C = K = 64 (forward and input gradient) on bf16 tensors: the stem-resolution layer of the
+// ResNets -- 16 launches of a training step, 72.5 GFLOP and 252 MB of activations each at batch 256, i.e. as close to the HBM
+// roofline (50 us) as to the MFMA one (30 us).  reference: BasicBlock conv1 / conv2, bird_view/models/resnet.py:15-22,38-54.
+//
+// Persistent successor of conv_halo.hip (register-staged halo, 2-byte stores, 0.124 ms) built from the pieces that worked elsewhere:
+//   * weights of all nine taps stationary in registers (144 VGPRs per wave: its 32 output channels), as conv_halo.hip: no weight
+//     stream, no barrier inside a tile -- 72 MFMAs per wave between barriers, one LDS fragment read per MFMA;
+//   * the ACTIVATION HALO of a 256-pixel tile (256 + 2W + 2 rows of 128 bytes) arrives by LDS-DMA into one of two buffers; a
+//     workgroup walks a contiguous range of tiles and requests tile i + 1's halo piece by piece under tile i's MFMAs;
+//   * image borders: a lane whose tap leaves the image reads the zero row of the buffer instead (conv_hdma.hip), one select per
+//     (tap, 32-row block) -- no per-fragment masking;
+//   * wave-private epilogue (conv_hdmap.hpp): 16 rows x 32 columns staged in the wave's own 1.25 KB of LDS, read back as 16-byte
+//     chunks and stored; the stores stay in flight under the next tile (the next tile's halo was requested BEFORE them, so the
+//     counted vmcnt at the tile boundary leaves them alone); the residual / pre-BatchNorm activation of the fused forms reach the
+//     accumulator layout through LDS: each wave DMAs its own 64 x 32 sub-tile (four 1-KiB pieces under the MFMA loop) and reads
+//     it back with 2-byte LDS reads (2-byte GLOBAL gathers, 32 per lane and tile, tripled the launch time);
+//   * statistics rows through a [2 parities][4][2][64] LDS array, combined after the next tile's opening barrier.
+#include "lbc_common.hpp"
+#include "lbc_act.hpp"
+#include "conv_lds_dma.hpp"
+
+namespace {
+
+// EPI: 0 = plain (affine / bias / ReLU / statistics), 1 = + residual, 2 = fused BatchNorm-backward reduce (IgemmArgs::bnb_*)
+template <int MODE, int EPI>
+__global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw)
+{
+    constexpr int BM = 256, BN = 64, WM = 4, WN = 2, MT = 2;
+    constexpr int HRMAX = 456;                                  // BM + 2 W + 2 < 456 <=> W <= 98
+    constexpr int NP = HRMAX / 8;                               // 1-KiB halo pieces per tile (57)
+    constexpr int PPW = (NP + 7) / 8;                           // ... per wave (the last wave has one)
+    constexpr int ABYTES = HRMAX * 128;
+    constexpr int ZROW = (HRMAX - 1) * 128;
+    constexpr int SROWS = 16, SROW_B = 32 * 2 + 16;             // staged rows per copy-out step, their LDS pitch (32 bf16 + 16 bytes)
+    constexpr int STG = 2 * ABYTES;                             // wave-private staging: 8 x SROWS x SROW_B
+    constexpr int RED = STG + 8 * SROWS * SROW_B;               // [2][WM][2][BN] floats
+    constexpr int GT = RED + 2 * WM * 2 * BN * 4;               // EPI 1 / 2: per wave [64 rows][32 columns] of the residual / pre-BatchNorm activation
+    constexpr int SMEM = GT + (EPI != 0 ? 8 * 64 * 64 : 0);
+    constexpr int NSTEP = 64 / SROWS;                           // copy-out steps per wave and tile = 16-byte stores per lane
+    static_assert(SMEM <= 160 * 1024 && PPW == 8, "conv_c64p: LDS / piece arithmetic");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kh = lane >> 5;
+    const int W = a.W, H = a.H;
+    const __bf16* xin = static_cast<const __bf16*>(a.x);
+    const __bf16* win = static_cast<const __bf16*>(a.w);
+    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 7) * 8;
+
+    // this workgroup's tiles: a contiguous range (neighbouring tiles share 2W + 2 halo rows: the second read comes from L2)
+    int first, cnt;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        const int p = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+        first = p * tpw;
+        cnt = ntiles - first < tpw ? ntiles - first : tpw;
+    }
+    if (cnt <= 0) return;
+
+    // stationary weights: output channel 32 wn + l31, k-slots = channels 16 g + 8 kh .. + 7 of tap t
+    bf16x8 wreg[9][4];
+    {
+        const __bf16* wrow = win + (size_t)(32 * wn + l31) * (9 * 64) + 8 * kh;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) wreg[t][g] = *reinterpret_cast<const bf16x8*>(wrow + t * 64 + g * 16);
+    }
+    // DMA roles: piece wave * PPW + j, lane -> (row, segment); halo row hr <-> input pixel m0 - (W + 1) + hr.  Rows outside the tensor
+    // or past the halo come from the zero page (the last buffer row is the ZERO ROW of the border select)
+    const int prow = lane >> 3, pseg = lane & 7;
+    const int prel0 = wave * PPW * 8 + prow - (W + 1);
+    const int pswz_even = (pseg ^ (prow >> 1)) * 8, pswz_odd = (pseg ^ (4 + (prow >> 1))) * 8;
+    auto issue_piece = [&](const int m0x, const int buf, const int j) {
+        const int piece = wave * PPW + j;
+        if (piece < NP) {                                       // wave-uniform
+            const int rel = prel0 + 8 * j;
+            const int q = m0x + rel;
+            const bool ok = q >= 0 && q < a.M && rel + (W + 1) < BM + 2 * W + 2;
+            const __bf16* src = ok ? xin + ((size_t)q * 64 + (size_t)((j & 1) ? pswz_odd : pswz_even)) : zero;
+            lds_dma16(src, smem + buf * ABYTES + piece * 1024);
+        }
+    };
+    const int npw = wave * PPW + PPW <= NP ? PPW : (NP - wave * PPW > 0 ? NP - wave * PPW : 0);   // pieces this wave requests per tile
+    int rowc[MT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) rowc[i] = W + 1 + wm * 64 + i * 32 + l31;
+
+    char* stg = smem + STG + wave * (SROWS * SROW_B);
+    float* red = reinterpret_cast<float*>(smem + RED);
+    __bf16* yout = static_cast<__bf16*>(a.y);
+    const int col = 32 * wn + l31;                              // this lane's output channel (accumulator layout)
+    const int crow = lane >> 2, cseg = lane & 3;                // copy-out role: 16-byte chunk (row crow, segment cseg) of a 16 x 32 step
+    float psc = 1.f, psh = 0.f, bia = 0.f, bsc = 0.f, bsh = 0.f, bmu = 0.f, biv = 0.f;
+    if (a.post_scale) { psc = a.post_scale[col]; psh = a.post_shift[col]; }
+    if (a.bias) bia = a.bias[col];
+    if (EPI == 2) { bsc = a.bnb_scale[col]; bsh = a.bnb_shift[col]; bmu = a.bnb_mean[col]; biv = a.bnb_invstd[col]; }
+    const __bf16* gsrc = EPI == 1 ? static_cast<const __bf16*>(a.resid) : (EPI == 2 ? static_cast<const __bf16*>(a.bnb_y) : nullptr);
+
+    // the first tile's halo
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) issue_piece(first * BM, 0, j);
+
+    bool stores_pending = false;
+    for (int it = 0; it < cnt; ++it) {
+        const int tile = first + it;
+        const int m0 = tile * BM;
+        const int buf = it & 1;
+        const bool more = it + 1 < cnt;
+        // tap validity of this lane's rows in this tile
+        int amask[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int m = m0 + wm * 64 + i * 32 + l31;
+            int bits = 0;
+            if (m < a.M) {
+                const int x = m % W;
+                const int y = (m / W) % H;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int r = t / 3, s = t - 3 * r;
+                    const int dy = MODE == 0 ? r - 1 : 1 - r;
+                    const int dx = MODE == 0 ? s - 1 : 1 - s;
+                    if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
+                }
+            }
+            amask[i] = bits;
+        }
+        // own halo pieces of this tile landed (they are OLDER in this wave's queue than the previous tile's stores, which stay in
+        // flight); then everybody's are visible -- and nobody reads the other buffer any more
+        if (stores_pending) LBC_WAIT_VM(NSTEP); else LBC_WAIT_VM(0);
+        __builtin_amdgcn_s_barrier();
+        if (a.stats && it > 0 && tid < BN) {                    // the previous tile's statistics row
+            const float* rp = red + ((it - 1) & 1) * (WM * 2 * BN);
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) { u1 += rp[(w2 * 2 + 0) * BN + tid]; u2 += rp[(w2 * 2 + 1) * BN + tid]; }
+            float* dst = a.stats + (size_t)(a.stat_row0 + tile - 1) * 2 * BN;
+            dst[tid] = u1;
+            dst[BN + tid] = u2;
+        }
+
+        f32x16 acc[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
+        const int abuf = buf * ABYTES;
+        int aaddr[MT];
+        auto tap_addr = [&](const int tap) {
+            const int r = tap / 3, s = tap - 3 * r;
+            const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
+#pragma unroll
+            for (int i = 0; i < MT; ++i) {
+                const int hr = rowc[i] + off;
+                const int val = (hr << 7) | ((kh ^ ((hr >> 1) & 7)) << 4), zval = ZROW | (kh << 4);
+                const int m = -((amask[i] >> tap) & 1);
+                aaddr[i] = abuf + (((val ^ zval) & m) ^ zval);
+            }
+        };
+        bf16x8 fa[2][MT];
+        tap_addr(0);
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + aaddr[i]);
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {                       // (tap, depth step) = (st / 4, st % 4)
+            const int t = st >> 2, g = st & 3;
+            if (st + 1 < 36) {
+                if (g == 3) tap_addr(t + 1);
+                const int g1 = (g + 1) & 3;
+#pragma unroll
+                for (int i = 0; i < MT; ++i) fa[(st + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + (aaddr[i] ^ (32 * g1)));
+            }
+            // the next tile's halo, one piece every fourth step (its last readers passed this tile's opening barrier)
+            if (more && (st & 3) == 1 && (st >> 2) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 2);
+            if (EPI != 0 && (st & 7) == 3 && st < 32) {
+                // this wave's 64 x 32 sub-tile of the residual / pre-BatchNorm activation, 16 rows (one DMA piece: 4 lanes per 64-byte
+                // row) at a time -> wave-private: its own vmcnt in front of the epilogue is all the synchronisation it needs
+                const int j = st >> 3;
+                int m = m0 + wm * 64 + j * 16 + (lane >> 2);
+                m = m < a.M ? m : a.M - 1;
+                lds_dma16(gsrc + ((unsigned)m * 64u + (unsigned)(32 * wn + (lane & 3) * 8)), smem + GT + wave * 4096 + j * 1024);
+            }
+#pragma unroll
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st & 1][i], wreg[t][g], acc[i], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);                  // keeps the address arithmetic of later taps out of this step (registers)
+        }
+
+        // ---- wave-private epilogue
+        if (EPI != 0) {     // own pieces of the side tile landed (requested at steps 3 .. 27; only the halo piece of step 29 is younger)
+            if (more) LBC_WAIT_VM(1); else LBC_WAIT_VM(0);
+        }
+        const char* gt = smem + GT + wave * 4096 + l31 * 2;
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSTEP; ++s) {
+            const int mi = s >> 1;
+#pragma unroll
+            for (int r8 = 0; r8 < 8; ++r8) {
+                const int e = (s & 1) * 8 + r8;
+                const int lr = (e & 3) + 4 * kh + 8 * ((e >> 2) & 1);                 // row inside the 16-row step
+                const bool live = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh < a.M;
+                float v = acc[mi][e];
+                if (a.post_scale) v = v * psc + psh;
+                if (a.bias) v += bia;
+                const int grow = mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;        // row of this element inside the wave's 64 x 32 sub-tile
+                if (EPI == 1) v += (float)*reinterpret_cast<const __bf16*>(gt + grow * 64);
+                if (a.relu) v = fmaxf(v, 0.f);
+                if (EPI == 2) {
+                    // sums of the STORED (bf16) gradient, as the separate reduce pass sees it
+                    const float yv = (float)*reinterpret_cast<const __bf16*>(gt + grow * 64);
+                    const float gq = (yv * bsc + bsh > 0.f) ? (float)(__bf16)v : 0.f;
+                    *reinterpret_cast<__bf16*>(stg + lr * SROW_B + l31 * 2) = (__bf16)gq;
+                    if (live) { s1 += gq; s2 += gq * (yv - bmu) * biv; }
+                } else {
+                    *reinterpret_cast<__bf16*>(stg + lr * SROW_B + l31 * 2) = (__bf16)v;
+                    if (live) { s1 += v; s2 += v * v; }
+                }
+            }
+            __builtin_amdgcn_wave_barrier();                    // (one wave's LDS operations execute in order; this pins the compiler -- and the emulator's fibers)
+            const int m = m0 + wm * 64 + s * SROWS + crow;
+            const bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + crow * SROW_B + cseg * 16);
+            if (m < a.M) *reinterpret_cast<bf16x8*>(yout + ((unsigned)m * 64u + (unsigned)(32 * wn + cseg * 8))) = ch;
+            __builtin_amdgcn_wave_barrier();
+        }
+        stores_pending = true;
+        if (a.stats) {
+            s1 += __shfl_xor(s1, 32);
+            s2 += __shfl_xor(s2, 32);
+            float* rp = red + (it & 1) * (WM * 2 * BN);
+            if (kh == 0) { rp[(wm * 2 + 0) * BN + col] = s1; rp[(wm * 2 + 1) * BN + col] = s2; }
+        }
+    }
+    if (a.stats) {                                              // the last tile's statistics row
+        LBC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+        if (tid < BN) {
+            const float* rp = red + ((cnt - 1) & 1) * (WM * 2 * BN);
+            float u1 = 0.f, u2 = 0.f;
+#pragma unroll
+            for (int w2 = 0; w2 < WM; ++w2) { u1 += rp[(w2 * 2 + 0) * BN + tid]; u2 += rp[(w2 * 2 + 1) * BN + tid]; }
+            float* dst = a.stats + (size_t)(a.stat_row0 + first + cnt - 1) * 2 * BN;
+            dst[tid] = u1;
+            dst[BN + tid] = u2;
+        }
+    }
+    (void)npw;
+}
+
+}  // namespace
+
+// C = K = 64, 3x3 / stride 1 on bf16 tensors with bf16 weight copies (lbc_conv_hdma_pick: cfg kLbcCfgHdma + 3); statistics rows
+// are per 256-pixel tile
+int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
+{
+    LBC_REQUIRE(a.C == 64 && a.K == 64 && !a.post_scale == !a.post_shift && !a.pre_scale && (mode == 0 || mode == 1), "conv_c64p: shape");
+    LBC_REQUIRE(256 + 2 * a.W + 2 < 456, "conv_c64p: image too wide for the halo buffer");
+    LBC_REQUIRE(!a.bnb_y || (mode == 1 && !a.resid), "conv_c64p: the fused BatchNorm-backward reduce serves input gradients without a residual");
+    const void* zero = nullptr;
+    int rc = lbc_zero_page(&zero);
+    if (rc) return rc;
+    const int ntiles = lbc_cdiv(a.M, 256);
+    const int cap = lbc_opt(kOptHaloBlocks) > 0 ? (int)lbc_opt(kOptHaloBlocks) : 256;     // one persistent workgroup per CU (tests: fewer)
+    const int tpw = lbc_cdiv(ntiles, cap);
+    const dim3 grid((unsigned)lbc_cdiv(ntiles, tpw));
+    const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
+#define LBC_C6(MODEv, EPIv) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw)
+    if (mode == 0) { if (epi == 1) LBC_C6(0, 1); else LBC_C6(0, 0); }
+    else { if (epi == 2) LBC_C6(1, 2); else if (epi == 1) LBC_C6(1, 1); else LBC_C6(1, 0); }
+#undef LBC_C6
+    return lbc_check_launch("conv_c64p");
+}

@@ -367,219 +367,9 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
 }
 #undef LBC_SG
 
-// ---------------------------------------------------------------------------------------------------------------------
-// The 64-channel layer (C = K = 64: layer 1 of both ResNets, 16 launches per step, 72.5 GFLOP and 252 MB each at batch 256).
-// conv_halo.hip stages a 128-pixel halo through registers, multiplies, stores, and only then loads the next tile; two workgroups
-// per CU overlap each other (0.126-0.145 ms, MFMA busy 0.18, ~2.5x the HBM time).  Same idea as above with the roles this
-// shape suggests:
-//   * one slab, so the two halo buffers alternate between TILES: a persistent workgroup (one per CU, 8 waves) issues the DMA
-//     pieces of tile i + 1 right after the barrier that opens tile i -- the whole multiply + epilogue of tile i hides them;
-//   * all 9 x 64 x 64 weights stay in registers (144 VGPRs per wave: its 32 output channels), as in conv_halo.hip: no weight
-//     ring, no barrier inside a tile -- 72 MFMAs per wave between barriers;
-//   * fragment reads one (tap, depth step) ahead of their MFMAs; epilogue shared with the other LDS-DMA kernels (its staging
-//     area lies behind the halo buffers, which keep receiving the next tile meanwhile).
-template <int MODE>
-__global__ __launch_bounds__(512, 2) void conv_hdma64_k(IgemmArgs a, const void* zero_page, const int ntiles)
-{
-    constexpr int BM = 256, BN = 64, WM = 4, WN = 2, MT = 2, NT = 1;
-    constexpr int HRMAX = 456;                                  // BM + 2 W + 2 < 456 <=> W <= 98
-    constexpr int NP = HRMAX / 8;                               // 1-KiB halo pieces per tile
-    constexpr int PPW = (NP + 7) / 8;                           // ... per wave (the last wave has fewer)
-    constexpr int ABYTES = HRMAX * 128;
-    constexpr int STAGE_OFF = 2 * ABYTES;
-    constexpr int ZROW = (HRMAX - 1) * 128;
-    constexpr int SMEM = STAGE_OFF + lds_dma_epilogue_bytes<BM, BN, WM>();
-    static_assert(SMEM <= 160 * 1024, "conv_hdma64: LDS");
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int W = a.W, H = a.H;
-    const __bf16* xin = static_cast<const __bf16*>(a.x);
-    const __bf16* win = static_cast<const __bf16*>(a.w);
-    const __bf16* zero = static_cast<const __bf16*>(zero_page) + (lane & 7) * 8;
-
-    // weights: output channel 32 wn + l31, k-slots = channels 16 g + 8 kh .. + 7 of tap t
-    bf16x8 wreg[9][4];
-    {
-        const __bf16* wrow = win + (size_t)(32 * wn + l31) * (9 * 64) + 8 * kh;
-#pragma unroll
-        for (int t = 0; t < 9; ++t)
-#pragma unroll
-            for (int g = 0; g < 4; ++g) wreg[t][g] = *reinterpret_cast<const bf16x8*>(wrow + t * 64 + g * 16);
-    }
-    // DMA roles: piece wave * PPW + j, lane -> (row, segment); halo row hr <-> input pixel m0 - (W + 1) + hr
-    // (registers are scarce next to 144 of weights: piece j's row is prel0 + 8 j, and its XOR term takes two values, j even / odd)
-    static_assert(PPW == 8, "conv_hdma64: piece arithmetic");
-    const int prow = lane >> 3, pseg = lane & 7;
-    const int prel0 = wave * PPW * 8 + prow - (W + 1);
-    const int pswz_even = (pseg ^ (prow >> 1)) * 8, pswz_odd = (pseg ^ (4 + (prow >> 1))) * 8;
-    auto issue_tile = [&](const int tile, const int buf) {
-        const int m0 = tile * BM;
-        char* base = smem + buf * ABYTES;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j) {
-            const int piece = wave * PPW + j;
-            if (piece < NP) {                                   // wave-uniform
-                const int rel = prel0 + 8 * j;
-                const int q = m0 + rel;
-                const bool ok = q >= 0 && q < a.M && rel + (W + 1) < BM + 2 * W + 2;
-                const __bf16* src = ok ? xin + ((size_t)q * 64 + (size_t)((j & 1) ? pswz_odd : pswz_even)) : zero;
-                lds_dma16(src, base + piece * 1024);
-            }
-        }
-    };
-    int rowc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) rowc[i] = W + 1 + wm * 64 + i * 32 + l31;
-
-    int tile = blockIdx.x, it = 0;
-    if (tile < ntiles) issue_tile(tile, 0);
-    for (; tile < ntiles; tile += gridDim.x, ++it) {
-        const int buf = it & 1;
-        const int m0 = tile * BM;
-        // tap validity of this lane's rows in this tile
-        int amask[MT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i) {
-            const int m = m0 + wm * 64 + i * 32 + l31;
-            int bits = 0;
-            if (m < a.M) {
-                const int x = m % W;
-                const int y = (m / W) % H;
-#pragma unroll
-                for (int t = 0; t < 9; ++t) {
-                    const int r = t / 3, s = t - 3 * r;
-                    const int dy = MODE == 0 ? r - 1 : 1 - r;
-                    const int dx = MODE == 0 ? s - 1 : 1 - s;
-                    if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
-                }
-            }
-            amask[i] = bits;
-        }
-        // own pieces of this tile landed (nothing younger is in flight), then everybody's are visible
-        LBC_WAIT_VM(0);
-        __builtin_amdgcn_s_barrier();
-        const int next = tile + gridDim.x;
-        if (next < ntiles) issue_tile(next, buf ^ 1);           // its last readers passed the epilogue barrier of the previous tile
-
-        f32x16 acc[MT][NT];
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][0][e] = 0.f;
-        const int abuf = buf * ABYTES;
-        int abase[MT], axor[MT];
-        auto tap_addr = [&](const int tap) {
-            const int r = tap / 3, s = tap - 3 * r;
-            const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-                const int hr = rowc[i] + off;
-                const bool ok = (amask[i] >> tap) & 1;
-                abase[i] = abuf + (ok ? (hr << 7) : ZROW);
-                axor[i] = ok ? (kh ^ ((hr >> 1) & 7)) : kh;
-            }
-        };
-        bf16x8 fa[2][MT];
-        tap_addr(0);
-#pragma unroll
-        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + ((0 ^ axor[i]) << 4));
-#pragma unroll
-        for (int st = 0; st < 36; ++st) {                       // (tap, depth step) = (st / 4, st % 4)
-            const int t = st >> 2, g = st & 3;
-            if (st + 1 < 36) {
-                if (g == 3) tap_addr(t + 1);
-                const int g1 = (g + 1) & 3;
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-                    fa[(st + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + abase[i] + (((2 * g1) ^ axor[i]) << 4));
-            }
-#pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st & 1][i], wreg[t][g], acc[i][0], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);                  // keeps the address arithmetic of later taps out of this step (registers)
-        }
-        // Epilogue on the accumulators (lane = output channel, registers = pixels): with 144 registers of weights live across it there
-        // is no room for the 8-channel vectors of the shared copy-out epilogue.  Residual / pre-BN activation are fetched per half
-        // 32-row block before use; the bf16 tile goes through LDS to 16-byte stores; statistics (or the fused BatchNorm-backward
-        // sums) stay per lane.
-        {
-            constexpr int OROW = BN * 2 + 16;
-            char* stage = smem + STAGE_OFF;
-            const int col = 32 * wn + l31;
-            const __bf16* resid = static_cast<const __bf16*>(a.resid);
-            const __bf16* bnb = static_cast<const __bf16*>(a.bnb_y);
-            float s1 = 0.f, s2 = 0.f;
-            float bsc = 0.f, bsh = 0.f, bmu = 0.f, biv = 0.f, psc = 1.f, psh = 0.f, bias = 0.f;
-            if (bnb) { bsc = a.bnb_scale[col]; bsh = a.bnb_shift[col]; bmu = a.bnb_mean[col]; biv = a.bnb_invstd[col]; }
-            if (a.post_scale) { psc = a.post_scale[col]; psh = a.post_shift[col]; }
-            if (a.bias) bias = a.bias[col];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) {
-#pragma unroll
-                for (int hb = 0; hb < 4; ++hb) {               // four accumulator rows at a time: registers (see above)
-                    float ev[4];
-                    if (resid || bnb) {
-                        const __bf16* src = bnb ? bnb : resid;
-#pragma unroll
-                        for (int k2 = 0; k2 < 4; ++k2) {
-                            const int e = hb * 4 + k2;
-                            const int m = m0 + wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                            ev[k2] = (float)src[(unsigned)(m < a.M ? m : 0) * 64u + (unsigned)col];
-                        }
-                    }
-#pragma unroll
-                    for (int k2 = 0; k2 < 4; ++k2) {
-                        const int e = hb * 4 + k2;
-                        const int row = wm * 64 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-                        const bool live = m0 + row < a.M;
-                        float v = acc[i][0][e] * psc + psh + bias;
-                        if (resid && !bnb) v += ev[k2];
-                        if (a.relu) v = fmaxf(v, 0.f);
-                        if (bnb) {
-                            const float g = (ev[k2] * bsc + bsh > 0.f) ? (float)(__bf16)v : 0.f;       // sums of the STORED gradient
-                            *reinterpret_cast<__bf16*>(stage + row * OROW + col * 2) = (__bf16)g;
-                            if (live) { s1 += g; s2 += g * (ev[k2] - bmu) * biv; }
-                        } else {
-                            *reinterpret_cast<__bf16*>(stage + row * OROW + col * 2) = (__bf16)v;
-                            if (live) { s1 += v; s2 += v * v; }
-                        }
-                    }
-                }
-            }
-            float* red = reinterpret_cast<float*>(stage + BM * OROW);   // [WM][2][BN]
-            if (a.stats) {
-                s1 += __shfl_xor(s1, 32);
-                s2 += __shfl_xor(s2, 32);
-                if (kh == 0) { red[(wm * 2 + 0) * BN + col] = s1; red[(wm * 2 + 1) * BN + col] = s2; }
-            }
-            __syncthreads();
-            __bf16* yout = static_cast<__bf16*>(a.y);
-#pragma unroll
-            for (int idx = tid; idx < BM * 8; idx += 512) {
-                const int row = idx >> 3, sg = idx & 7;
-                if (m0 + row < a.M)
-                    *reinterpret_cast<bf16x8*>(yout + ((unsigned)(m0 + row) * 64u + (unsigned)(sg * 8))) =
-                        *reinterpret_cast<const bf16x8*>(stage + row * OROW + sg * 16);
-            }
-            if (a.stats && tid < BN) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int w2 = 0; w2 < WM; ++w2) { t1 += red[(w2 * 2 + 0) * BN + tid]; t2 += red[(w2 * 2 + 1) * BN + tid]; }
-                float* dst = a.stats + (size_t)(a.stat_row0 + tile) * 2 * 64;
-                dst[tid] = t1;
-                dst[64 + tid] = t2;
-            }
-        }
-        __builtin_amdgcn_s_barrier();                           // the staging area (and this tile's halo buffer) are free again
-    }
-}
-
 struct HdmaCfg { int bm, bn, hrmax; };
 // cfg ids kLbcCfgHdma + 0 .. 2
-const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{256, 256, 320}, {256, 128, 384}, {128, 256, 192}, {256, 64, 456}};   // the last: conv_hdma64_k
+const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{256, 256, 320}, {256, 128, 384}, {128, 256, 192}, {256, 64, 456}};   // the last: conv_c64p.hip
 
 }  // namespace
 
@@ -597,10 +387,10 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     // the 64 x 64 register-staged tiles; at 60 tiles = layer 3 at batch 32 it loses, 0.029 vs 0.027)
     const long long fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 96;
     const long long forced = lbc_opt(kOptHdmaCfg);          // tests / tuning: pin one shape
-    if (a.C == 64 && a.K == 64) {                           // the 64-channel layer: persistent tiles of 256 pixels
-        // measured at batch 256: 0.224 ms against 0.127 ms of conv_halo.hip -- next to 144 registers of stationary weights the
-        // epilogue pushes 62 VGPRs of them into scratch, reloaded every tile; selected only when pinned (LBC_HDMA_CFG=3: tests)
-        if (lbc_opt_on(kOptNoHdma64) || forced != 3) return -1;
+    if (a.C == 64 && a.K == 64) {                           // the 64-channel layer: conv_c64p.hip (persistent, weights in registers)
+        // (its round-2 predecessor conv_hdma64_k lost to conv_halo.hip, 0.224 vs 0.127 ms at batch 256: 62 spilled registers in a
+        //  workgroup-wide LDS-staged epilogue; the wave-private epilogue of round 3 needs none)
+        if (lbc_opt_on(kOptNoHdma64) || (forced >= 0 && forced != 3)) return -1;
         if (256 + 2 * a.W + 2 >= kHdmaCfg[3].hrmax || lbc_cdiv(a.M, 256) < fill) return -1;
         return kLbcCfgHdma + 3;
     }
@@ -630,15 +420,7 @@ int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const void* zero = nullptr;
     int rc = lbc_zero_page(&zero);
     if (rc) return rc;
-    if (cfg == kLbcCfgHdma + 3) {
-        LBC_REQUIRE(a.C == 64 && a.K == 64 && !a.post_scale == !a.post_shift, "conv_hdma64: shape");
-        const int ntiles = lbc_cdiv(a.M, 256);
-        const int cap = lbc_opt(kOptHaloBlocks) > 0 ? (int)lbc_opt(kOptHaloBlocks) : 256;   // one persistent workgroup per CU (tests: fewer)
-        const dim3 g64((unsigned)(ntiles < cap ? ntiles : cap));
-        if (mode == 0) hipLaunchKernelGGL((conv_hdma64_k<0>), g64, dim3(512), 0, s, a, zero, ntiles);
-        else           hipLaunchKernelGGL((conv_hdma64_k<1>), g64, dim3(512), 0, s, a, zero, ntiles);
-        return lbc_check_launch("conv_hdma64");
-    }
+    if (cfg == kLbcCfgHdma + 3) return lbc_conv_c64p_launch(a, mode, s);
     const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn)));
     const bool early = lbc_opt_on(kOptHdmaEarly);
     if (!early && lbc_opt(kOptHdmaDiag) <= 0 && lbc_conv_hdmap_eligible(a, mode, cfg)) return lbc_conv_hdmap_launch(a, mode, cfg, s);

@@ -116,7 +116,9 @@ Net::Net(const lbc_net_desc& d) : d_(d)
             // kernel (conv_glds.hip cannot transform what it stages): there one bn_apply pass (read + write 2 bytes per element)
             // costs less than the register-staged convolution does (batch 256: layer 2 144 -> 95 + 29 us, layer 3 120 -> 72 + 14 us)
             // (with LBC_HDMA_PROLOGUE=1 the halo-staged kernel applies bn1 itself: fused again)
-            b.fuse_z1 = fuse_z1_ < 0 ? (!conv_takes_glds(b.c2, (int)NB) || conv_takes_glds(b.c2, (int)NB, true)) : fuse_z1_ == 0;
+            // (the 64-channel layer keeps bn1 on load: conv_halo.hip transforms its register-staged halo for free, while the LDS-DMA kernel
+            //  for that layer -- conv_c64p.hip -- would need the extra pass; its other launches take that kernel)
+            b.fuse_z1 = fuse_z1_ < 0 ? (planes == 64 || !conv_takes_glds(b.c2, (int)NB) || conv_takes_glds(b.c2, (int)NB, true)) : fuse_z1_ == 0;
             b.z1 = b.fuse_z1 ? 0 : alloc_act(NB * oh * ow * planes);
             b.out = alloc_act(NB * oh * ow * planes);
             blocks_.push_back(b);

@@ -262,6 +262,7 @@ def test_bf16_gradients_match_autocast_reference(env):
     del warm
     sd = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
     x, sp_, cm = seeded_inputs("image", n, 56)
+    x = x.contiguous()               # (seeded_inputs hands out a permuted view of the uint8-style NHWC frames; the raw engine takes dense NCHW)
     oh = O.one_hot(cm)
     eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=2)
     ps, pa = eng.forward(x.to(dev), sp_.to(dev), oh.to(dev), True)
