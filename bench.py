@@ -198,15 +198,17 @@ def self_spawn(args):
 
 
 def read_traffic():
-    """HBM bytes per launch of the dominant kernels from the committed PMC passes (profiles/r02_pmc_traffic.json, written by
-    scripts/pmc_summary.py --json from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs of this command)"""
-    p = os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")
-    if not os.path.exists(p):
-        return None
-    try:
-        return json.load(open(p))
-    except Exception:
-        return None
+    """HBM bytes per launch of the convolution family from the committed PMC passes of THIS round's code: profiles/r03_pmc_traffic.json,
+    written by scripts/pmc_traffic.py from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_r03_evidence.sh (counters need
+    their own runs: they cannot be collected inside this process)"""
+    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+        p = os.path.join(ROOT, "profiles", name)
+        if os.path.exists(p):
+            try:
+                return json.load(open(p))
+            except Exception:
+                pass
+    return None
 
 
 def main():
@@ -234,6 +236,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="skip the short exact-f32 run reported under 'also'")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel-class profile of the instrumented step here (json)")
+    ap.add_argument("--serial", action="store_true",
+                    help="profiling runs: the teacher forward stays on the main stream (with LBC_NO_SIDE_STREAM=1 every kernel then runs alone, "
+                         "so that rocprofv3 per-kernel durations are not inflated by co-running kernels)")
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     kind = wl["kind"]
@@ -317,6 +322,8 @@ def main():
             del warm
             tr = NativeTrainer(student, teacher, per_gpu, (3, 160, 384), device, phase=1, lr=1e-4, world_size=world, grad_dtype=gdt,
                                sync_bn=args.sync_bn)
+        if args.serial:
+            tr.overlap_teacher = False
         weights = []
         run_steps(tr, warmup, "train", weights)
         torch.cuda.synchronize()
@@ -362,6 +369,8 @@ def main():
         ach = gf / ms if ms > 0 else 0.0     # GFLOP / ms = TFLOP/s
         roof = {"bound": "mfma", "kernel": "convolution family (%s): %s" % (mf, ", ".join(sorted(conv))), "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
+                "instrumented_step": "serialized: one extra step on one stream with HIP events around every launch (the timed steps overlap the "
+                                     "teacher forward and the weight gradients on side streams, so the sum of these durations exceeds ms_per_step)",
                 "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "gflop_per_launch": round(gf / max(n, 1), 3),
                 "share_of_step_kernel_time": round(ms / total_ms, 3) if total_ms else None,
                 "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["gflop"] / v["ms"], 1) if v["ms"] else None}

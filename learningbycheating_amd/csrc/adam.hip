@@ -54,7 +54,8 @@ int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, double lr, double 
     const double bc2 = 1.0 - pow(beta2, (double)step);
     const float lr_over_bc1 = (float)(lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
-    LbcProfScope prof("adam", 0.0, 0.0, s);
+    // algorithmic bytes: read p, g, m, v and write p, m, v = 7 x 4 bytes per element (648 MB for the 23.13 M parameters of the student)
+    LbcProfScope prof("adam", 0.0, 28.0 * (double)(lbc_opt(kOptAdamElems) > 0 ? lbc_opt(kOptAdamElems) : 0), s);
     hipLaunchKernelGGL(adam_k, dim3((unsigned)nchunks), dim3(256), 0, s, chunks_dev, lr_over_bc1, inv_bc2_sqrt, (float)beta1,
                        (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay);
     return lbc_check_launch("adam");

@@ -63,6 +63,7 @@ enum LbcOpt {
     kOptHdmaPersistWgs,    // LBC_HDMA_PERSIST_WGS: cap on the persistent workgroups of conv_hdmap.hip (default 256 = one per CU; tests: fewer)
     kOptHdmapProf,         // LBC_HDMAP_PROF: device address of a u64[grid][8 waves][8] buffer -> the s_memtime-stamped build of conv_hdmap_k (diagnostic)
     kOptHdmapVar,          // LBC_HDMAP_VAR: A/B variants of conv_hdmap_k's plain forward (1 priority alternation, 2 DMA burst in the tail, 4 reads interleaved with MFMAs)
+    kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-3 evidence: driver-default bench + breakdown, the per-GPU loads of 2 / 4 / 8 GPUs, SERIALIZED rocprofv3 kernel stats (no side streams:
+# per-kernel durations are those of kernels running alone), PMC passes (MFMA busy, FETCH_SIZE, WRITE_SIZE) of the shipped code ->
+# profiles/r03_pmc_traffic.json, the per-shape convolution table, BASELINE config 1's literal shape, the full GPU test suite, smoke.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out; R=gpurun_out
+S=$R/summary.txt; echo "== $(date)" > $S
+timeout 600 python bench.py --breakdown $R/breakdown_bs256_bf16.json > $R/bench_bf16.log 2>&1; echo "bench exit $?" >> $S; tail -1 $R/bench_bf16.log | cut -c1-300 >> $S
+for B in 128 64 32; do
+  timeout 300 python bench.py --global-batch $B --steps 20 --warmup 5 --no-cpu-baseline --no-alt --breakdown $R/breakdown_b${B}_bf16.json > $R/bench_b${B}_bf16.log 2>&1
+  echo "b$B: $(tail -1 $R/bench_b${B}_bf16.log | cut -c1-200)" >> $S
+done
+rm -rf $R/prof
+(cd /tmp && LBC_NO_SIDE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$R/prof" -o lbc -- python "$OLDPWD/bench.py" --serial --steps 3 --warmup 1 --init-steps 2 --no-cpu-baseline --no-alt) > $R/prof.log 2>&1
+echo "prof exit $?" >> $S
+find $R/prof -name "*kernel_trace*" -size +20M -delete
+i=0
+for ctrs in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_BUSY_CYCLES" "FETCH_SIZE" "WRITE_SIZE"; do
+  i=$((i+1)); rm -rf $R/pmc$i
+  (cd /tmp && LBC_NO_SIDE_STREAM=1 timeout 400 rocprofv3 --pmc $ctrs --kernel-trace --output-format csv -d "$OLDPWD/$R/pmc$i" -o lbc -- python "$OLDPWD/bench.py" --serial --steps 1 --warmup 1 --init-steps 1 --no-cpu-baseline --no-alt) > $R/pmc$i.log 2>&1
+  echo "pmc$i ($ctrs) exit $?" >> $S
+  find $R/pmc$i -name "*kernel_trace*" -delete
+done
+P1=$(find $R/pmc1 -name "*counter_collection.csv" | head -1); P2=$(find $R/pmc2 -name "*counter_collection.csv" | head -1); P3=$(find $R/pmc3 -name "*counter_collection.csv" | head -1)
+python scripts/pmc_summary.py $P1 $P2 $P3 > $R/pmc_summary.txt 2>&1
+python scripts/pmc_traffic.py $P2 $P3 bf16 "profiles/r03_final_pmc_bf16/pass2.csv (FETCH_SIZE x 2, MI355X_MICROARCH.md gfx950 correction) + pass3.csv (WRITE_SIZE): rocprofv3 --pmc passes of \`LBC_NO_SIDE_STREAM=1 bench.py --serial --steps 1 --warmup 1 --init-steps 1 --no-cpu-baseline --no-alt\` (scripts/gpu_r03_evidence.sh)" > $R/r03_pmc_traffic.json 2> $R/pmc_traffic_table.txt
+timeout 200 python scripts/bench_ops.py 256 3 fwd,dgrad,wgrad > $R/per_shape_bs256.txt 2>&1
+timeout 120 python scripts/bench_ops.py 32 3 fwd,dgrad,wgrad > $R/per_shape_bs32.txt 2>&1
+rm -f $R/grad_diag.txt
+timeout ${PYTEST_TIMEOUT:-1500} python -m pytest tests -m gpu -q --durations=8 > $R/pytest_gpu.log 2>&1; echo "pytest exit $?" >> $S; tail -12 $R/pytest_gpu.log >> $S
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $R/smoke.log 2>&1; echo "smoke exit $?: $(tail -1 $R/smoke.log)" >> $S
+cat $S

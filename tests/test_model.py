@@ -898,6 +898,27 @@ def test_training_scripts_chain_phase0_to_phase1(env, tmp_path, precision):
 
 
 @gpu
+def test_baseline_config_1_phase0_256_frames_batch_8(env, tmp_path):
+    """BASELINE.json configs[0] at its literal shape: train_image_phase0 (training/train_image_phase0.py:152-242), ImagePolicyModelSS,
+    256 synthetic 160 x 384 frames, batch 8, 32 steps = one pass over the frames (the reference runs it on PyTorch-CPU as a plumbing
+    check; this package has no CPU path by design, so the same loop runs on the GPU): config.json + model-1.th in the reference's
+    layout, finite decreasing loss in the log"""
+    import json
+    from learningbycheating_amd.training import train_image_phase0
+    d0 = tmp_path / "cfg1"
+    train_image_phase0.main(["--log_dir", str(d0), "--synthetic", "256", "--batch_size", "8", "--iters_per_epoch", "32", "--max_epoch", "1",
+                             "--log_iterations", "8", "--lr", "1e-3"])
+    cfg = json.loads((d0 / "config.json").read_text())
+    assert cfg["model_args"]["backbone"] == "resnet34" and cfg["data_args"]["batch_size"] == 8
+    sd = torch.load(str(d0 / "model-1.th"), map_location="cpu")
+    assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(shape)) for k, shape in O.state_dict_layout("image", "resnet34")]
+    assert all(torch.isfinite(v.float()).all() for v in sd.values())
+    log = [json.loads(l) for l in open(d0 / "log.jsonl")]
+    # (epoch 0 is the reference's no-update pass, train_image_phase0.py:165,202: the first record is the untrained loss)
+    assert all(np.isfinite(r["train_loss_mean"]["mean"]) for r in log) and log[-1]["train_loss_mean"]["mean"] < log[0]["train_loss_mean"]["mean"]
+
+
+@gpu
 @pytest.mark.parametrize("precision", [0, 2])
 def test_side_stream_backward_is_bit_identical_to_single_stream(env, lbc_config, precision):
     """the residual blocks' weight gradients run on an internal side stream; every kernel is deterministic, so a missing
