@@ -369,7 +369,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdma_k(IgemmArgs a, const void* z
 
 struct HdmaCfg { int bm, bn, hrmax; };
 // cfg ids kLbcCfgHdma + 0 .. 2
-const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{256, 256, 320}, {256, 128, 384}, {128, 256, 192}, {256, 64, 456}};   // the last: conv_c64p.hip
+const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{256, 256, 320}, {256, 128, 384}, {128, 256, 192}, {256, 64, 456}, {128, 64, 192}};   // 3: conv_c64p.hip, 4: conv_hdmap.hpp with four waves
 
 }  // namespace
 
@@ -407,7 +407,15 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
         const double score = (double)tiles / (double)(((tiles + 255) / 256) * 256) * (c.bm * c.bn >= 256 * 256 ? 1.0 : 0.9);
         if (score > best_score) { best_score = score; best = i; }
     }
-    return best < 0 ? -1 : kLbcCfgHdma + best;
+    if (best >= 0) return kLbcCfgHdma + best;
+    // Few rows (the per-GPU load of the 8-GPU run: layer 3 / 4 at 32 images have 7680 / 1920 output pixels): 128 x 64 tiles, four waves,
+    // two workgroups per CU (conv_hdmap.hpp) instead of the 64 x 64 register-staged tiles of conv_igemm.hip (31 us per 9-GFLOP launch)
+    if ((forced < 0 || forced == 4) && !a.pre_scale && a.K % 64 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4)) {
+        const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64);
+        const long long small_fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 48;
+        if (tiles >= small_fill) return kLbcCfgHdma + 4;
+    }
+    return -1;
 }
 
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kHdmaCfg[cfg - kLbcCfgHdma].bm); }
@@ -417,6 +425,7 @@ int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     LBC_REQUIRE(cfg >= kLbcCfgHdma && cfg < kLbcCfgHdma + kLbcHdmaCfgs, "conv_hdma: bad cfg %d", cfg);
     const HdmaCfg c = kHdmaCfg[cfg - kLbcCfgHdma];
     LBC_REQUIRE(a.K % c.bn == 0 && a.C % 64 == 0 && c.bm + 2 * a.W + 2 < c.hrmax, "conv_hdma: shape not tileable");
+    if (cfg == kLbcCfgHdma + 4) return lbc_conv_hdmap_launch(a, mode, cfg, s);
     const void* zero = nullptr;
     int rc = lbc_zero_page(&zero);
     if (rc) return rc;

@@ -42,12 +42,14 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p)
 // per wave: [0] K-tiles, [1] cycles in the three leading depth steps, [2] in the vmcnt wait, [3] in lgkmcnt(0) + barrier, [4] in the
 // tail (step-0 reads of the next K-tile, last depth step, DMA issue), [5] in epilogues, [6] whole stream, [7] tiles
 template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, bool PROF = false, int VAR = 0>
-__global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    static_assert(WM * WN == 8 && NT == 2 && MT == 2, "conv_hdmap: wave tiling");
-    static_assert(HRMAX % 64 == 0 && BN % 64 == 0 && (SROWS == 8 || SROWS == 16), "conv_hdmap: staging");
+    constexpr int NW = WM * WN;                                 // waves per workgroup: 8 (256 x 128 / 128 x 256 tiles, one workgroup per CU) or
+                                                                // 4 (128 x 64 tiles for launches with few rows: two workgroups per CU)
+    static_assert((NW == 8 || NW == 4) && (NT == 2 || NT == 1) && MT == 2, "conv_hdmap: wave tiling");
+    static_assert(HRMAX % (8 * NW) == 0 && BN % (8 * NW) == 0 && (SROWS == 8 || SROWS == 16), "conv_hdmap: staging");
     constexpr int NB = 3;                                       // weight ring depth: slot of K-tile (slab, tap) = tap % 3 (9 taps per slab)
     constexpr bool PRIO = (VAR & 1) != 0;                       // A/B variants: 1 = priority alternation, 2 = DMA pieces in the tail (one burst), 4 = reads interleaved with the MFMAs
     constexpr int KS = 4;                                       // depth steps of 16 channels per K-tile
@@ -55,24 +57,26 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
     constexpr int TILE_B = BN * 128;
     constexpr int BRING = 2 * ABYTES;                           // ring of NB weight tiles behind the two halo buffers
     constexpr int SROW_B = WTN * 2 + 16;                        // LDS pitch of a staged row (64 bf16 + 16 bytes); SROWS rows per copy-out step
-    constexpr int STG = BRING + NB * TILE_B;                    // wave-private staging: 8 x SROWS x SROW_B
-    constexpr int RED = STG + 8 * SROWS * SROW_B;               // [WM][2][BN] floats
+    constexpr int STG = BRING + NB * TILE_B;                    // wave-private staging: NW x SROWS x SROW_B
+    constexpr int RED = STG + NW * SROWS * SROW_B;              // [WM][2][BN] floats
     constexpr int SMEM = RED + WM * 2 * BN * 4;
     constexpr int ZROW = (HRMAX - 1) * 128;                     // last row of either halo buffer: beyond the halo, filled from the zero page
     static_assert(SMEM <= 160 * 1024, "conv_hdmap: LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
-    constexpr int HPW = HRMAX / 64;                             // 1-KiB halo pieces (8 rows) per wave per slab
-    constexpr int NBW = BN / 64;                                // 1-KiB weight pieces per wave per K-tile
+    constexpr int HPW = HRMAX / (8 * NW);                       // 1-KiB halo pieces (8 rows) per wave per slab
+    constexpr int NBW = BN / (8 * NW);                          // 1-KiB weight pieces per wave per K-tile
     constexpr int ATAPS = 7;                                    // taps of a slab whose issue slot may carry halo pieces of the next slab
     static_assert(HPW <= ATAPS, "conv_hdmap: one halo piece per tap");
     constexpr int NSTEP = WTM / SROWS;                          // copy-out steps per wave and tile
-    constexpr int CPL = SROWS / 8;                              // 16-byte chunks per lane and step
+    constexpr int SEGS = WTN / 8;                               // 16-byte segments per staged row
+    constexpr int CPL = SROWS * SEGS / 64;                      // 16-byte chunks per lane and step
+    constexpr int RPP = 64 / SEGS;                              // rows per copy-out pass of the wave
     constexpr int NST = NSTEP * CPL;                            // 16-byte store instructions per wave and tile
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
-    const int upper = wave >> 2;            // waves 4-7: the younger wave of each SIMD
+    const int upper = wave / (NW / 2);      // the younger half of the workgroup's waves
     const int l31 = lane & 31, kh = lane >> 5;
     const int W = a.W, H = a.H, C = a.C;
     const int ntn = a.K / BN;
@@ -350,7 +354,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
             const __bf16* resid = EPI == 1 ? static_cast<const __bf16*>(a.resid) : nullptr;
             const __bf16* by = EPI == 2 ? static_cast<const __bf16*>(a.bnb_y) : nullptr;
             const int colw = n0 + wn * WTN;                     // first column of this wave
-            const int crow = lane >> 3, cseg = lane & 7;        // copy-out role: chunk lane + 64 q = (row crow + 8 q, segment cseg)
+            const int crow = lane / SEGS, cseg = lane % SEGS;   // copy-out role: chunk lane + 64 q = (row crow + RPP q, segment cseg)
             float psc[NT], psh[NT], bia[NT];
 #pragma unroll
             for (int nj = 0; nj < NT; ++nj) {
@@ -385,7 +389,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
                 for (int s = 0; s < NSTEP; ++s)
 #pragma unroll
                     for (int q = 0; q < CPL; ++q) {
-                        const int m = m0 + wm * WTM + s * SROWS + crow + 8 * q;
+                        const int m = m0 + wm * WTM + s * SROWS + crow + RPP * q;
                         yv[s][q] = *reinterpret_cast<const bf16x8*>(by + ((unsigned)(m < a.M ? m : 0) * (unsigned)a.K + (unsigned)(colw + cseg * 8)));
                     }
             }
@@ -418,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int q = 0; q < CPL; ++q) {
-                    const int row = crow + 8 * q;
+                    const int row = crow + RPP * q;
                     const int m = m0 + wm * WTM + s * SROWS + row;
                     bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + row * SROW_B + cseg * 16);
                     if constexpr (EPI == 2) {
@@ -437,12 +441,12 @@ __global__ __launch_bounds__(512, 2) void conv_hdmap_k(IgemmArgs a, const void* 
             }
             if (a.stats) {
                 if constexpr (EPI == 2) {
-                    // lanes with the same segment (lane & 7) hold partial sums of the same 8 channels: combine over lane >> 3
+                    // lanes with the same segment (lane % SEGS) hold partial sums of the same 8 channels: combine over lane / SEGS
 #pragma unroll
-                    for (int off = 8; off < 64; off <<= 1)
+                    for (int off = SEGS; off < 64; off <<= 1)
 #pragma unroll
                         for (int e = 0; e < 8; ++e) { t1[e] += __shfl_xor(t1[e], off); t2[e] += __shfl_xor(t2[e], off); }
-                    if (lane < 8) {
+                    if (lane < SEGS) {
 #pragma unroll
                         for (int e = 0; e < 8; ++e) {
                             red[(wm * 2 + 0) * BN + wn * WTN + lane * 8 + e] = t1[e];
@@ -501,13 +505,13 @@ int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int 
     const long long var = lbc_opt(kOptHdmapVar) > 0 ? lbc_opt(kOptHdmapVar) : 0;       // A/B variants (plain forward only)
     unsigned long long* prof = lbc_opt(kOptHdmapProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptHdmapProf)) : nullptr;
     if ((prof || var) && mode == 0 && epi == 0) {
-#define LBC_HV(PROFv, VARv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, PROFv, VARv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof)
+#define LBC_HV(PROFv, VARv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, PROFv, VARv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, prof)
         if (prof) { if (var == 1) LBC_HV(true, 1); else if (var == 2) LBC_HV(true, 2); else if (var == 4) LBC_HV(true, 4); else if (var == 6) LBC_HV(true, 6); else LBC_HV(true, 0); }
         else      { if (var == 1) LBC_HV(false, 1); else if (var == 2) LBC_HV(false, 2); else if (var == 4) LBC_HV(false, 4); else if (var == 6) LBC_HV(false, 6); else LBC_HV(false, 0); }
 #undef LBC_HV
         return lbc_check_launch("conv_hdmap");
     }
-#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr)
+#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr)
     if (mode == 0) {
         LBC_REQUIRE(epi != 2, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
         if (epi == 1) LBC_HP(0, 1); else LBC_HP(0, 0);

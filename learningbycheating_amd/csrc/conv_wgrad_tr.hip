@@ -189,7 +189,10 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
                     af = __builtin_bit_cast(bf16x8, bits);
                 }
                 const bf16x8 bf = __builtin_shufflevector(b0, b1, 0, 1, 2, 3, 4, 5, 6, 7);
-                acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[r * 3 + s], 0, 0, 0);
+                // operands swapped: the accumulator holds the TRANSPOSED tile -- lane = P channel, registers = Q channels, four consecutive
+                // ones per register quad -- so that the slab row out[p][tap][q .. q + 3] leaves as one 16-byte store (same products, same
+                // summation order: bit-identical to the untransposed form, whose 144 four-byte stores per lane were issue-bound)
+                acc[r * 3 + s] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf, af, acc[r * 3 + s], 0, 0, 0);
             };
             const int qlane = (8 * kh + (t16 >> 2)) * kRS + 32 * wq + 16 * G1 + (t16 & 3) * 4;
 #pragma unroll
@@ -238,13 +241,14 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
     }
 
     float* out = a.partial + (size_t)split * (size_t)a.CP * 9 * (size_t)a.CQ;
+    const int prow = p0 + 32 * wp + l31;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int prow = p0 + 32 * wp + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            const int qcol = q0 + 32 * wq + l31;
-            out[((size_t)prow * 9 + (size_t)t) * (size_t)a.CQ + (size_t)qcol] = acc[t][e];
+        for (int k = 0; k < 4; ++k) {
+            const int qcol = q0 + 32 * wq + 8 * k + 4 * kh;
+            *reinterpret_cast<f32x4*>(out + (((size_t)prow * 9 + (size_t)t) * (size_t)a.CQ + (size_t)qcol)) =
+                f32x4{acc[t][4 * k], acc[t][4 * k + 1], acc[t][4 * k + 2], acc[t][4 * k + 3]};
         }
 }
 

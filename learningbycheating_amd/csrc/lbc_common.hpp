@@ -158,7 +158,7 @@ int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
 constexpr int kLbcGldsCfgs = 5;
 constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 persistent (C = K = 64)}
-constexpr int kLbcHdmaCfgs = 4;
+constexpr int kLbcHdmaCfgs = 5;                             // ... 4: 128 x 64, four waves, two workgroups per CU (launches with few rows)
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);

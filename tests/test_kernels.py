@@ -411,9 +411,9 @@ def early_reads_checked(dev):
 
 
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
-HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64)
+HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256, 4: 128}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves)
 HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
-              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2),
+              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2), (3, 10, 24, 128, 128, 4), (2, 5, 12, 192, 256, 4), (1, 9, 27, 64, 192, 4),
               (2, 9, 17, 64, 64, 3), (5, 12, 40, 64, 64, 3), (1, 7, 96, 64, 64, 3)]       # the last three: several tiles per persistent workgroup needs LBC_HALO_BLOCKS-like forcing on the GPU only
 HDMA_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, -1), (64, 10, 24, 256, 256, -1), (256, 5, 12, 512, 512, -1),
                                                    (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 0),
@@ -453,13 +453,13 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     yy = F.conv2d(xg, rbf(w), None, 1, 1)
     dy = rbf(torch.randn(yy.shape, generator=g))
     yy.backward(dy)
-    if K % 64 == 0 and (C % 128 == 0 or C == K == 64):        # the input gradient's output channels are C: needs a column tile of 128 / 256 (or the 64-channel kernel)
+    if K % 64 == 0 and (C % 128 == 0 or C == K == 64 or (cfgid == 4 and C % 64 == 0)):        # the input gradient's output channels are C: needs a column tile of 128 / 256 (64 for the four-wave shape or the 64-channel kernel)
         rr = rbf(torch.randn(x.shape, generator=g))
         dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
         assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
     # BatchNorm(+ReLU) of the producer on load: an in-place transform of the staged halo (LBC_HDMA_PROLOGUE=1), against the reference
     # and against the register-staged kernel (same rounding points: f32 affine of the bf16 input, rounded to bf16 once)
-    if not (C == 64 and K == 64):
+    if not (C == 64 and K == 64) and cfgid != 4:          # (the four-wave persistent shape has no on-load transform)
         ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
         xin = rbf(F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)))
         refp = F.conv2d(xin, rbf(w), None, 1, 1)
@@ -473,7 +473,7 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     # LBC_HDMA_EARLY=1 (fragment reads issued a full depth step ahead, hand-counted lgkmcnt waits): the same MFMAs in the same
     # order -> bit-identical.  On the GPU only when asked for (LBC_TEST_EXPERIMENTAL=1) until the variant has been run on hardware:
     # the emulator checks its address pipeline, not its wait counts.
-    if cfgid != 3 and early_reads_checked(dev):
+    if cfgid not in (3, 4) and early_reads_checked(dev):
         lbc_config("LBC_HDMA_EARLY", 1)
         ye, ste = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
         assert torch.equal(ye, y) and torch.equal(ste, st)
@@ -485,9 +485,11 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     # several tiles (halo and weight prefetch across the tile boundary, wave-private copy-out, stores in flight under the next
     # tile) -- and the one-tile-per-workgroup kernel (conv_hdma_k): same MFMAs in the same order, same order of the statistics
     # sums -> bit-identical outputs and statistics rows
-    if cfgid in (1, 2):
-        have_dx = K % 64 == 0 and C % 128 == 0
+    if cfgid in (1, 2, 4):
+        have_dx = K % 64 == 0 and (C % 128 == 0 or (cfgid == 4 and C % 64 == 0))
         for opt, val in (("LBC_HDMA_PERSIST_WGS", 1), ("LBC_HDMA_PERSIST_WGS", 2), ("LBC_NO_HDMA_PERSIST", 1)):
+            if cfgid == 4 and opt == "LBC_NO_HDMA_PERSIST":
+                continue                  # (the four-wave shape exists in the persistent form only)
             lbc_config(opt, val)
             yb, stb = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
             assert torch.equal(yb, y) and torch.equal(stb, st), (opt, val)
