@@ -42,13 +42,15 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p)
 // per wave: [0] K-tiles, [1] cycles in the three leading depth steps, [2] in the vmcnt wait, [3] in lgkmcnt(0) + barrier, [4] in the
 // tail (step-0 reads of the next K-tile, last depth step, DMA issue), [5] in epilogues, [6] whole stream, [7] tiles
 template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, bool PROF = false, int VAR = 0>
-__global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
+__global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
     constexpr int NW = WM * WN;                                 // waves per workgroup: 8 (256 x 128 / 128 x 256 tiles, one workgroup per CU) or
                                                                 // 4 (128 x 64 tiles for launches with few rows: two workgroups per CU)
-    static_assert((NW == 8 || NW == 4) && (NT == 2 || NT == 1) && MT == 2, "conv_hdmap: wave tiling");
+    // (MT = 4 with four waves: ONE wave per SIMD with a 128 x 64 tile and the whole register file -- 32 MFMAs per K-tile barrier, 24
+    //  fragment reads, no second wave competing for the matrix pipe)
+    static_assert((NW == 8 || NW == 4) && (NT == 2 || NT == 1) && (MT == 2 || MT == 4), "conv_hdmap: wave tiling");
     static_assert(HRMAX % (8 * NW) == 0 && BN % (8 * NW) == 0 && (SROWS == 8 || SROWS == 16), "conv_hdmap: staging");
     constexpr int NB = 3;                                       // weight ring depth: slot of K-tile (slab, tap) = tap % 3 (9 taps per slab)
     constexpr bool PRIO = (VAR & 1) != 0;                       // A/B variants: 1 = priority alternation, 2 = DMA pieces in the tail (one burst), 4 = reads interleaved with the MFMAs
@@ -66,7 +68,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
     constexpr int HPW = HRMAX / (8 * NW);                       // 1-KiB halo pieces (8 rows) per wave per slab
     constexpr int NBW = BN / (8 * NW);                          // 1-KiB weight pieces per wave per K-tile
     constexpr int ATAPS = 7;                                    // taps of a slab whose issue slot may carry halo pieces of the next slab
-    static_assert(HPW <= ATAPS, "conv_hdmap: one halo piece per tap");
+    constexpr int PPT = (HPW + ATAPS - 1) / ATAPS;              // halo pieces of the next slab requested per tap (taps 0 .. ATAPS - 1)
+    static_assert(PPT >= 1 && PPT <= 2, "conv_hdmap: halo pieces per tap");
     constexpr int NSTEP = WTM / SROWS;                          // copy-out steps per wave and tile
     constexpr int SEGS = WTN / 8;                               // 16-byte segments per staged row
     constexpr int CPL = SROWS * SEGS / 64;                      // 16-byte chunks per lane and step
@@ -186,12 +189,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
     };
 
     bf16x8 fa[2][MT], fb[2][NT];            // two register sets: depth step g computes from set g & 1 while set (g + 1) & 1 is read
+    // ASMRD (VAR & 8): the fragment reads are inline asm the compiler does not track, waited for with hand-counted lgkmcnt.  With LDS-DMA
+    // in flight hipcc's own wait insertion puts `s_waitcnt lgkmcnt(0)` in front of every depth step's MFMAs -- which also waits for the
+    // reads of the NEXT step issued just before it: a full LDS latency per depth step that only the SIMD's other wave can cover.  Here
+    // the wait in front of step g leaves the MT + NT youngest reads (step g + 1) in flight; LBC_USE (an empty asm the MFMAs depend on)
+    // keeps the MFMAs behind that wait.
+    constexpr bool ASMRD = (VAR & 8) != 0 && NB * TILE_B + (NT - 1) * 4096 < 65536;
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+#ifdef LBC_HIP_EMULATED_FOR_TESTS
+#define LBC_RD1(DST, ADDR, OFF) DST = *reinterpret_cast<const bf16x8*>(smem + (ADDR) + (OFF))
+#define LBC_USE(SET) do { } while (0)
+#else
+#define LBC_RD1(DST, ADDR, OFF)                                                                                                  \
+    do {                                                                                                                         \
+        if constexpr (ASMRD) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(lds0 + (unsigned)(ADDR)), "n"(OFF)); \
+        else DST = *reinterpret_cast<const bf16x8*>(smem + (ADDR) + (OFF));                                                      \
+    } while (0)
+#define LBC_USE(SET)                                                                                                             \
+    do {                                                                                                                         \
+        if constexpr (ASMRD) {                                                                                                   \
+            _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[SET][i]));                                  \
+            _Pragma("unroll") for (int j = 0; j < NT; ++j) asm volatile("" : "+v"(fb[SET][j]));                                  \
+        }                                                                                                                        \
+    } while (0)
+#endif
+    // all but the MT + NT youngest LDS reads of this wave have returned (ASMRD: fragment reads are the only LGKM traffic of the K loop)
+#define LBC_WAIT_OLDER_READS() do { if constexpr (ASMRD) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, MT + NT)); } while (0)
 #define LBC_RD(SLOT, G, SET)                                                                                                     \
     do {                                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
-            fa[SET][i] = *reinterpret_cast<const bf16x8*>(smem + (aaddr[i] ^ (32 * (G))));                                       \
-        _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                           \
-            fb[SET][j] = *reinterpret_cast<const bf16x8*>(smem + (SLOT) * TILE_B + j * 32 * 128 + (baddr ^ (32 * (G))));         \
+        _Pragma("unroll") for (int i = 0; i < MT; ++i) LBC_RD1(fa[SET][i], aaddr[i] ^ (32 * (G)), 0);                            \
+        if constexpr (NT == 2) { LBC_RD1(fb[SET][0], baddr ^ (32 * (G)), (SLOT) * TILE_B); LBC_RD1(fb[SET][NT - 1], baddr ^ (32 * (G)), (SLOT) * TILE_B + 4096); } \
+        else LBC_RD1(fb[SET][0], baddr ^ (32 * (G)), (SLOT) * TILE_B);                                                           \
     } while (0)
 #define LBC_MM(SET)                                                                                                              \
     do {                                                                                                                         \
@@ -202,15 +230,15 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
 
     // s_waitcnt vmcnt(n) for the handful of counts the stream produces (the immediate must be a constant)
     auto wait_vm = [&](const int n) {
-        if (n == 0) LBC_WAIT_VM(0);
-        else if (n == NBW) LBC_WAIT_VM(NBW);
-        else if (n == NBW + 1) LBC_WAIT_VM(NBW + 1);
-        else if (n == NBW + 2) LBC_WAIT_VM(NBW + 2);
-        else if (n == NST) LBC_WAIT_VM(NST);
-        else if (n == NBW + NST) LBC_WAIT_VM(NBW + NST);
-        else if (n == NBW + NST + 1) LBC_WAIT_VM(NBW + NST + 1);
-        else LBC_WAIT_VM(0);
+        switch (n) {
+#define LBC_WV(N) case N: LBC_WAIT_VM(N); break;
+            LBC_WV(1) LBC_WV(2) LBC_WV(3) LBC_WV(4) LBC_WV(5) LBC_WV(6) LBC_WV(7) LBC_WV(8) LBC_WV(9) LBC_WV(10) LBC_WV(11) LBC_WV(12)
+            LBC_WV(13) LBC_WV(14) LBC_WV(15) LBC_WV(16) LBC_WV(17) LBC_WV(18) LBC_WV(19) LBC_WV(20) LBC_WV(21) LBC_WV(22) LBC_WV(23) LBC_WV(24)
+#undef LBC_WV
+            default: LBC_WAIT_VM(0); break;      // (0, and anything unforeseen: wait for everything)
+        }
     };
+    static_assert(NBW + 2 * PPT + NST <= 24, "conv_hdmap: counted waits");
 
     // ---- the tile stream
     int tile = first;
@@ -252,11 +280,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
             const int buf = sg & 1;
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
-                constexpr int dummy = 0; (void)dummy;
                 const int slot = t % 3, nslot = (t + 1) % 3, islot = (t + 2) % 3;
                 const bool has_next = t < 8 || follows;
                 const bool w2 = t + 2 < 9 || follows;                          // K-tile k + 2 exists
-                const bool hp = t < HPW && follows;                            // this K-tile requests a halo piece of the next slab
+                const int np_here = (t * PPT < HPW ? (HPW - t * PPT < PPT ? HPW - t * PPT : PPT) : 0);            // halo pieces of the next slab requested here
+                const int np_prev = t >= 1 ? ((t - 1) * PPT < HPW ? (HPW - (t - 1) * PPT < PPT ? HPW - (t - 1) * PPT : PPT) : 0) : 0;
+                const bool hp = np_here > 0 && follows;
                 // DMA requests of this K-tile: K-tile k + 2's weight tile -> ring slot (t + 2) % 3 (read last by K-tile k - 1: free since
                 // that K-tile's barrier), piece by piece; then the halo piece
                 auto issue_w = [&](const int j0, const int j1) {
@@ -268,8 +297,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
                 };
                 auto issue_h = [&]() {
                     if (!hp) return;
-                    if (!LAST) issue_a(m0, c + 1, buf ^ 1, t);
-                    else issue_a(m0n, 0, buf ^ 1, t);
+#pragma unroll
+                    for (int q = 0; q < PPT; ++q)
+                        if (t * PPT + q < HPW) {
+                            if (!LAST) issue_a(m0, c + 1, buf ^ 1, t * PPT + q);
+                            else issue_a(m0n, 0, buf ^ 1, t * PPT + q);
+                        }
                 };
 #pragma unroll
                 for (int g = 0; g + 1 < KS; ++g) {
@@ -288,6 +321,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
                         else if (g == 1) issue_w(NBW / 2, NBW);
                         else issue_h();
                     }
+                    LBC_WAIT_OLDER_READS();                              // set g & 1 is in (its reads were issued a full step ago)
+                    LBC_USE(g & 1);
                     LBC_MM(g & 1);
                     if (VAR & 4) {
 #pragma unroll
@@ -311,8 +346,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
                     if (VAR & 2) {      // burst variant: the requests of K-tile k - 1 came after its wait: [halo piece][weight tile k + 1] -> all landed
                         n = (c == 0 && t == 0 && stores_pending) ? NST : 0;
                     } else if (w2) {
-                        const bool hp_prev = t >= 1 && t - 1 < HPW && follows;
-                        n = NBW + (hp_prev ? 1 : 0) + (hp ? 1 : 0);
+                        n = NBW + (follows ? np_prev + np_here : 0);
                         if (c == 0 && t == 0 && stores_pending) n += NST;
                     }
                     wait_vm(n);
@@ -326,6 +360,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
                     if (((KS - 1) & 1) == upper) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 }
                 if (has_next) LBC_RD(nslot, 0, 0);
+                LBC_USE((KS - 1) & 1);                                   // in since the lgkmcnt(0) in front of the barrier
                 LBC_MM((KS - 1) & 1);
                 if (VAR & 2) {          // everything in one burst behind the barrier: K-tile k + 1's successor is K-tile k + 2 -> slot (t + 2) % 3
                     issue_h();
@@ -493,6 +528,9 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_hdmap_k(IgemmArgs a, con
     }
 #undef LBC_NOW
 #undef LBC_RD
+#undef LBC_RD1
+#undef LBC_USE
+#undef LBC_WAIT_OLDER_READS
 #undef LBC_MM
 }
 #undef LBC_SG
@@ -502,16 +540,17 @@ template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
 int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, dim3 grid, hipStream_t s)
 {
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
-    const long long var = lbc_opt(kOptHdmapVar) > 0 ? lbc_opt(kOptHdmapVar) : 0;       // A/B variants (plain forward only)
+    // A/B variants (plain forward only); 16 = the shipped schedule with compiler-managed fragment reads instead of the asm ones
+    const long long var = lbc_opt(kOptHdmapVar) > 0 ? lbc_opt(kOptHdmapVar) : 0;
     unsigned long long* prof = lbc_opt(kOptHdmapProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptHdmapProf)) : nullptr;
     if ((prof || var) && mode == 0 && epi == 0) {
 #define LBC_HV(PROFv, VARv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, PROFv, VARv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, prof)
-        if (prof) { if (var == 1) LBC_HV(true, 1); else if (var == 2) LBC_HV(true, 2); else if (var == 4) LBC_HV(true, 4); else if (var == 6) LBC_HV(true, 6); else LBC_HV(true, 0); }
-        else      { if (var == 1) LBC_HV(false, 1); else if (var == 2) LBC_HV(false, 2); else if (var == 4) LBC_HV(false, 4); else if (var == 6) LBC_HV(false, 6); else LBC_HV(false, 0); }
+        if (prof) { if (var == 16) LBC_HV(true, 0); else if (var == 2) LBC_HV(true, 2); else if (var == 4) LBC_HV(true, 4); else LBC_HV(true, 8); }
+        else      { if (var == 16) LBC_HV(false, 0); else if (var == 1) LBC_HV(false, 1); else if (var == 2) LBC_HV(false, 2); else if (var == 4) LBC_HV(false, 4); else LBC_HV(false, 8); }
 #undef LBC_HV
         return lbc_check_launch("conv_hdmap");
     }
-#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr)
+#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr)
     if (mode == 0) {
         LBC_REQUIRE(epi != 2, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
         if (epi == 1) LBC_HP(0, 1); else LBC_HP(0, 0);
