@@ -66,6 +66,18 @@ int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                      const float* pre_scale, const float* pre_shift, int pre_relu,
                      float* dw, float beta, void* workspace, lbc_stream_t stream);
 
+/* The weight gradients of n same-shaped 3x3 / stride-1 / pad-1 convolutions on bf16 tensors (d->bf16 >= 2) in ONE launch: the
+ * BasicBlock convolutions of one ResNet stage (bird_view/models/resnet.py:15-22: layer1..4 hold 6 / 7 / 11 / 5 of one shape),
+ * whose gradients autograd produces one by one behind loss.backward() (training/train_image_phase1.py:204).  dw[i][K][3][3][C] =
+ * sum_m dy[i][m][k] * x'[i][gather(m)][c]; pre_scale / pre_shift: nullptr, or n per-channel vectors (x' = relu?(x * scale + shift)).
+ * n <= 12; workspace: lbc_conv2d_wgrad_group_workspace(d, n) bytes.  lbc_conv2d_wgrad_group_supported(d): 1 when d's geometry and
+ * dtype have the grouped kernel (otherwise call lbc_conv2d_wgrad per convolution). */
+int lbc_conv2d_wgrad_group_supported(const lbc_conv_desc* d);
+size_t lbc_conv2d_wgrad_group_workspace(const lbc_conv_desc* d, int n);
+int lbc_conv2d_wgrad_group(const lbc_conv_desc* d, int n, const void* const* x, const void* const* dy,
+                           const float* const* pre_scale, const float* const* pre_shift, int pre_relu,
+                           float* const* dw, void* workspace, lbc_stream_t stream);
+
 /* nn.ConvTranspose2d(C,K,3,2,1,1) forward (reference bird_view/models/image.py:39,42,45;
  * birdview.py:37,40,43).  x[N,H,W,C] -> y[N,2H,2W,K]; d->KH=KW=3, S=2, P=1 required. */
 int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const void* w, const float* bias,

@@ -53,6 +53,9 @@ _SIGNATURES = {
     "lbc_conv2d_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "lbc_deconv3x3s2_fwd": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 5 + [c_int, c_void_p, c_void_p, ctypes.POINTER(c_int), c_void_p]),
     "lbc_deconv3x3s2_dgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4),
+    "lbc_conv2d_wgrad_group_supported": (c_int, [ctypes.POINTER(ConvDesc)]),
+    "lbc_conv2d_wgrad_group_workspace": (c_size_t, [ctypes.POINTER(ConvDesc), c_int]),
+    "lbc_conv2d_wgrad_group": (c_int, [ctypes.POINTER(ConvDesc), c_int] + [c_void_p] * 4 + [c_int, c_void_p, c_void_p, c_void_p]),
     "lbc_deconv3x3s2_wgrad_workspace": (c_size_t, [ctypes.POINTER(ConvDesc)]),
     "lbc_deconv3x3s2_wgrad": (c_int, [ctypes.POINTER(ConvDesc)] + [c_void_p] * 4 + [c_int, c_void_p, c_float, c_void_p, c_void_p]),
     "lbc_net_create": (c_int, [ctypes.POINTER(NetDesc), ctypes.POINTER(c_void_p)]),

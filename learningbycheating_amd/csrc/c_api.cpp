@@ -166,6 +166,46 @@ int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
     return lbc_splitk_reduce(a.partial, a.nsplit, (long long)a.CP * a.KH * a.KW * a.CQ, dw, beta, (hipStream_t)stream);
 }
 
+// n same-shaped 3x3 / stride-1 convolutions on bf16 tensors in one launch (+ one reduce launch)
+int lbc_conv2d_wgrad_group_supported(const lbc_conv_desc* d)
+{
+    if (!d) return 0;
+    WgradArgs a = conv_wgrad_args(d);
+    a.p = d; a.q = d;     // (eligibility looks at geometry and flags only)
+    return lbc_wgrad_tr_eligible(a) ? 1 : 0;
+}
+
+size_t lbc_conv2d_wgrad_group_workspace(const lbc_conv_desc* d, int n)
+{
+    if (!d || n < 1 || !lbc_conv2d_wgrad_group_supported(d)) return 0;
+    WgradArgs a = conv_wgrad_args(d);
+    return (size_t)lbc_wgrad_tr_group_split(a, n) * n * (size_t)a.CP * 9 * (size_t)a.CQ * sizeof(float);
+}
+
+int lbc_conv2d_wgrad_group(const lbc_conv_desc* d, int n, const void* const* x, const void* const* dy,
+                           const float* const* pre_scale, const float* const* pre_shift, int pre_relu,
+                           float* const* dw, void* workspace, lbc_stream_t stream)
+{
+    LBC_REQUIRE(d && x && dy && dw && workspace && n >= 1 && n <= kLbcWgradGroupMax, "conv2d_wgrad_group: null argument or group size %d outside [1,%d]", n, kLbcWgradGroupMax);
+    LBC_REQUIRE(lbc_conv2d_wgrad_group_supported(d), "conv2d_wgrad_group: 3x3 / stride 1 / pad 1 on bf16 tensors (bf16 mode >= 2), channels multiples of 64");
+    WgradArgs a = conv_wgrad_args(d);
+    a.nsplit = lbc_wgrad_tr_group_split(a, n);
+    a.q_relu = pre_relu;
+    const size_t count = (size_t)a.CP * 9 * (size_t)a.CQ;
+    WgradGroup g;
+    memset(&g, 0, sizeof(g));
+    g.n = n;
+    for (int i = 0; i < n; ++i) {
+        g.p[i] = dy[i]; g.q[i] = x[i];
+        g.q_scale[i] = pre_scale ? pre_scale[i] : nullptr; g.q_shift[i] = pre_shift ? pre_shift[i] : nullptr;
+        g.out[i] = a.nsplit == 1 ? dw[i] : (float*)workspace + (size_t)i * a.nsplit * count;
+    }
+    a.q_scale = g.q_scale[0]; a.q_shift = g.q_shift[0];
+    const int rc = lbc_wgrad_tr_group_launch(a, g, (hipStream_t)stream);
+    if (rc || a.nsplit == 1) return rc;
+    return lbc_splitk_reduce_group((const float*)workspace, a.nsplit, (long long)count, n, dw, (hipStream_t)stream);
+}
+
 // ConvTranspose2d wgrad: dw[c][kh][kw][k] = sum x'[n,iy,ix,c] * dy[n,2iy-1+kh,2ix-1+kw,k]
 // == Conv2d wgrad with P-side = x (dense rows) and Q-side = dy gathered with stride 2.
 static WgradArgs deconv_wgrad_args(const lbc_conv_desc* d)

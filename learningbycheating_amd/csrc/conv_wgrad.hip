@@ -20,6 +20,7 @@
 #include "lbc_act.hpp"
 #include <type_traits>
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -418,8 +419,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_k(WgradArgs a, int rows_p
 // partial sums are combined through LDS in a fixed order (deterministic).  G > 1 keeps the chip busy when the result
 // is small and the slab count large (layer1 at small batch: 147 KB result, > 100 slabs).
 template <int G>
-__global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict__ partial, int nsplit, long long count4,
-                                                         float* __restrict__ out, float beta)
+__device__ __forceinline__ void splitk_reduce_body(const float* __restrict__ partial, int nsplit, long long count4, float* __restrict__ out, float beta)
 {
     constexpr int E = 256 / G;
     __shared__ __attribute__((aligned(16))) f32x4 red[256];
@@ -449,6 +449,21 @@ __global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict
         if (beta != 0.f) s += beta * *o;
         *o = s;
     }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_f32(const float* __restrict__ partial, int nsplit, long long count4,
+                                                         float* __restrict__ out, float beta)
+{
+    splitk_reduce_body<G>(partial, nsplit, count4, out, beta);
+}
+
+// blockIdx.y = member of a grouped weight-gradient launch: its slabs lie at partial + member * nsplit * count
+struct SplitkOuts { float* out[kLbcWgradGroupMax]; };
+template <int G>
+__global__ __launch_bounds__(256) void splitk_reduce_group_f32(const float* __restrict__ partial, int nsplit, long long count4, SplitkOuts outs)
+{
+    splitk_reduce_body<G>(partial + (size_t)blockIdx.y * (size_t)nsplit * (size_t)count4 * 4, nsplit, count4, outs.out[blockIdx.y], 0.f);
 }
 
 // 128x128 tiles when the channel counts allow and the reduction is long enough to amortise them; short reductions
@@ -487,10 +502,7 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "wgrad: bf16 operands need bf16 = 1");
     const long long M = (long long)a.N * a.OH * a.OW;
     LBC_REQUIRE(M > 0 && M * a.CP < (1ll << 31) && (long long)a.N * a.H * a.W * a.CQ < (1ll << 31), "wgrad: bad tensor size");
-    if (lbc_wgrad_tr_eligible(a)) {
-        LbcProfScope prof("conv_wgrad_tr", 2.0 * M * a.CP * (double)a.CQ * 9, 2.0 * ((double)M * a.CP + (double)M * a.CQ) + 4.0 * (double)a.nsplit * a.CP * 9 * a.CQ, s);
-        return lbc_wgrad_tr_launch(a, s);
-    }
+    if (lbc_wgrad_tr_eligible(a)) return lbc_wgrad_tr_launch(a, s);
     const int br = a.bf16 ? 64 : BR;
     const long long chunks = (M + br - 1) / br;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * br;
@@ -534,4 +546,25 @@ int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* 
         default: hipLaunchKernelGGL(splitk_reduce_f32<16>, dim3(blocks), dim3(256), 0, s, partial, nsplit, c4, out, beta); break;
     }
     return lbc_check_launch("splitk_reduce_f32");
+}
+
+int lbc_splitk_reduce_group(const float* partial, int nsplit, long long count, int n, float* const* out, hipStream_t s)
+{
+    LBC_REQUIRE(count % 4 == 0 && n >= 1 && n <= kLbcWgradGroupMax, "splitk_reduce_group: count %lld, %d members", count, n);
+    const long long c4 = count / 4;
+    SplitkOuts o;
+    memset(&o, 0, sizeof(o));
+    for (int i = 0; i < n; ++i) o.out[i] = out[i];
+    int G = 1;
+    while (G < 16 && c4 * G * n < 512 * 256 && 4 * G <= nsplit) G *= 2;
+    const dim3 grid((unsigned)((c4 * G + 255) / 256), (unsigned)n);
+    LbcProfScope prof("splitk_reduce", 0.0, 4.0 * (double)count * (nsplit + 1) * n, s);
+    switch (G) {
+        case 1: hipLaunchKernelGGL(splitk_reduce_group_f32<1>, grid, dim3(256), 0, s, partial, nsplit, c4, o); break;
+        case 2: hipLaunchKernelGGL(splitk_reduce_group_f32<2>, grid, dim3(256), 0, s, partial, nsplit, c4, o); break;
+        case 4: hipLaunchKernelGGL(splitk_reduce_group_f32<4>, grid, dim3(256), 0, s, partial, nsplit, c4, o); break;
+        case 8: hipLaunchKernelGGL(splitk_reduce_group_f32<8>, grid, dim3(256), 0, s, partial, nsplit, c4, o); break;
+        default: hipLaunchKernelGGL(splitk_reduce_group_f32<16>, grid, dim3(256), 0, s, partial, nsplit, c4, o); break;
+    }
+    return lbc_check_launch("splitk_reduce_group_f32");
 }

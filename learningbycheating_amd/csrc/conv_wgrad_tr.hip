@@ -16,10 +16,13 @@
 //   * out-of-image taps are removed on the P fragment: with W % 8 == 0 a lane's 8-pixel group lies in one image row, so
 //     a tap is either invalid for the whole group (top / bottom row) or for its first / last pixel (left / right column);
 //     other widths (the 5 x 12 maps of layer 4) build per-pixel keep-masks for the four border classes;
-//   * one barrier per chunk, 36 MFMAs per wave between barriers, two workgroups per CU.
+//   * one barrier per chunk, 36 MFMAs per wave between barriers, two workgroups per CU;
+//   * a launch covers n same-shaped convolutions (WgradGroup: a ResNet stage's): the ~512 workgroups a launch needs come from
+//     n x tiles x splits, so the pixel range is split n times less -- n times fewer partial tiles to write and to reduce.
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -34,7 +37,7 @@ constexpr int kRingNarrow = 232, kRsNarrow = 96;  // W <= 48
 // ALIGN = 4: W % 4 == 0 (the 5 x 12 maps of layer 4): the same per 4-pixel half of the group (the second half may sit in
 // the next row).  ALIGN = 0: any W >= 8, every pixel gets its own flags.
 template <int ALIGN, int kRS, int kRing>
-__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_per_split)
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, WgradGroup grp, int rows_per_split)
 {
     constexpr int BRH = 64;
     __shared__ __attribute__((aligned(16))) __bf16 sP[2][BRH * kRS];
@@ -50,20 +53,22 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
     const int HRW = BRH + 2 * W + 2;                  // live halo rows of a chunk
     const int qtiles = a.CQ / 64;
     const int ntiles = (a.CP / 64) * qtiles;
-    const int tile = blockIdx.x % ntiles, split = blockIdx.x / ntiles;
+    // workgroup -> (tile, member, split), tile fastest: the tiles of one (member, split) share their pixel range through L2
+    const int tile = blockIdx.x % ntiles;
+    const int member = (blockIdx.x / ntiles) % grp.n, split = blockIdx.x / (ntiles * grp.n);
     const int tp = tile / qtiles, tq = tile - tp * qtiles;
     const int p0 = tp * 64, q0 = tq * 64;
     const int mbeg = split * rows_per_split;
     const int mend = (mbeg + rows_per_split < M) ? mbeg + rows_per_split : M;
     const int nchunk = (mend > mbeg) ? (mend - mbeg + BRH - 1) / BRH : 0;
     const int qorg = mbeg - W - 1;                    // pixel held by ring row 0 (before wrapping)
-    const __bf16* pin = static_cast<const __bf16*>(a.p);
-    const __bf16* qin = static_cast<const __bf16*>(a.q);
+    const __bf16* pin = static_cast<const __bf16*>(grp.p[member]);
+    const __bf16* qin = static_cast<const __bf16*>(grp.q[member]);
 
     const int seg = tid & 7, srow = tid >> 3;         // staging: 16-byte segment (8 channels), row (+32 per pass)
     const float relu_floor = (a.q_scale && a.q_relu) ? 0.f : -INFINITY;
     f32x8 qsc = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f}, qsh = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    if (a.q_scale) { qsc = ParamVec<8>::ld(a.q_scale + q0 + seg * 8); qsh = ParamVec<8>::ld(a.q_shift + q0 + seg * 8); }
+    if (a.q_scale) { qsc = ParamVec<8>::ld(grp.q_scale[member] + q0 + seg * 8); qsh = ParamVec<8>::ld(grp.q_shift[member] + q0 + seg * 8); }
 
     f32x16 acc[9];
 #pragma unroll
@@ -240,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, int rows_
         __syncthreads();
     }
 
-    float* out = a.partial + (size_t)split * (size_t)a.CP * 9 * (size_t)a.CQ;
+    float* out = grp.out[member] + (size_t)split * (size_t)a.CP * 9 * (size_t)a.CQ;
     const int prow = p0 + 32 * wp + l31;
 #pragma unroll
     for (int t = 0; t < 9; ++t)
@@ -275,19 +280,54 @@ int lbc_wgrad_tr_pick_split(const WgradArgs& a)
     return (int)ns;
 }
 
+// Splits of a grouped launch: the slots are 2 workgroups x 256 CUs, workgroups of one launch take the same time, so the launch
+// lasts ceil(workgroups / slots) rounds of (chunks per split + ~6 chunks of halo prologue and slab stores).  The smallest split count
+// within 2 % of the best: fewer slabs for the same time.
+int lbc_wgrad_tr_group_split(const WgradArgs& a, int n)
+{
+    if (n <= 1) return lbc_wgrad_tr_pick_split(a);
+    const long long slots = lbc_opt(kOptWgradTrBlocks) > 0 ? lbc_opt(kOptWgradTrBlocks) : 512;
+    const long long tiles = (long long)(a.CP / 64) * (a.CQ / 64) * n;
+    const long long chunks = ((long long)a.N * a.H * a.W + 63) / 64;
+    long long maxns = chunks / 8 > 0 ? chunks / 8 : 1;
+    if (maxns > 1024) maxns = 1024;
+    auto cost = [&](long long ns) { return (double)((tiles * ns + slots - 1) / slots) * ((double)((chunks + ns - 1) / ns) + 6.0); };
+    double best = cost(1);
+    for (long long ns = 2; ns <= maxns; ++ns) best = cost(ns) < best ? cost(ns) : best;
+    for (long long ns = 1; ns <= maxns; ++ns)
+        if (cost(ns) <= 1.02 * best) return (int)ns;
+    return 1;
+}
+
 int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s)
 {
+    WgradGroup g;
+    memset(&g, 0, sizeof(g));
+    g.n = 1; g.p[0] = a.p; g.q[0] = a.q; g.q_scale[0] = a.q_scale; g.q_shift[0] = a.q_shift; g.out[0] = a.partial;
+    return lbc_wgrad_tr_group_launch(a, g, s);
+}
+
+int lbc_wgrad_tr_group_launch(const WgradArgs& a0, const WgradGroup& g, hipStream_t s)
+{
+    LBC_REQUIRE(g.n >= 1 && g.n <= kLbcWgradGroupMax, "wgrad_tr: group of %d", g.n);
+    WgradArgs a = a0;
+    a.p = g.p[0]; a.q = g.q[0]; a.q_scale = g.q_scale[0]; a.q_shift = g.q_shift[0]; a.partial = g.out[0];
     LBC_REQUIRE(lbc_wgrad_tr_eligible(a), "wgrad_tr: launch not eligible");
+    for (int i = 0; i < g.n; ++i)
+        LBC_REQUIRE(g.p[i] && g.q[i] && g.out[i] && (g.q_scale[i] != nullptr) == (a.q_scale != nullptr) && (g.q_shift[i] != nullptr) == (a.q_scale != nullptr),
+                    "wgrad_tr: group member %d incomplete", i);
     const long long M = (long long)a.N * a.H * a.W;
     const long long chunks = (M + 63) / 64;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 64;
-    const unsigned blocks = (unsigned)((a.CP / 64) * (a.CQ / 64) * a.nsplit);
+    const unsigned blocks = (unsigned)((a.CP / 64) * (a.CQ / 64) * a.nsplit * g.n);
+    LbcProfScope prof("conv_wgrad_tr", g.n * 2.0 * (double)M * a.CP * (double)a.CQ * 9,
+                      g.n * (2.0 * ((double)M * a.CP + (double)M * a.CQ) + 4.0 * (double)a.nsplit * a.CP * 9 * a.CQ), s);
 #define LBC_WT(AL)                                                                                                              \
     do {                                                                                                                        \
         if (64 + 2 * a.W + 2 + 64 <= kRingNarrow)                                                                               \
-            hipLaunchKernelGGL((conv_wgrad_tr_k<AL, kRsNarrow, kRingNarrow>), dim3(blocks), dim3(256), 0, s, a, rows_per_split); \
+            hipLaunchKernelGGL((conv_wgrad_tr_k<AL, kRsNarrow, kRingNarrow>), dim3(blocks), dim3(256), 0, s, a, g, rows_per_split); \
         else                                                                                                                    \
-            hipLaunchKernelGGL((conv_wgrad_tr_k<AL, kRsWide, kRingWide>), dim3(blocks), dim3(256), 0, s, a, rows_per_split);     \
+            hipLaunchKernelGGL((conv_wgrad_tr_k<AL, kRsWide, kRingWide>), dim3(blocks), dim3(256), 0, s, a, g, rows_per_split);     \
     } while (0)
     if (a.W % 8 == 0)      LBC_WT(8);
     else if (a.W % 4 == 0) LBC_WT(4);

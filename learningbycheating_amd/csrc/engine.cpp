@@ -79,6 +79,8 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     side_allowed_ = !lbc_opt_on(kOptNoSideStream);
     bf16_ = d.precision >= 1;
     act_bf16_ = d.precision == 2;
+    defer_wgrad_ = act_bf16_ && !lbc_opt_on(kOptNoWgradDefer);
+    if (defer_wgrad_) side_allowed_ = false;      // nothing is left for a side stream: the deferred launches fill the chip by themselves
     if (bf16_) dgrad_wt_ = true;   // the bf16 tiles are [row][depth] only: every weight operand must be depth-contiguous
 
     // ---- stem (resnet.py:102-106) ----
@@ -189,6 +191,31 @@ Net::Net(const lbc_net_desc& d) : d_(d)
     for (int i = 0; i < 3; ++i)
         wg = std::max(wg, wg_need((int)NB, dec_[i].H, dec_[i].W, dec_[i].Cin, 2 * dec_[i].H, 2 * dec_[i].W, dec_[i].Cout, 3, 2, 1));
     wg = std::max(wg, (size_t)lbc_stem_wgrad_split((int)NB, H0, W0, Cin, bf16_) * 64 * 49 * Cin);
+    if (defer_wgrad_) {
+        // a stage's 3x3 / stride-1 convolutions share one shape: the slabs of their grouped launch, and one dY slot per convolution
+        for (size_t li = 0; li < stage_first_block_.size(); ++li) {
+            const size_t first = stage_first_block_[li], last = li + 1 < stage_first_block_.size() ? (size_t)stage_first_block_[li + 1] : blocks_.size();
+            size_t members = 0, dy = 0;
+            for (size_t bi = first; bi < last; ++bi) {
+                const Block& b = blocks_[bi];
+                const size_t slot = (((size_t)NB * b.c1.OH * b.c1.OW * b.c1.Cout + 1) / 2 + 63) / 64 * 64;
+                members += 1 + (b.c1.s == 1 ? 1 : 0);
+                dy += (b.has_ds ? 3 : 2) * slot;
+            }
+            const Conv& c = blocks_[last - 1].c2;
+            WgradArgs a;
+            memset(&a, 0, sizeof(a));
+            a.N = (int)NB; a.OH = c.OH; a.OW = c.OW; a.CP = c.Cout; a.H = c.H; a.W = c.W; a.CQ = c.Cin; a.KH = 3; a.KW = 3; a.S = 1; a.P = 1;
+            a.bf16 = 1; a.act_bf16 = 1; a.p = &a; a.q = &a;
+            if (lbc_wgrad_tr_eligible(a)) {
+                // (the members split into groups by their on-load transform: any group size up to the member count can occur)
+                for (int n = 1; n <= (int)std::min(members, (size_t)kLbcWgradGroupMax); ++n)
+                    wg = std::max(wg, (size_t)lbc_wgrad_tr_group_split(a, n) * n * c.Cout * 9 * c.Cin);
+            }
+            dy_arena_floats_ = std::max(dy_arena_floats_, dy);
+        }
+        dy_arena_ = alloc(dy_arena_floats_);
+    }
     wg_partial_ = alloc(wg);
 
     wt_ = alloc((size_t)640 * 512 * 9);
@@ -614,6 +641,61 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
     return lbc_bn_bwd_apply(ap, s);
 }
 
+float* Net::dy_slot(long long elems)
+{
+    const size_t floats = ((size_t)(elems + 1) / 2 + 63) / 64 * 64;      // bf16 tensors (defer_wgrad_ implies act_bf16_)
+    if (dy_used_ + floats > dy_arena_floats_) return nullptr;
+    float* p = W(dy_arena_) + dy_used_;
+    dy_used_ += floats;
+    return p;
+}
+
+// The stage's pending weight gradients: same-shaped 3x3 / stride-1 convolutions in grouped launches, the rest (the stage's first
+// stride-2 convolution, its 1x1 downsample) one by one.
+int Net::flush_wgrads(int N, hipStream_t s)
+{
+    std::vector<char> done(pending_.size(), 0);
+    for (size_t i = 0; i < pending_.size(); ++i) {
+        if (done[i]) continue;
+        const PendingWgrad& pi = pending_[i];
+        const Conv& c = *pi.c;
+        WgradArgs a;
+        memset(&a, 0, sizeof(a));
+        a.p = pi.dy; a.q = pi.x;
+        if (pi.pre) { a.q_scale = W(pi.pre->scale); a.q_shift = W(pi.pre->shift); a.q_relu = 1; }
+        a.bf16 = bf16_; a.act_bf16 = act_bf16_;
+        a.N = N; a.OH = c.OH; a.OW = c.OW; a.CP = c.Cout; a.H = c.H; a.W = c.W; a.CQ = c.Cin;
+        a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
+        if (!lbc_wgrad_tr_eligible(a)) {
+            LBC_TRY(conv_wgrad_pre(c, pi.x, pi.pre, pi.dy, N, s));
+            done[i] = 1;
+            continue;
+        }
+        WgradGroup g;
+        memset(&g, 0, sizeof(g));
+        float* grads[kLbcWgradGroupMax];
+        for (size_t j = i; j < pending_.size() && g.n < kLbcWgradGroupMax; ++j) {
+            const PendingWgrad& pj = pending_[j];
+            const Conv& cj = *pj.c;
+            if (done[j] || cj.Cout != c.Cout || cj.Cin != c.Cin || cj.H != c.H || cj.W != c.W || cj.k != c.k || cj.s != c.s || cj.p != c.p ||
+                (pj.pre != nullptr) != (pi.pre != nullptr)) continue;
+            g.p[g.n] = pj.dy; g.q[g.n] = pj.x;
+            if (pj.pre) { g.q_scale[g.n] = W(pj.pre->scale); g.q_shift[g.n] = W(pj.pre->shift); }
+            grads[g.n] = G(cj.w);
+            ++g.n;
+            done[j] = 1;
+        }
+        a.nsplit = lbc_wgrad_tr_group_split(a, g.n);
+        const size_t count = (size_t)c.Cout * 9 * c.Cin;
+        for (int m = 0; m < g.n; ++m) g.out[m] = a.nsplit == 1 ? grads[m] : W(wg_partial_) + (size_t)m * a.nsplit * count;
+        LBC_TRY(lbc_wgrad_tr_group_launch(a, g, s));
+        if (a.nsplit > 1) LBC_TRY(lbc_splitk_reduce_group(W(wg_partial_), a.nsplit, (long long)count, g.n, grads, s));
+    }
+    pending_.clear();
+    dy_used_ = 0;
+    return LBC_OK;
+}
+
 int Net::conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s)
 {
     return conv_wgrad_pre(c, x, nullptr, dy, N, s);
@@ -682,6 +764,35 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
     const int N = lastN_;
     const long long pix = (long long)N * b.c1.OH * b.c1.OW;
     const float* xin = (&b == &blocks_.front()) ? W(p0_) : W((&b - 1)->out);
+    if (defer_wgrad_) {
+        // every dY in a slot of its own until the stage's grouped weight-gradient launches have read it (flush_wgrads)
+        float* E2 = dy_slot(pix * b.b2.C);
+        float* E1 = dy_slot(pix * b.b1.C);
+        LBC_REQUIRE(E1 && E2, "net.backward: dY arena exhausted");
+        LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E2, b.b2.C, s, nullptr, false));   // E2 = dY2
+        int fr = 0;
+        LBC_TRY(conv_dgrad(b.c2, E2, nullptr, F, N, s, &b.b1, W(b.c1.y), &fr));                       // F = dZ1 (masked when fr > 0)
+        if (b.fuse_z1) {
+            pending_.push_back({&b.c2, W(b.c1.y), &b.b1, E2});
+            LBC_TRY(bn_backward(b.b1, F, W(b.c1.y), F, W(b.c1.y), pix, E1, b.b1.C, s, &b.b1, false, fr));   // E1 = dY1
+        } else {
+            pending_.push_back({&b.c2, W(b.z1), nullptr, E2});
+            LBC_TRY(bn_backward(b.b1, F, W(b.z1), F, W(b.c1.y), pix, E1, b.b1.C, s, nullptr, false, fr));
+        }
+        pending_.push_back({&b.c1, xin, nullptr, E1});
+        if (!b.has_ds) {
+            LBC_TRY(conv_dgrad(b.c1, E1, D, Gbuf, N, s));                                 // G = dgrad + identity gradient
+        } else {
+            float* Fd = dy_slot(pix * b.bd.C);
+            LBC_REQUIRE(Fd, "net.backward: dY arena exhausted");
+            LBC_TRY(conv_dgrad(b.c1, E1, nullptr, Gbuf, N, s));
+            LBC_TRY(bn_backward(b.bd, D, nullptr, nullptr, W(b.ds.y), pix, Fd, b.bd.C, s));
+            pending_.push_back({&b.ds, xin, nullptr, Fd});
+            LBC_TRY(conv_dgrad(b.ds, Fd, Gbuf, Gbuf, N, s));                              // G += dgrad_1x1 (even pixels)
+        }
+        std::swap(D, Gbuf);
+        return LBC_OK;
+    }
     // Weight gradients go to the side stream (wstream), next to the input gradient that consumes the same dY.  E and F are
     // rewritten by the BatchNorm-backward apply passes / dgrads of the main stream: every apply that overwrites a buffer a
     // pending weight gradient may still read joins first (join_before_apply), every weight gradient forks after its dY exists.
@@ -718,6 +829,7 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
 int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t s)
 {
     const int rc = backward_impl(d_sel, d_all, stage, s);
+    if (rc != LBC_OK) { pending_.clear(); dy_used_ = 0; }
     if (rc != LBC_OK && side_dirty_) {
         // an early return between fork() and join(): weight gradients may still be in flight on the side stream; let them
         // finish before anything (a retry, the next forward) reuses the gradient ping-pong buffers or the split-K slabs
@@ -847,6 +959,7 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
         const int first = stage_first_block_[li];
         const int lastb = li == 3 ? (int)blocks_.size() : stage_first_block_[li + 1];
         for (int bi = lastb - 1; bi >= first; --bi) LBC_TRY(block_backward(blocks_[bi], bwd_D_, bwd_G_, E, F, s));
+        if (defer_wgrad_) LBC_TRY(flush_wgrads(N, s));
         LBC_TRY(join(s));     // the stage's gradients are complete on s (the caller all-reduces them behind an event on s)
     }
 

@@ -142,6 +142,14 @@ private:
     int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s, const BN* bnb = nullptr,
                    const float* bnb_y = nullptr, int* fused_rows = nullptr);
     int block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s);
+    // Stage-deferred weight gradients (bf16 tensors): the 3x3 weight gradients of a stage wait for the stage's last block and leave as
+    // one grouped launch per shape (lbc_wgrad_tr_group_launch); until then every dY keeps its own slot of the dy arena.
+    struct PendingWgrad { const Conv* c; const float* x; const BN* pre; const float* dy; };
+    std::vector<PendingWgrad> pending_;
+    bool defer_wgrad_ = false;
+    size_t dy_arena_ = 0, dy_arena_floats_ = 0, dy_used_ = 0;
+    float* dy_slot(long long elems);
+    int flush_wgrads(int N, hipStream_t s);
     int backward_impl(const float* d_sel, const float* d_all, int stage, hipStream_t s);
     long long generation_ = 0;
 

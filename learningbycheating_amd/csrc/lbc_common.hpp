@@ -63,6 +63,7 @@ enum LbcOpt {
     kOptHdmaPersistWgs,    // LBC_HDMA_PERSIST_WGS: cap on the persistent workgroups of conv_hdmap.hip (default 256 = one per CU; tests: fewer)
     kOptHdmapProf,         // LBC_HDMAP_PROF: device address of a u64[grid][8 waves][8] buffer -> the s_memtime-stamped build of conv_hdmap_k (diagnostic)
     kOptHdmapVar,          // LBC_HDMAP_VAR: A/B variants of conv_hdmap_k's plain forward (1 priority alternation, 2 DMA burst in the tail, 4 reads interleaved with MFMAs)
+    kOptNoWgradDefer,      // LBC_NO_WGRAD_DEFER (read when a network is created): 1 = every weight gradient launched next to its input gradient (A/B)
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptCount
 };
@@ -205,4 +206,21 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s);
 bool lbc_wgrad_tr_eligible(const WgradArgs& a);
 int lbc_wgrad_tr_pick_split(const WgradArgs& a);
 int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s);
+// The same kernel over n same-shaped convolutions in ONE launch (a ResNet stage's 3x3 convolutions: 6 / 7 / 11 / 5 of them).  A launch
+// wants ~512 workgroups whatever it computes and every workgroup leaves a 64 x 9 x 64 f32 partial tile: one launch per convolution
+// writes (and splitk_reduce re-reads) 75 MB of slabs per convolution; the grouped launch splits the pixel range n times less.
+// `a` carries the geometry, the transform flags (q_scale != nullptr: on) and nsplit (lbc_wgrad_tr_group_split); the tensors come from g.
+constexpr int kLbcWgradGroupMax = 12;
+struct WgradGroup {
+    int n;
+    const void* p[kLbcWgradGroupMax];
+    const void* q[kLbcWgradGroupMax];
+    const float* q_scale[kLbcWgradGroupMax];
+    const float* q_shift[kLbcWgradGroupMax];
+    float* out[kLbcWgradGroupMax];      // slab 0 of member i (slab stride CP * 9 * CQ floats); the gradient itself when nsplit == 1
+};
+int lbc_wgrad_tr_group_split(const WgradArgs& a, int n);
+int lbc_wgrad_tr_group_launch(const WgradArgs& a, const WgradGroup& g, hipStream_t s);
+// out[i] = sum over the nsplit slabs at partial + i * nsplit * count, i < n (one launch)
+int lbc_splitk_reduce_group(const float* partial, int nsplit, long long count, int n, float* const* out, hipStream_t s);
 int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* out, float beta, hipStream_t s);

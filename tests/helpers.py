@@ -101,6 +101,27 @@ class Conv:
         check_guard(buf, dw.numel())
         return dw.permute(0, 3, 1, 2).contiguous().cpu()
 
+    def wgrad_group(self, xs, dys, pres=None, bf16=2):
+        """lbc_conv2d_wgrad_group over len(xs) same-shaped 3x3 / stride-1 convolutions; pres: None or [(scale, shift)] per member (ReLU on)"""
+        n = len(xs)
+        N, C, H, W = xs[0].shape
+        K = dys[0].shape[1]
+        d = self.desc(N, H, W, C, K, 3, 1, 1, 0, bf16)
+        assert self.lib.lbc_conv2d_wgrad_group_supported(ctypes.byref(d)) == 1
+        ws = torch.empty(self.lib.lbc_conv2d_wgrad_group_workspace(ctypes.byref(d), n) // 4 + 1, device=self.dev)
+        at = act_dtype(bf16)
+        xh = [nhwc(x).to(self.dev).to(at) for x in xs]
+        dyh = [nhwc(dy).to(self.dev).to(at) for dy in dys]
+        outs = [guarded((K, 3, 3, C), self.dev) for _ in range(n)]
+        ptrs = lambda ts: (ctypes.c_void_p * n)(*[_lib.ptr(t) for t in ts])
+        keep = [[p[0].to(self.dev) for p in pres], [p[1].to(self.dev) for p in pres]] if pres else None
+        _lib.check(self.lib.lbc_conv2d_wgrad_group(ctypes.byref(d), n, ptrs(xh), ptrs(dyh), ptrs(keep[0]) if pres else None,
+                                                   ptrs(keep[1]) if pres else None, 1 if pres else 0, ptrs([o[1] for o in outs]),
+                                                   _lib.ptr(ws), _lib.stream_for(xh[0])))
+        for buf, dw in outs:
+            check_guard(buf, dw.numel())
+        return [dw.permute(0, 3, 1, 2).contiguous().cpu() for _, dw in outs]
+
     def deconv_all(self, x, w, bias, pre, relu, bf16=0):
         """fwd, dgrad and wgrad of ConvTranspose2d(k3,s2,p1,op1) with BN-on-load; returns (y, stats, fn(dy)->(dx, dw))"""
         N, C, H, W = x.shape

@@ -375,6 +375,34 @@ def test_conv_wgrad_tap_fused(env, cfg):
     assert relerr(dw2, w2.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
 
 
+@pytest.mark.parametrize("cfg", [(3, 2, 5, 12, 64, 64), (5, 1, 4, 16, 64, 128), (12, 4, 16, 16, 64, 64), (2, 3, 2, 16, 128, 64)] +
+                         [pytest.param(c, marks=gpu) for c in [(5, 16, 5, 12, 512, 512), (6, 8, 40, 96, 64, 64), (7, 4, 20, 48, 128, 128), (11, 8, 10, 24, 256, 256)]])
+def test_conv_wgrad_group(env, cfg):
+    """n same-shaped convolutions in one launch (a ResNet stage's): every member's gradient, plain and with BatchNorm+ReLU on load;
+    member by member the same numbers as the single launch up to the summation order of the splits"""
+    dev, _ = env
+    n, N, H, W, C, K = cfg
+    g = torch.Generator().manual_seed(67)
+    xs = [rbf(torch.randn((N, C, H, W), generator=g)) for _ in range(n)]
+    dys = [rbf(torch.randn((N, K, H, W), generator=g)) for _ in range(n)]
+    want = []
+    for x, dy in zip(xs, dys):
+        w1 = torch.zeros((K, C, 3, 3), requires_grad=True)
+        F.conv2d(x, w1, None, 1, 1).backward(dy)
+        want.append(w1.grad)
+    got = Conv(dev).wgrad_group(xs, dys)
+    for i in range(n):
+        assert relerr(got[i], want[i]) < 1e-4, i
+    assert relerr(got[n - 1], Conv(dev).wgrad(xs[n - 1], dys[n - 1], 3, 1, 1, bf16=2)) < 1e-5
+    pres = [(torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)) for _ in range(n)]
+    got = Conv(dev).wgrad_group(xs, dys, pres=pres)
+    for i in (0, n - 1):
+        xin = F.relu(xs[i] * pres[i][0].view(1, -1, 1, 1) + pres[i][1].view(1, -1, 1, 1))
+        w2 = torch.zeros((K, C, 3, 3), requires_grad=True)
+        F.conv2d(rbf(xin), w2, None, 1, 1).backward(dys[i])
+        assert relerr(got[i], w2.grad) < 5e-4, i
+
+
 @pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 1), (1, 12, 14, 128, 256, 2), (3, 8, 10, 64, 256, 0), (2, 6, 34, 128, 128, 3), (1, 4, 6, 192, 128, 1)] +
                          [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128, -1), (64, 20, 48, 128, 256, -1), (256, 10, 24, 256, 512, -1)]])
 def test_conv_glds_stride2_transposed_phases(env, case, lbc_config):
@@ -487,7 +515,9 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     # sums -> bit-identical outputs and statistics rows
     if cfgid in (1, 2, 4):
         have_dx = K % 64 == 0 and (C % 128 == 0 or (cfgid == 4 and C % 64 == 0))
-        for opt, val in (("LBC_HDMA_PERSIST_WGS", 1), ("LBC_HDMA_PERSIST_WGS", 2), ("LBC_NO_HDMA_PERSIST", 1)):
+        # (LBC_HDMAP_VAR=16: compiler-managed fragment reads in place of the shipped inline-asm reads with hand-counted lgkmcnt waits -- same arithmetic; what it exercises, the
+        #  wait counts, exists on the GPU only)
+        for opt, val in (("LBC_HDMA_PERSIST_WGS", 1), ("LBC_HDMA_PERSIST_WGS", 2), ("LBC_NO_HDMA_PERSIST", 1), ("LBC_HDMAP_VAR", 16)):
             if cfgid == 4 and opt == "LBC_NO_HDMA_PERSIST":
                 continue                  # (the four-wave shape exists in the persistent form only)
             lbc_config(opt, val)
@@ -498,6 +528,7 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
             if have_dx:
                 assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True), dx), (opt, val)
             lbc_config(opt, -1)
+            lbc_config("LBC_HDMA_PERSIST_WGS", -1)
     # A/B: the per-tap LDS-DMA kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_HDMA", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, 1, bf16=3)
