@@ -64,6 +64,7 @@ enum LbcOpt {
     kOptHdmapProf,         // LBC_HDMAP_PROF: device address of a u64[grid][8 waves][8] buffer -> the s_memtime-stamped build of conv_hdmap_k (diagnostic)
     kOptHdmapVar,          // LBC_HDMAP_VAR: A/B variants of conv_hdmap_k's plain forward (1 priority alternation, 2 DMA burst in the tail, 4 reads interleaved with MFMAs)
     kOptNoWgradDefer,      // LBC_NO_WGRAD_DEFER (read when a network is created): 1 = every weight gradient launched next to its input gradient (A/B)
+    kOptDecoderPassMinCout, // LBC_DECODER_PASS_MIN_COUT: transposed convolutions with at least this many output channels pay a bn_apply pass for the LDS-DMA kernel (default 64: all three)
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptCount
 };

@@ -32,7 +32,7 @@ extern "C" const char* lbc_last_error(void) { return g_err; }
 namespace {
 const char* const kOptNames[kOptCount] = {
     "LBC_FORCE_CFG", "LBC_NO_HALO", "LBC_HALO_BLOCKS", "LBC_WGRAD_BIGM", "LBC_WGRAD_BLOCKS", "LBC_WGRAD_KB", "LBC_NO_WGRAD_TR",
-    "LBC_WGRAD_TR_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_FUSE_Z1", "LBC_DGRAD_WT", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256", "LBC_GEMM256_MIN_TILES", "LBC_GEMM256_CFG", "LBC_GLDS_DIAG", "LBC_GLDS_V1", "LBC_GLDS_KT", "LBC_STEM_V1", "LBC_NO_BN_BWD_FUSE", "LBC_NO_HDMA", "LBC_HDMA_CFG", "LBC_NO_HDMA64", "LBC_NO_GLDS_PHASED", "LBC_HDMA_PROLOGUE", "LBC_HDMA_EARLY", "LBC_HDMA_DIAG", "LBC_NO_HDMA_PERSIST", "LBC_HDMA_PERSIST_WGS", "LBC_HDMAP_PROF", "LBC_HDMAP_VAR", "LBC_NO_WGRAD_DEFER", "LBC_ADAM_ELEMS"};
+    "LBC_WGRAD_TR_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_FUSE_Z1", "LBC_DGRAD_WT", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256", "LBC_GEMM256_MIN_TILES", "LBC_GEMM256_CFG", "LBC_GLDS_DIAG", "LBC_GLDS_V1", "LBC_GLDS_KT", "LBC_STEM_V1", "LBC_NO_BN_BWD_FUSE", "LBC_NO_HDMA", "LBC_HDMA_CFG", "LBC_NO_HDMA64", "LBC_NO_GLDS_PHASED", "LBC_HDMA_PROLOGUE", "LBC_HDMA_EARLY", "LBC_HDMA_DIAG", "LBC_NO_HDMA_PERSIST", "LBC_HDMA_PERSIST_WGS", "LBC_HDMAP_PROF", "LBC_HDMAP_VAR", "LBC_NO_WGRAD_DEFER", "LBC_DECODER_PASS_MIN_COUT", "LBC_ADAM_ELEMS"};
 struct OptTable {
     long long v[kOptCount];
     OptTable()
@@ -109,6 +109,9 @@ extern "C" int lbc_profile_report(char* buf, int cap)
     struct Agg { long long n = 0; double ms = 0, flops = 0, bytes = 0; };
     std::map<std::string, Agg> agg;
     std::vector<std::string> order;
+    // LBC_PROF_LAUNCHES=<file>: additionally one line per launch, in launch order ("name ms flops bytes")
+    const char* per_launch = getenv("LBC_PROF_LAUNCHES");
+    FILE* pl = (per_launch && *per_launch) ? fopen(per_launch, "a") : nullptr;
     for (ProfRec& r : g_recs) {
         (void)hipEventSynchronize(r.e1);
         float ms = 0.f;
@@ -116,8 +119,10 @@ extern "C" int lbc_profile_report(char* buf, int cap)
         if (!agg.count(r.name)) order.push_back(r.name);
         Agg& a = agg[r.name];
         a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
+        if (pl) fprintf(pl, "%s %.6f %.6e %.6e\n", r.name, ms, r.flops, r.bytes);
         (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
     }
+    if (pl) fclose(pl);
     g_recs.clear();
     int off = 0;
     for (const std::string& k : order) {
