@@ -370,7 +370,8 @@ def main():
         roof = {"bound": "mfma", "kernel": "convolution family (%s): %s" % (mf, ", ".join(sorted(conv))), "achieved": round(ach, 2),
                 "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": None,
                 "instrumented_step": "serialized: one extra step on one stream with HIP events around every launch (the timed steps overlap the "
-                                     "teacher forward and the weight gradients on side streams, so the sum of these durations exceeds ms_per_step)",
+                                     "teacher forward -- and, in the f32 modes, the weight gradients -- on side streams, and carry no per-launch "
+                                     "events: the sum of these durations exceeds ms_per_step)",
                 "launches_per_step": n, "avg_launch_ms": round(ms / max(n, 1), 4), "gflop_per_launch": round(gf / max(n, 1), 3),
                 "share_of_step_kernel_time": round(ms / total_ms, 3) if total_ms else None,
                 "by_kernel": {k: {"launches": v["launches"], "ms": round(v["ms"], 3), "tflops": round(v["gflop"] / v["ms"], 1) if v["ms"] else None}

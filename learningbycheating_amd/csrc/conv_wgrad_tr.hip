@@ -53,9 +53,19 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, WgradGrou
     const int HRW = BRH + 2 * W + 2;                  // live halo rows of a chunk
     const int qtiles = a.CQ / 64;
     const int ntiles = (a.CP / 64) * qtiles;
-    // workgroup -> (tile, member, split), tile fastest: the tiles of one (member, split) share their pixel range through L2
-    const int tile = blockIdx.x % ntiles;
-    const int member = (blockIdx.x / ntiles) % grp.n, split = blockIdx.x / (ntiles * grp.n);
+    // workgroup -> (tile, member, split), tile fastest: the tiles of one (member, split) read the same pixel range, P once per Q tile and
+    // Q once per P tile.  Workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own: taken as they come, the 16 tiles of a
+    // 256-channel (member, split) sit on 8 different L2s and every one of them fetches its share again (PMC: 1.92 GB fetched per
+    // layer-3 group launch for 0.68 GB of operands, profiles/r03_final_pmc_summary_bf16.txt).  Logical index: XCD-major, so that
+    // consecutive logical ids -- the tiles of one (member, split) -- are consecutive workgroups of ONE XCD.
+    int logical;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+    }
+    const int tile = logical % ntiles;
+    const int member = (logical / ntiles) % grp.n, split = logical / (ntiles * grp.n);
     const int tp = tile / qtiles, tq = tile - tp * qtiles;
     const int p0 = tp * 64, q0 = tq * 64;
     const int mbeg = split * rows_per_split;

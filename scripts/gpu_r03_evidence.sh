@@ -23,6 +23,16 @@ done
 P1=$(find $R/pmc1 -name "*counter_collection.csv" | head -1); P2=$(find $R/pmc2 -name "*counter_collection.csv" | head -1); P3=$(find $R/pmc3 -name "*counter_collection.csv" | head -1)
 python scripts/pmc_summary.py $P1 $P2 $P3 > $R/pmc_summary.txt 2>&1
 python scripts/pmc_traffic.py $P2 $P3 bf16 "profiles/r03_final_pmc_bf16/pass2.csv (FETCH_SIZE x 2, MI355X_MICROARCH.md gfx950 correction) + pass3.csv (WRITE_SIZE): rocprofv3 --pmc passes of \`LBC_NO_SIDE_STREAM=1 bench.py --serial --steps 1 --warmup 1 --init-steps 1 --no-cpu-baseline --no-alt\` (scripts/gpu_r03_evidence.sh)" > $R/r03_pmc_traffic.json 2> $R/pmc_traffic_table.txt
+rm -f $R/launches_bs256.txt $R/launches_bs32.txt
+LBC_PROF_LAUNCHES=$R/launches_bs256.txt timeout 300 python bench.py --steps 3 --warmup 2 --no-cpu-baseline --no-alt --breakdown /dev/null > /dev/null 2>&1
+LBC_PROF_LAUNCHES=$R/launches_bs32.txt timeout 300 python bench.py --global-batch 32 --steps 3 --warmup 2 --no-cpu-baseline --no-alt --breakdown /dev/null > /dev/null 2>&1
+for B in 256 32; do
+  rm -rf $R/trace
+  (cd /tmp && timeout 600 rocprofv3 --kernel-trace --output-format csv -d "$OLDPWD/$R/trace" -o lbc -- python "$OLDPWD/bench.py" --global-batch $B --steps 4 --warmup 2 --init-steps 2 --no-cpu-baseline --no-alt) > $R/trace.log 2>&1
+  python scripts/trace_gaps.py $(find $R/trace -name "*kernel_trace.csv" | head -1) 2 > $R/trace_gaps_bs$B.txt 2>&1; head -1 $R/trace_gaps_bs$B.txt | cut -c1-260 >> $S
+  rm -rf $R/trace
+done
+timeout 200 python scripts/bench_wgrad_group.py 256 > $R/wgrad_group_bs256.txt 2>&1
 timeout 200 python scripts/bench_ops.py 256 3 fwd,dgrad,wgrad > $R/per_shape_bs256.txt 2>&1
 timeout 120 python scripts/bench_ops.py 32 3 fwd,dgrad,wgrad > $R/per_shape_bs32.txt 2>&1
 rm -f $R/grad_diag.txt
