@@ -481,6 +481,7 @@ inline bool big_tile(const WgradArgs& a)
 int lbc_wgrad_pick_split(const WgradArgs& a)
 {
     if (lbc_wgrad_tr_eligible(a)) return lbc_wgrad_tr_pick_split(a);
+    if (lbc_wgrad_tr2_eligible(a)) return lbc_wgrad_tr2_pick_split(a);
     const int bp = big_tile(a) ? 128 : 64;
     const long long tiles = (long long)(a.CP / bp) * (a.CQ / bp) * a.KH * a.KW;
     const long long M = (long long)a.N * a.OH * a.OW;
@@ -503,6 +504,7 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     const long long M = (long long)a.N * a.OH * a.OW;
     LBC_REQUIRE(M > 0 && M * a.CP < (1ll << 31) && (long long)a.N * a.H * a.W * a.CQ < (1ll << 31), "wgrad: bad tensor size");
     if (lbc_wgrad_tr_eligible(a)) return lbc_wgrad_tr_launch(a, s);
+    if (lbc_wgrad_tr2_eligible(a)) return lbc_wgrad_tr2_launch(a, s);
     const int br = a.bf16 ? 64 : BR;
     const long long chunks = (M + br - 1) / br;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * br;

@@ -63,6 +63,7 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, WgradGrou
         const int nwg = gridDim.x, b = blockIdx.x;
         const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
         logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+        if (grp.linear_order) logical = b;
     }
     const int tile = logical % ntiles;
     const int member = (logical / ntiles) % grp.n, split = logical / (ntiles * grp.n);
@@ -317,9 +318,11 @@ int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s)
     return lbc_wgrad_tr_group_launch(a, g, s);
 }
 
-int lbc_wgrad_tr_group_launch(const WgradArgs& a0, const WgradGroup& g, hipStream_t s)
+int lbc_wgrad_tr_group_launch(const WgradArgs& a0, const WgradGroup& g_in, hipStream_t s)
 {
-    LBC_REQUIRE(g.n >= 1 && g.n <= kLbcWgradGroupMax, "wgrad_tr: group of %d", g.n);
+    LBC_REQUIRE(g_in.n >= 1 && g_in.n <= kLbcWgradGroupMax, "wgrad_tr: group of %d", g_in.n);
+    WgradGroup g = g_in;
+    g.linear_order = lbc_opt_on(kOptWgradTrLinear) ? 1 : 0;
     WgradArgs a = a0;
     a.p = g.p[0]; a.q = g.q[0]; a.q_scale = g.q_scale[0]; a.q_shift = g.q_shift[0]; a.partial = g.out[0];
     LBC_REQUIRE(lbc_wgrad_tr_eligible(a), "wgrad_tr: launch not eligible");

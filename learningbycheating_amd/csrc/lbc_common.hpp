@@ -65,6 +65,10 @@ enum LbcOpt {
     kOptHdmapVar,          // LBC_HDMAP_VAR: A/B variants of conv_hdmap_k's plain forward (1 priority alternation, 2 DMA burst in the tail, 4 reads interleaved with MFMAs)
     kOptNoWgradDefer,      // LBC_NO_WGRAD_DEFER (read when a network is created): 1 = every weight gradient launched next to its input gradient (A/B)
     kOptDecoderPassMinCout, // LBC_DECODER_PASS_MIN_COUT: transposed convolutions with at least this many output channels pay a bn_apply pass for the LDS-DMA kernel (default 64: all three)
+    kOptWgradTrLinear,     // LBC_WGRAD_TR_LINEAR: 1 = the tap-fused weight gradient takes workgroup ids as logical ids (A/B of the XCD-major order)
+    kOptNoWgradTr2,        // LBC_NO_WGRAD_TR2: 1 = the stride-2 / transposed weight gradients stay on the generic kernel (A/B)
+    kOptWgradTr2MinWgs,    // LBC_WGRAD_TR2_MIN_WGS: the stride-2 tap-fused weight gradient takes a launch that yields at least this many workgroups of 16 chunks (default 192)
+    kOptWgradTr2Blocks,    // LBC_WGRAD_TR2_BLOCKS: workgroups per launch the split count aims at (default 256)
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptCount
 };
@@ -214,6 +218,7 @@ int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s);
 constexpr int kLbcWgradGroupMax = 12;
 struct WgradGroup {
     int n;
+    int linear_order;       // 1: workgroup id = logical id (A/B: LBC_WGRAD_TR_LINEAR); 0: XCD-major logical order
     const void* p[kLbcWgradGroupMax];
     const void* q[kLbcWgradGroupMax];
     const float* q_scale[kLbcWgradGroupMax];
@@ -224,4 +229,9 @@ int lbc_wgrad_tr_group_split(const WgradArgs& a, int n);
 int lbc_wgrad_tr_group_launch(const WgradArgs& a, const WgradGroup& g, hipStream_t s);
 // out[i] = sum over the nsplit slabs at partial + i * nsplit * count, i < n (one launch)
 int lbc_splitk_reduce_group(const float* partial, int nsplit, long long count, int n, float* const* out, hipStream_t s);
+// 3x3 / stride-2 weight gradients (and the transposed convolutions') on bf16 tensors: all nine taps per workgroup over a ring of
+// high-resolution rows that advances 128 rows per 32 low-resolution pixels (conv_wgrad_tr2.hip)
+bool lbc_wgrad_tr2_eligible(const WgradArgs& a);
+int lbc_wgrad_tr2_pick_split(const WgradArgs& a);
+int lbc_wgrad_tr2_launch(const WgradArgs& a, hipStream_t s);
 int lbc_splitk_reduce(const float* partial, int nsplit, long long count, float* out, float beta, hipStream_t s);

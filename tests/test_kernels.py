@@ -375,6 +375,55 @@ def test_conv_wgrad_tap_fused(env, cfg):
     assert relerr(dw2, w2.grad) < 5e-4   # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
 
 
+# ---- tap-fused 3x3 / STRIDE-2 weight gradient (conv_wgrad_tr2.hip): the first convolution of layers 2-4 and the decoder's transposed convolutions ----------
+WTR2_SMALL = [(2, 8, 24, 64, 128), (1, 10, 48, 128, 128), (3, 6, 32, 64, 256), (2, 24, 24, 64, 128), (1, 4, 96, 64, 128), (5, 2, 24, 128, 128), (1, 34, 40, 64, 128)]
+WTR2_REAL = [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128), (64, 20, 48, 128, 256), (256, 10, 24, 256, 512), (7, 40, 96, 64, 128)]]
+
+
+@pytest.mark.parametrize("cfg", WTR2_SMALL + WTR2_REAL)
+def test_conv_wgrad_stride2_tap_fused(env, cfg, lbc_config):
+    """image borders (top / left taps), several images per split, output rows that end inside a 16-pixel group, ring wrap; bit-compared with
+    nothing (its summation order is its own): against torch on bf16-rounded operands, and against the generic kernel (LBC_NO_WGRAD_TR2=1)"""
+    dev, _ = env
+    lbc_config("LBC_WGRAD_TR2_MIN_WGS", 1)       # (the kernel is selected from ~192 workgroups of work; here at any size)
+    N, H, W, C, K = cfg
+    x, w = make((N, H, W, C, K, 3, 2, 1), 70)
+    x = rbf(x)
+    g = torch.Generator().manual_seed(71)
+    dy = rbf(torch.randn((N, K, H // 2, W // 2), generator=g))
+    w1 = w.clone().requires_grad_(True)
+    F.conv2d(x, w1, None, 2, 1).backward(dy)
+    dw = Conv(dev).wgrad(x, dy, 3, 2, 1, bf16=2)
+    assert relerr(dw, w1.grad) < 1e-4
+    lbc_config("LBC_NO_WGRAD_TR2", 1)
+    assert relerr(dw, Conv(dev).wgrad(x, dy, 3, 2, 1, bf16=2)) < 1e-5
+
+
+@pytest.mark.parametrize("cfg", [(2, 5, 12, 128, 64), (1, 7, 16, 256, 128), (3, 4, 48, 128, 64)] +
+                         [pytest.param(c, marks=gpu) for c in [(64, 5, 12, 640, 256), (64, 10, 24, 256, 128), (64, 20, 48, 128, 64), (256, 20, 48, 128, 64)]])
+def test_deconv_wgrad_stride2_tap_fused(env, cfg, lbc_config):
+    """ConvTranspose2d weight gradient on bf16 tensors with the preceding BatchNorm applied to x on load: the same kernel with the roles
+    of the two tensors swapped (P = bn(x) on the low-resolution lattice, Q = dY on the high-resolution one)"""
+    dev, _ = env
+    lbc_config("LBC_WGRAD_TR2_MIN_WGS", 1)
+    N, H, W, C, K = cfg
+    g = torch.Generator().manual_seed(72)
+    x = rbf(torch.randn((N, C, H, W), generator=g))
+    w = (torch.randn((C, K, 3, 3), generator=g) * (2.0 / (C * 2.25)) ** 0.5)
+    b = torch.randn(K, generator=g)
+    ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+    _, _, bwd = Conv(dev).deconv_all(x, w, b, (ps, pt), relu=0, bf16=2)
+    dy = rbf(torch.randn((N, K, 2 * H, 2 * W), generator=g))
+    w1 = w.clone().requires_grad_(True)
+    xn = rbf(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1))
+    F.conv_transpose2d(xn, w1, None, 2, 1, 1).backward(dy)
+    _, dw = bwd(dy)
+    assert relerr(dw, w1.grad) < 5e-4      # (fma vs mul + add in front of the operand's bf16 rounding)
+    lbc_config("LBC_NO_WGRAD_TR2", 1)
+    _, dw0 = bwd(dy)
+    assert relerr(dw, dw0) < 1e-5
+
+
 @pytest.mark.parametrize("cfg", [(3, 2, 5, 12, 64, 64), (5, 1, 4, 16, 64, 128), (12, 4, 16, 16, 64, 64), (2, 3, 2, 16, 128, 64)] +
                          [pytest.param(c, marks=gpu) for c in [(5, 16, 5, 12, 512, 512), (6, 8, 40, 96, 64, 64), (7, 4, 20, 48, 128, 128), (11, 8, 10, 24, 256, 256)]])
 def test_conv_wgrad_group(env, cfg):
@@ -433,9 +482,9 @@ def test_conv_glds_stride2_transposed_phases(env, case, lbc_config):
 
 def early_reads_checked(dev):
     """the LBC_HDMA_EARLY variants (fragment reads a full depth step ahead, hand-counted lgkmcnt waits) are compared bit for bit with
-    the default kernels on the emulator -- which checks their address pipeline, not their wait counts -- and on the GPU only when
-    asked for (LBC_TEST_EXPERIMENTAL=1) until they have been run on hardware"""
-    return dev.type == "cpu" or os.environ.get("LBC_TEST_EXPERIMENTAL") == "1"
+    the default kernels: on the emulator, which checks their address pipeline, and on the GPU, which checks their wait counts (they
+    ran there in round 3: profiles/r03_run1_early_pytest.log; LBC_TEST_EXPERIMENTAL=0 skips them)"""
+    return dev.type == "cpu" or os.environ.get("LBC_TEST_EXPERIMENTAL", "1") != "0"
 
 
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
@@ -499,8 +548,7 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
         assert relerr(yp, yq) < 2.0 ** -7
     # LBC_HDMA_EARLY=1 (fragment reads issued a full depth step ahead, hand-counted lgkmcnt waits): the same MFMAs in the same
-    # order -> bit-identical.  On the GPU only when asked for (LBC_TEST_EXPERIMENTAL=1) until the variant has been run on hardware:
-    # the emulator checks its address pipeline, not its wait counts.
+    # order -> bit-identical (the emulator checks its address pipeline, the GPU its wait counts)
     if cfgid not in (3, 4) and early_reads_checked(dev):
         lbc_config("LBC_HDMA_EARLY", 1)
         ye, ste = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
