@@ -217,6 +217,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
         dy_arena_ = alloc(dy_arena_floats_);
     }
     wg_partial_ = alloc(wg);
+    wg_floats_ = wg;
 
     wt_ = alloc((size_t)640 * 512 * 9);
     gD_ = alloc_act(max_act); gE_ = alloc_act(max_act); gF_ = alloc_act(max_act); gG_ = alloc_act(max_act);
@@ -689,6 +690,8 @@ int Net::flush_wgrads(int N, hipStream_t s)
         }
         a.nsplit = lbc_wgrad_tr_group_split(a, g.n);
         const size_t count = (size_t)c.Cout * 9 * c.Cin;
+        // (the slab arena was planned at max_batch; the split policy is not monotone in the batch: never more slabs than it holds)
+        if ((size_t)a.nsplit * g.n * count > wg_floats_) a.nsplit = (int)std::max<size_t>(1, wg_floats_ / (g.n * count));
         for (int m = 0; m < g.n; ++m) g.out[m] = a.nsplit == 1 ? grads[m] : W(wg_partial_) + (size_t)m * a.nsplit * count;
         LBC_TRY(lbc_wgrad_tr_group_launch(a, g, s));
         if (a.nsplit > 1) LBC_TRY(lbc_splitk_reduce_group(W(wg_partial_), a.nsplit, (long long)count, g.n, grads, s));
@@ -714,6 +717,10 @@ int Net::conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const floa
     a.H = c.H; a.W = c.W; a.CQ = c.Cin;
     a.KH = c.k; a.KW = c.k; a.S = c.s; a.P = c.p;
     a.nsplit = lbc_wgrad_pick_split(a);
+    {   // (planned at max_batch; kernel choice and split policy depend on the batch: never more slabs than the arena holds)
+        const size_t count = (size_t)c.Cout * c.k * c.k * c.Cin;
+        if ((size_t)a.nsplit * count > wg_floats_) a.nsplit = (int)std::max<size_t>(1, wg_floats_ / count);
+    }
     if (a.nsplit == 1) { a.partial = G(c.w); return lbc_wgrad_launch(a, s); }   // a single slab is the gradient itself
     LBC_TRY(lbc_wgrad_launch(a, s));
     return lbc_splitk_reduce(a.partial, a.nsplit, (long long)c.Cout * c.k * c.k * c.Cin, G(c.w), 0.f, s);
@@ -936,6 +943,7 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
             wa.H = 2 * D.H; wa.W = 2 * D.W; wa.CQ = D.Cout; wa.KH = 3; wa.KW = 3; wa.S = 2; wa.P = 1;
             wa.bf16 = bf16_; wa.act_bf16 = act_bf16_;
             wa.nsplit = lbc_wgrad_pick_split(wa);
+            if ((size_t)wa.nsplit * D.Cin * 9 * D.Cout > wg_floats_) wa.nsplit = (int)std::max<size_t>(1, wg_floats_ / ((size_t)D.Cin * 9 * D.Cout));
             if (wa.nsplit == 1) wa.partial = G(D.w);
             LBC_TRY(lbc_wgrad_launch(wa, s));
             if (wa.nsplit > 1) LBC_TRY(lbc_splitk_reduce(wa.partial, wa.nsplit, (long long)D.Cin * 9 * D.Cout, G(D.w), 0.f, s));

@@ -148,6 +148,7 @@ private:
     std::vector<PendingWgrad> pending_;
     bool defer_wgrad_ = false;
     size_t dy_arena_ = 0, dy_arena_floats_ = 0, dy_used_ = 0;
+    size_t wg_floats_ = 0;               // size of the split-K slab arena (planned at max_batch)
     float* dy_slot(long long elems);
     int flush_wgrads(int N, hipStream_t s);
     int backward_impl(const float* d_sel, const float* d_all, int stage, hipStream_t s);

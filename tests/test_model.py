@@ -642,6 +642,29 @@ def test_bn_backward_reduce_fused_into_dgrad_epilogue(env, kind, backbone, h, w,
     assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
 
 
+@pytest.mark.parametrize("kind,backbone,h,w,nmax,n", [("image", "resnet18", 64, 128, 6, 2), pytest.param("image", "resnet34", 160, 384, 64, 24, marks=gpu)])
+def test_batch_below_the_planned_maximum(env, kind, backbone, h, w, nmax, n, lbc_config):
+    """bf16 mode: the workspace (dY arena, split-K slabs) is planned at max_batch, kernel choice and split counts follow the batch of the
+    call -- a smaller batch on a larger plan must give what a plan of its own size gives (same kernels, same splits: bit-identical)"""
+    dev, _ = env
+    lbc_config("LBC_GEMM256_MIN_TILES", 1)
+    sd = O.make_state_dict(kind, backbone, 17, h, w)
+    x, speed, cmd = _inputs(kind, nmax, h, w, 12)
+    g = torch.Generator().manual_seed(9)
+    d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g), torch.randn((n, 5, 2), generator=g)
+    grads = []
+    for plan in (nmax, n):
+        eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, plan, dev, precision=2)
+        if plan == nmax:      # the plan's own size first: leaves its traces in every buffer
+            eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
+            eng.backward(torch.randn((nmax, 5, 2), generator=g).to(dev), torch.randn((nmax, 4, 5, 2), generator=g).to(dev))
+        eng.forward(x[:n].contiguous().to(dev), speed[:n].to(dev), cmd[:n].to(dev), True)
+        eng.backward(d_sel.to(dev), d_all.to(dev))
+        grads.append({k: v.detach().cpu().clone() for k, v in eng.grad_views.items()})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
 @pytest.mark.parametrize("precision", [1, 2, "2-tiles128", "2-glds", "2-hdma-prologue"])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),
                                                  pytest.param("birdview", "resnet18", 192, 192, 8, marks=gpu)])
