@@ -285,12 +285,16 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
 // (2 ly + oy0, 2 lx + ox0) gather x at (ly + dy, lx + dx) through the 1 / 2 / 2 / 4 taps with (oy0 + 1 - r, ox0 + 1 - s) even.
 // EARLY (LBC_HDMA_EARLY=1, not yet measured): fragment reads issued a full depth step ahead with hand-counted waits, as in
 // conv_hdma.hip (see there and conv_lds_dma.hpp)
+// WM x WN = 8 waves (one workgroup per CU), or 4 (256 x 64 / 128 x 128 tiles in half the LDS: TWO workgroups per CU, for the launches
+// whose K loop is a handful of K-tiles -- the phased stride-2 transposed ones, the 1x1 downsamples -- where a workgroup is mostly
+// prologue and epilogue and a second one has something to overlap them with)
 template <int BM, int BN, int WM, int WN, int MODE, int KT, int DIAG = 0, int PH = 0, int EARLY = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
-__global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* zero_page)
+__global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
-    static_assert(WM * WN == 8 && NT == 2 && (MT == 2 || MT == 4), "conv_glds2: wave tiling");
+    constexpr int NW = WM * WN;
+    static_assert((NW == 8 || NW == 4) && NT == 2 && (MT == 2 || MT == 4), "conv_glds2: wave tiling");
     // K-tile = one filter tap x KT channels.  KT = 32: 64-byte LDS rows, four tiles in the ring.  KT = 64: 128-byte rows = whole
     // cache lines per DMA row (a 64-byte row leaves half of every 128-byte line it pulls through L2 -> L1 unused; the same
     // line comes again nine K-tiles later), two tiles in the ring, half as many barriers; same prefetch distance in cycles.
@@ -303,14 +307,14 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
     constexpr int TILE_A = BM * ROWB, TILE_B = BN * ROWB, BUF = TILE_A + TILE_B;
     // 1-KiB DMA pieces per wave per K-tile.  When the weight tile has fewer than eight pieces (BN = 64) the upper waves re-issue
     // the pieces of the lower ones (same bytes to the same LDS rows), which keeps every wave's vmcnt arithmetic equal
-    constexpr int NA = BM / (PROWS * 8), NB = BN >= PROWS * 8 ? BN / (PROWS * 8) : 1, NL = NA + NB;
-    constexpr int BWAVES = BN >= PROWS * 8 ? 8 : BN / PROWS;
-    static_assert(BM % (PROWS * 8) == 0 && (BN % (PROWS * 8) == 0 || BN == 64), "conv_glds2: tile extents");
+    constexpr int NA = BM / (PROWS * NW), NB = BN >= PROWS * NW ? BN / (PROWS * NW) : 1, NL = NA + NB;
+    constexpr int BWAVES = BN >= PROWS * NW ? NW : BN / PROWS;
+    static_assert(BM % (PROWS * NW) == 0 && (BN % (PROWS * NW) == 0 || BN == 64), "conv_glds2: tile extents");
     constexpr int OROW = BN * 2 + 16;                           // staged output row: BN bf16 + 16 bytes (rows 4 apart on distinct banks)
     constexpr int STAGE = BM * OROW;
     constexpr int RED = WM * 2 * BN * 4;
     constexpr int SMEM = NBUF * BUF > STAGE + RED ? NBUF * BUF : STAGE + RED;
-    static_assert(SMEM <= 160 * 1024, "conv_glds2: LDS");
+    static_assert(SMEM <= (NW == 4 ? 80 : 160) * 1024, "conv_glds2: LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -593,7 +597,8 @@ __global__ __launch_bounds__(512, 2) void conv_glds2_k(IgemmArgs a, const void* 
 
 struct GldsCfg { int bm, bn; double eff; };
 // cfg ids kLbcCfgGlds + 0 .. 3; eff = measured relative MFMA efficiency of a full round of tiles (MI355X, batch 256)
-const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128, 256, 0.95}, {512, 128, 1.0}, {512, 64, 1.0}};
+// 5, 6: the four-wave shapes (two workgroups per CU); chosen by lbc_conv_glds_pick for short K loops only
+const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128, 256, 0.95}, {512, 128, 1.0}, {512, 64, 1.0}, {256, 64, 1.02}, {128, 128, 1.02}};
 
 }  // namespace
 
@@ -604,6 +609,19 @@ static bool lbc_glds_phased(const IgemmArgs& a, int mode)
     return mode == 1 && a.nphase == 4 && a.S == 2 && a.ostep == 2 && a.KH == 3 && a.KW == 3 && a.P == 1 && a.H == a.LH && a.W == a.LW &&
            a.OH == 2 * a.LH && a.OW == 2 * a.LW && a.M == a.N * a.LH * a.LW && !a.resid && !a.bnb_y && !lbc_opt_on(kOptGldsV1) &&
            !lbc_opt_on(kOptNoGldsPhased);
+}
+
+// The four-wave shapes (two workgroups per CU) take a launch only where measured better: see the policy's comment
+static bool lbc_glds_wants_four_waves(const IgemmArgs& a, int mode, bool phased, int i)
+{
+    const long long pol = lbc_opt(kOptGlds4w);       // LBC_GLDS_4W: 0 = never, 1 = wherever the shape fits, default = the measured policy
+    if (pol == 0) return false;
+    if (pol == 1) return true;
+    // measured at 256 images (profiles/r03_run34_glds_four_wave_*): the phased stride-2 transposed launches gain a little (layer 2's first
+    // input gradient 133 -> 115 us on 256 x 64, layers 3 / 4 76 / 65 -> 70 / 63 on 128 x 128; step -0.07 ms); the stride-2 forwards lose
+    // 10-30 %, the 1x1 downsamples are level -- a second workgroup per CU is not what these short-K launches lack
+    (void)a; (void)mode; (void)i;
+    return phased;
 }
 
 // Tile configuration for a launch, or -1 when the launch keeps conv_igemm.hip / conv_halo.hip.
@@ -634,6 +652,7 @@ int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
         const GldsCfg& c = kGldsCfg[i];
         if (a.K % c.bn) continue;
         if (forced >= 0 && forced != i) continue;
+        if (i >= 5 && forced != i && !lbc_glds_wants_four_waves(a, mode, phased, i)) continue;
         // 64 output channels: the stride-1 3x3 layer is better off in conv_halo.hip (0.187 vs 0.126 ms), so this shape is chosen only when
         // pinned -- or for the phased stride-2 transposed launches (layer 2's first input gradient: 0.173 -> 0.135 ms)
         if (c.bn == 64 && (a.K != 64 || lbc_opt_on(kOptGldsV1) || (forced != i && !phased))) continue;
@@ -670,14 +689,14 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
 #define LBC_GL2(BMv, BNv, WMv, WNv)                                                                                          \
     do {                                                                                                                     \
         if (kt64 && early) {                                                                                                 \
-            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64, 0, 0, 1>), grid, dim3(512), 0, s, a, zero); \
-            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 0, 1>), grid, dim3(512), 0, s, a, zero); \
+            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64, 0, 0, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero); \
+            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 0, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero); \
         } else if (kt64) {                                                                                                   \
-            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64>), grid, dim3(512), 0, s, a, zero);    \
-            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64>), grid, dim3(512), 0, s, a, zero);    \
+            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);    \
+            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);    \
         } else {                                                                                                             \
-            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 32>), grid, dim3(512), 0, s, a, zero);    \
-            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 32>), grid, dim3(512), 0, s, a, zero);    \
+            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 32>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);    \
+            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 32>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);    \
         }                                                                                                                    \
     } while (0)
         const bool early = lbc_opt_on(kOptHdmaEarly);
@@ -693,14 +712,16 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
         if (phased) {
 #define LBC_GLP(BMv, BNv, WMv, WNv)                                                                                          \
     do {                                                                                                                     \
-        if (early) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1, 1>), grid, dim3(512), 0, s, a, zero);   \
-        else       hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1>), grid, dim3(512), 0, s, a, zero);      \
+        if (early) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);   \
+        else       hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);      \
     } while (0)
             if (cfg == kLbcCfgGlds + 0) LBC_GLP(256, 256, 2, 4);
             else if (cfg == kLbcCfgGlds + 1) LBC_GLP(256, 128, 4, 2);
             else if (cfg == kLbcCfgGlds + 2) LBC_GLP(128, 256, 2, 4);
             else if (cfg == kLbcCfgGlds + 3) LBC_GLP(512, 128, 4, 2);
-            else LBC_GLP(512, 64, 8, 1);
+            else if (cfg == kLbcCfgGlds + 4) LBC_GLP(512, 64, 8, 1);
+            else if (cfg == kLbcCfgGlds + 5) LBC_GLP(256, 64, 4, 1);
+            else LBC_GLP(128, 128, 2, 2);
 #undef LBC_GLP
             return lbc_check_launch("conv_glds2");
         }
@@ -708,7 +729,9 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
         else if (cfg == kLbcCfgGlds + 1) LBC_GL2(256, 128, 4, 2);
         else if (cfg == kLbcCfgGlds + 2) LBC_GL2(128, 256, 2, 4);
         else if (cfg == kLbcCfgGlds + 3) LBC_GL2(512, 128, 4, 2);
-        else LBC_GL2(512, 64, 8, 1);
+        else if (cfg == kLbcCfgGlds + 4) LBC_GL2(512, 64, 8, 1);
+        else if (cfg == kLbcCfgGlds + 5) LBC_GL2(256, 64, 4, 1);
+        else LBC_GL2(128, 128, 2, 2);
 #undef LBC_GL2
         return lbc_check_launch("conv_glds2");
     }
@@ -721,7 +744,7 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     else if (cfg == kLbcCfgGlds + 1) LBC_GL(256, 128, 4, 2, 3);
     else if (cfg == kLbcCfgGlds + 2) LBC_GL(128, 256, 2, 4, 3);
     else if (cfg == kLbcCfgGlds + 3) LBC_GL(512, 128, 4, 2, 2);
-    else { lbc_set_error("conv_glds: the 512 x 64 shape exists in the second-generation kernel only"); return LBC_EINVAL; }
+    else { lbc_set_error("conv_glds: the 512 x 64 and four-wave shapes exist in the second-generation kernel only"); return LBC_EINVAL; }
 #undef LBC_GL
     return lbc_check_launch("conv_glds");
 }

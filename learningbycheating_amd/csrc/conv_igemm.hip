@@ -514,7 +514,7 @@ int lbc_igemm_pick_for(const IgemmArgs& a, int mode)
         }
         const int g = lbc_conv_glds_pick(a, mode);
         // the 64-channel layers have two candidates: conv_halo.hip, unless the 512 x 64 LDS-DMA shape is selected
-        if (g >= 0 && (g == kLbcCfgGlds + 4 || !lbc_conv3x3_halo_eligible(a, mode))) return g;
+        if (g >= 0 && (g == kLbcCfgGlds + 4 || g == kLbcCfgGlds + 5 || !lbc_conv3x3_halo_eligible(a, mode))) return g;   // (+4, +5: the 64-column shapes, picked for such a layer only when pinned)
     }
     return lbc_igemm_pick(a.M, a.K);
 }

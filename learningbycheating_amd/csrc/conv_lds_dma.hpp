@@ -51,7 +51,7 @@ template <int N, int STRIDE, int I = 0> __device__ __forceinline__ void lds_read
 // LDS the epilogue below needs: the staged output tile + the statistics rows
 template <int BM, int BN, int WM> constexpr int lds_dma_epilogue_bytes() { return BM * (BN * 2 + 16) + WM * 2 * BN * 4; }
 
-// Epilogue of a 512-thread workgroup whose 8 waves (WM x WN) hold a BM x BN output tile in 32 x 32 MFMA accumulators.
+// Epilogue of a workgroup whose WM x WN waves (8, or 4 for the two-workgroups-per-CU shapes) hold a BM x BN output tile in 32 x 32 MFMA accumulators.
 // Every wave must have left its main loop reads before this is entered (it starts with a barrier); smem is reused from byte 0.
 template <int BM, int BN, int WM, int WN, int MT, int NT>
 // ostep = 2 (phased stride-2 transposed launches): row m is lattice point (n, ly, lx) of a.LH x a.LW and lands on output pixel
@@ -60,6 +60,7 @@ __device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&ac
                                                  const int ostep = 1, const int oy0 = 0, const int ox0 = 0)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;
+    constexpr int NTH = WM * WN * 64;                           // threads of the workgroup
     constexpr int OROW = BN * 2 + 16;                           // staged output row: BN bf16 + 16 bytes (rows 4 apart on distinct banks)
     constexpr int STAGE = BM * OROW;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -124,7 +125,7 @@ __device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&ac
     constexpr int SEG = BN / 8;                         // 16-byte segments per output row
     if (a.bnb_y == nullptr) {
 #pragma unroll 4
-        for (int idx = tid; idx < BM * SEG; idx += 512) {
+        for (int idx = tid; idx < BM * SEG; idx += NTH) {
             const int row = idx / SEG, sg = idx - row * SEG;
             const int m = m0 + row;
             if (m < a.M) {
@@ -149,8 +150,8 @@ __device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&ac
     } else {
         // Fused BatchNorm-backward reduce (IgemmArgs::bnb_*): the copy-out pass reads the pre-BN activation next to the staged
         // gradient (16 bytes each), masks, stores, and sums (g, g * xhat) for the thread's fixed 8-channel segment
-        // (512 % SEG == 0); the 512 / SEG threads of a segment are combined through LDS in thread order (deterministic).
-        static_assert(512 % SEG == 0, "conv_glds2: segment ownership");
+        // (NTH % SEG == 0); the NTH / SEG threads of a segment are combined through LDS in thread order (deterministic).
+        static_assert(NTH % SEG == 0 && NTH * 64 <= STAGE, "conv_glds2: segment ownership / scratch");
         const __bf16* by = static_cast<const __bf16*>(a.bnb_y);
         const int sg = tid % SEG;
         const int c0 = n0 + sg * 8;
@@ -158,7 +159,7 @@ __device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&ac
         const f32x8 bmu = ParamVec<8>::ld(a.bnb_mean + c0), biv = ParamVec<8>::ld(a.bnb_invstd + c0);
         f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
 #pragma unroll 4
-        for (int row = tid / SEG; row < BM; row += 512 / SEG) {
+        for (int row = tid / SEG; row < BM; row += NTH / SEG) {
             const int m = m0 + row;
             if (m < a.M) {
                 const size_t o = (size_t)m * (size_t)a.K + (size_t)c0;
@@ -173,14 +174,14 @@ __device__ __forceinline__ void lds_dma_epilogue(const IgemmArgs& a, f32x16 (&ac
             }
         }
         __syncthreads();                                // the staged tile has been consumed: its LDS holds the partial sums now
-        float* ps = reinterpret_cast<float*>(smem);     // [512][16]
+        float* ps = reinterpret_cast<float*>(smem);     // [NTH][16]
         ParamVec<8>::st(ps + tid * 16, t1);
         ParamVec<8>::st(ps + tid * 16 + 8, t2);
         __syncthreads();
         if (a.stats && tid < BN) {
             const int seg = tid >> 3, e = tid & 7;
             float u1 = 0.f, u2 = 0.f;
-            for (int k = 0; k < 512 / SEG; ++k) {
+            for (int k = 0; k < NTH / SEG; ++k) {
                 u1 += ps[(k * SEG + seg) * 16 + e];
                 u2 += ps[(k * SEG + seg) * 16 + 8 + e];
             }

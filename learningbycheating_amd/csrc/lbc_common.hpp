@@ -69,6 +69,7 @@ enum LbcOpt {
     kOptNoWgradTr2,        // LBC_NO_WGRAD_TR2: 1 = the stride-2 / transposed weight gradients stay on the generic kernel (A/B)
     kOptWgradTr2MinWgs,    // LBC_WGRAD_TR2_MIN_WGS: the stride-2 tap-fused weight gradient takes a launch that yields at least this many workgroups of 16 chunks (default 192)
     kOptWgradTr2Blocks,    // LBC_WGRAD_TR2_BLOCKS: workgroups per launch the split count aims at (default 256)
+    kOptGlds4w,            // LBC_GLDS_4W: the four-wave (two workgroups per CU) shapes of conv_glds2_k: 0 = never, 1 = wherever they fit, unset = measured policy
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptCount
 };
@@ -162,7 +163,7 @@ int lbc_igemm_pick(long long M, int K);            // tile configuration 0..2 of
 // tile configuration for a fully described launch: conv_glds.hip's (kLbcCfgGlds + 0..2) when eligible, else lbc_igemm_pick
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
-constexpr int kLbcGldsCfgs = 5;
+constexpr int kLbcGldsCfgs = 7;
 constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 persistent (C = K = 64)}
 constexpr int kLbcHdmaCfgs = 5;                             // ... 4: 128 x 64, four waves, two workgroups per CU (launches with few rows)
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);

@@ -452,7 +452,8 @@ def test_conv_wgrad_group(env, cfg):
         assert relerr(got[i], w2.grad) < 5e-4, i
 
 
-@pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 1), (1, 12, 14, 128, 256, 2), (3, 8, 10, 64, 256, 0), (2, 6, 34, 128, 128, 3), (1, 4, 6, 192, 128, 1)] +
+@pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 1), (1, 12, 14, 128, 256, 2), (3, 8, 10, 64, 256, 0), (2, 6, 34, 128, 128, 3), (1, 4, 6, 192, 128, 1),
+                                  (2, 10, 18, 64, 128, 5), (2, 6, 34, 128, 128, 6), (1, 4, 6, 192, 128, 6)] +
                          [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128, -1), (64, 20, 48, 128, 256, -1), (256, 10, 24, 256, 512, -1)]])
 def test_conv_glds_stride2_transposed_phases(env, case, lbc_config):
     """input gradient of a stride-2 3x3 convolution on the LDS-DMA kernel: the four output-parity phases in one grid (1 / 2 / 2 / 4
@@ -583,7 +584,8 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     assert relerr(y, y3) < 2.0 ** -7
 
 
-@pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 3, 1), (1, 12, 14, 128, 256, 3, 2), (3, 8, 10, 64, 128, 1, 3), (2, 6, 34, 128, 128, 3, 3)] +
+@pytest.mark.parametrize("case", [(2, 10, 18, 64, 128, 3, 1), (1, 12, 14, 128, 256, 3, 2), (3, 8, 10, 64, 128, 1, 3), (2, 6, 34, 128, 128, 3, 3),
+                                  (2, 10, 18, 64, 128, 3, 6), (3, 8, 10, 64, 128, 1, 6), (2, 6, 34, 128, 64, 3, 5)] +
                          [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128, 3, -1), (64, 20, 48, 128, 256, 3, -1), (64, 40, 96, 64, 128, 1, -1), (256, 10, 24, 256, 512, 3, -1)]])
 def test_conv_glds_stride2_gather(env, case, lbc_config):
     """stride-2 forward (3x3 pad 1 and the 1x1 downsample) on the LDS-DMA kernel: odd output extents, borders, statistics"""
@@ -753,7 +755,7 @@ def test_deconv_f32_large_tile_configs(env, cfg, cfgid, force_cfg):
 
 
 # ---- 8-wave LDS-DMA convolution (conv_glds.hip): bf16 tensors + bf16 weight copies --------------------------------------------
-GLDS_BM = {0: 256, 1: 256, 2: 128, 3: 512, 4: 512}      # tile rows of LBC_GEMM256_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64
+GLDS_BM = {0: 256, 1: 256, 2: 128, 3: 512, 4: 512, 5: 256, 6: 128}      # tile rows of LBC_GEMM256_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64; four waves, two workgroups per CU: 5: 256x64, 6: 128x128
 
 
 def _glds_cases():
@@ -763,6 +765,7 @@ def _glds_cases():
         for cfgid in ((0, 2) if K % 256 == 0 else (1, 3)):
             out.append((N, H, W, C, K, k, cfgid))
     out += [(2, 9, 17, 64, 64, 3, 4), (1, 30, 20, 128, 64, 3, 4)]      # 512 x 64 tiles (second-generation kernel only)
+    out += [(2, 9, 17, 64, 64, 3, 5), (1, 30, 20, 128, 64, 3, 5), (3, 7, 9, 64, 128, 3, 6), (2, 16, 17, 128, 128, 3, 6), (1, 10, 30, 64, 256, 1, 6)]      # four-wave shapes
     return out
 
 
@@ -782,8 +785,8 @@ def test_conv_glds_fwd_dgrad(env, case, gen, lbc_config):
     from learningbycheating_amd import _lib
     N, H, W, C, K, k, cfgid = case
     if gen == 1:
-        if cfgid == 4:
-            pytest.skip("512 x 64 tiles exist in the second-generation kernel only")
+        if cfgid >= 4:
+            pytest.skip("512 x 64 and four-wave tiles exist in the second-generation kernel only")
         lbc_config("LBC_GLDS_V1", 1)       # the first-generation (phase-barrier) kernel, kept for A/B runs
     lbc_config("LBC_NO_HDMA", 1)           # this test is about conv_glds.hip (3x3 stride-1 launches prefer conv_hdma.hip otherwise)
     if cfgid >= 0:
