@@ -94,10 +94,9 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
     __bf16* yout = static_cast<__bf16*>(a.y);
     const int col = 32 * wn + l31;                              // this lane's output channel (accumulator layout)
     const int crow = lane >> 2, cseg = lane & 3;                // copy-out role: 16-byte chunk (row crow, segment cseg) of a 16 x 32 step
-    float psc = 1.f, psh = 0.f, bia = 0.f, bsc = 0.f, bsh = 0.f, bmu = 0.f, biv = 0.f;
+    float psc = 1.f, psh = 0.f, bia = 0.f;
     if (a.post_scale) { psc = a.post_scale[col]; psh = a.post_shift[col]; }
     if (a.bias) bia = a.bias[col];
-    if (EPI == 2) { bsc = a.bnb_scale[col]; bsh = a.bnb_shift[col]; bmu = a.bnb_mean[col]; biv = a.bnb_invstd[col]; }
     const __bf16* gsrc = EPI == 1 ? static_cast<const __bf16*>(a.resid) : (EPI == 2 ? static_cast<const __bf16*>(a.bnb_y) : nullptr);
 
     // the first tile's halo
@@ -150,6 +149,12 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
         const int abuf = buf * ABYTES;
         int aaddr[MT];
+        // (the row base and XOR term of a tap depend on the lane's row only: left alone, the compiler keeps all 9 x MT of them in registers
+        //  across the tile loop -- next to 144 weight registers that is what spilled into the K loop of the fused-epilogue forms)
+#ifndef LBC_HIP_EMULATED_FOR_TESTS
+#pragma unroll
+        for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rowc[i]));
+#endif
         auto tap_addr = [&](const int tap) {
             const int r = tap / 3, s = tap - 3 * r;
             const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
@@ -195,6 +200,18 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
         }
         const char* gt = smem + GT + wave * 4096 + l31 * 2;
         float s1 = 0.f, s2 = 0.f;
+        // EPI 2 (fused BatchNorm-backward reduce): mask and sums in the CHUNK phase -- the staged gradient and the pre-BatchNorm activation
+        // as 16-byte LDS reads, eight channels per lane in vector arithmetic -- instead of per accumulator element (32 two-byte LDS reads
+        // and ~15 VALU each: 163 us per launch against 91 plain).  The per-channel operands are loaded HERE, through an address the
+        // compiler cannot hoist: live across the K loop they would spill next to the 144 weight registers.
+        f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1, bsc8 = t1, bsh8 = t1;
+        int c0 = 32 * wn + cseg * 8;
+        if (EPI == 2) {
+#ifndef LBC_HIP_EMULATED_FOR_TESTS
+            asm volatile("" : "+v"(c0));
+#endif
+            bsc8 = ParamVec<8>::ld(a.bnb_scale + c0); bsh8 = ParamVec<8>::ld(a.bnb_shift + c0);
+        }
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
             const int mi = s >> 1;
@@ -210,11 +227,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
                 if (EPI == 1) v += (float)*reinterpret_cast<const __bf16*>(gt + grow * 64);
                 if (a.relu) v = fmaxf(v, 0.f);
                 if (EPI == 2) {
-                    // sums of the STORED (bf16) gradient, as the separate reduce pass sees it
-                    const float yv = (float)*reinterpret_cast<const __bf16*>(gt + grow * 64);
-                    const float gq = (yv * bsc + bsh > 0.f) ? (float)(__bf16)v : 0.f;
-                    *reinterpret_cast<__bf16*>(stg + lr * SROW_B + l31 * 2) = (__bf16)gq;
-                    if (live) { s1 += gq; s2 += gq * (yv - bmu) * biv; }
+                    *reinterpret_cast<__bf16*>(stg + lr * SROW_B + l31 * 2) = (__bf16)v;
                 } else {
                     *reinterpret_cast<__bf16*>(stg + lr * SROW_B + l31 * 2) = (__bf16)v;
                     if (live) { s1 += v; s2 += v * v; }
@@ -222,12 +235,36 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             }
             __builtin_amdgcn_wave_barrier();                    // (one wave's LDS operations execute in order; this pins the compiler -- and the emulator's fibers)
             const int m = m0 + wm * 64 + s * SROWS + crow;
-            const bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + crow * SROW_B + cseg * 16);
+            bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + crow * SROW_B + cseg * 16);
+            if (EPI == 2) {
+                // sums of the STORED (bf16) gradient, as the separate reduce pass sees it; second sum as sum g * y, centred per tile below
+                const f32x8 yf = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(smem + GT + wave * 4096 + (s * SROWS + crow) * 64 + cseg * 16), f32x8);
+                f32x8 g = __builtin_convertvector(ch, f32x8);
+                const f32x8 z = yf * bsc8 + bsh8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+                ch = __builtin_convertvector(g, bf16x8);
+                if (m < a.M) { t1 += g; t2 += g * yf; }
+            }
             if (m < a.M) *reinterpret_cast<bf16x8*>(yout + ((unsigned)m * 64u + (unsigned)(32 * wn + cseg * 8))) = ch;
             __builtin_amdgcn_wave_barrier();
         }
         stores_pending = true;
-        if (a.stats) {
+        if (a.stats && EPI == 2) {
+            // lanes with the same segment (lane & 3) hold partial sums of the same 8 channels: combine over lane >> 2, then centre:
+            // sum g * xhat = (sum g * y - mean * sum g) * invstd
+#pragma unroll
+            for (int off = 4; off < 64; off <<= 1)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { t1[e] += __shfl_xor(t1[e], off); t2[e] += __shfl_xor(t2[e], off); }
+            float* rp = red + (it & 1) * (WM * 2 * BN);
+            if (lane < 4) {
+                const f32x8 bmu8 = ParamVec<8>::ld(a.bnb_mean + c0), biv8 = ParamVec<8>::ld(a.bnb_invstd + c0);
+                t2 = (t2 - bmu8 * t1) * biv8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { rp[(wm * 2 + 0) * BN + c0 + e] = t1[e]; rp[(wm * 2 + 1) * BN + c0 + e] = t2[e]; }
+            }
+        } else if (a.stats) {
             s1 += __shfl_xor(s1, 32);
             s2 += __shfl_xor(s2, 32);
             float* rp = red + (it & 1) * (WM * 2 * BN);
