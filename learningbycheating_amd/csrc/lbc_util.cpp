@@ -28,6 +28,7 @@ extern "C" const char* lbc_last_error(void) { return g_err; }
 
 // ---- runtime options -----------------------------------------------------------------
 #include <stdlib.h>
+#include <mutex>
 #include <string.h>
 namespace {
 const char* const kOptNames[kOptCount] = {
@@ -63,11 +64,16 @@ extern "C" long long lbc_config_get(const char* name)
 }
 
 // ---- zero page ---------------------------------------------------------------------------
+// One 256-byte page of zeros per device, keyed by the calling thread's CURRENT device: the launch entry points of this library run
+// with the device of their tensors current (torch's and HIP's own convention for kernel launches; the one place that launches from a
+// foreign device context, the network's side stream, switches first).  The table is filled under a lock.
 int lbc_zero_page(const void** p)
 {
     static void* pages[64] = {nullptr};
+    static std::mutex mu;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { lbc_set_error("zero_page: bad device"); return LBC_ELAUNCH; }
+    std::lock_guard<std::mutex> lock(mu);
     if (!pages[dev]) {
         // first use per device (a warm-up call, outside any stream capture): a synchronous 256-byte allocation, never freed
         void* q = nullptr;
