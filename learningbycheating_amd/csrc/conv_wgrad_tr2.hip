@@ -26,7 +26,10 @@
 
 namespace {
 
-constexpr int kRsQ = 96;         // ring pitch: 64 channels + 32 (192 bytes: the four pixel rows of a transpose read hit disjoint bank groups)
+// ring pitch: 64 channels + 16 = 160 bytes.  The four pixel rows of a transpose read lie TWO ring rows apart here (consecutive low-resolution
+// pixels): 2 x 160 = 320 = 64 (mod 256) puts their 64-byte windows on four disjoint bank groups.  (The 192 bytes of the stride-1 kernel
+// put rows 0 / 2 and 1 / 3 on the same banks: PMC SQ_LDS_BANK_CONFLICT 37 % of the LDS cycles, profiles/r03_final_pmc_lds_conflicts.txt.)
+constexpr int kRsQ = 80;
 constexpr int kRsP = 160;        // P pitch: 128 channels + 32 (320 bytes: likewise for the 64-byte window of a wave's 32 channels)
 
 // kRing >= 128 + 3 W + 2 + 128, kMirror >= W + 40; kRing % 8 == 0
@@ -104,16 +107,22 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tr2_k(WgradArgs a, int rows
     // low-resolution coordinates of the chunk's first pixel (wave-uniform)
     int cx = mbeg % OW, cy = (mbeg / OW) % OH;
     const int j = t16 >> 2;                           // this lane's pixel inside a 4-pixel transpose read
-    for (int c = 0; c < nchunk; ++c) {
+    // Loads run TWO chunks ahead of their use: one workgroup per CU and 18 MFMAs per wave and chunk (~1150 matrix-pipe cycles per SIMD) do not
+    // cover an HBM round trip.  Chunk k's rows travel in register set k & 1 (set A even, B odd): requested at the top of chunk k - 2, written
+    // to LDS at the bottom of chunk k - 1.  The loop is unrolled by two so that the sets stay registers.
+    bf16x8 rpA = {}, rqA[2] = {}, rpB = {}, rqB[2] = {};
+    auto request = [&](const int k, bf16x8& rp, bf16x8 (&rq)[2]) {        // chunk k >= 1: its P rows and the 128 ring rows its window adds
+        if (k < nchunk) {
+            rp = load_p(mbeg + k * BRH + srowP);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) rq[i] = load_q((k - 1) * 128 + HRW + srowQ + 64 * i);
+        }
+    };
+    request(1, rpB, rqB);
+    auto chunk_body = [&](const int c, bf16x8& rp_req, bf16x8 (&rq_req)[2], const bf16x8& rp_st, const bf16x8 (&rq_st)[2]) {
         const int buf = c & 1;
         const bool more = c + 1 < nchunk;
-        bf16x8 rp, rq[2];
-        if (more) {
-            const int mc = mbeg + (c + 1) * BRH;
-            rp = load_p(mc + srowP);
-#pragma unroll
-            for (int k = 0; k < 2; ++k) rq[k] = load_q(c * 128 + HRW + srowQ + 64 * k);
-        }
+        request(c + 2, rp_req, rq_req);
 
         // ---- 2 groups of 16 pixels x 9 taps
         int gx = cx, gy = cy;
@@ -168,13 +177,17 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tr2_k(WgradArgs a, int rows
 
         if (more) {
             const int mc = mbeg + (c + 1) * BRH;
-            store_p(rp, mc + srowP, buf ^ 1);
+            store_p(rp_st, mc + srowP, buf ^ 1);
 #pragma unroll
-            for (int k = 0; k < 2; ++k) store_q(rq[k], base + HRW + srowQ + 64 * k);     // (never overlaps the live window: HRW + 128 <= kRing)
+            for (int k = 0; k < 2; ++k) store_q(rq_st[k], base + HRW + srowQ + 64 * k);     // (never overlaps the live window: HRW + 128 <= kRing)
         }
         base += 128;
         base = base >= kRing ? base - kRing : base;
         __syncthreads();
+    };
+    for (int c = 0; c < nchunk; c += 2) {
+        chunk_body(c, rpA, rqA, rpB, rqB);                     // requests chunk c + 2 (even: set A), stores chunk c + 1 (odd: set B)
+        if (c + 1 < nchunk) chunk_body(c + 1, rpB, rqB, rpA, rqA);
     }
 
     float* out = a.partial + (size_t)split * (size_t)a.CP * 9 * (size_t)a.CQ;
