@@ -288,6 +288,14 @@ typedef struct lbc_aug_params {
 } lbc_aug_params;
 int lbc_birdview_crop_u8(const unsigned char* src, unsigned char* dst, int N, int SH, int SW, int C, int y0, int x0, int H, int W,
                          lbc_stream_t stream);
+/* lbc_birdview_warp_crop_u8: the jittered sample of the privileged agent's loader (reference bird_view/utils/datasets/birdview_lmdb.py:
+ *   103-125): per image, cv2.warpAffine(bird_view, cv2.getRotationMatrix2D((160, 260), delta_angle, 1.0), (320, 320), INTER_LINEAR) and
+ *   the 192 x 192 window at (y0, x0) of the result, in one pass.  params[n].im = the INVERTED 2 x 3 matrix (what warpAffine derives from
+ *   its argument), source (X, Y) = (im[0] x + im[1] y + im[2], im[3] x + im[4] y + im[5]); OpenCV's 8-bit bilinear arithmetic (1/32-pixel
+ *   coordinates, 15-bit weight table, zero border).  src [N][SH][SW][C] -> dst [N][H][W][C]. */
+typedef struct lbc_warp_params { double im[6]; int y0, x0; } lbc_warp_params;
+int lbc_birdview_warp_crop_u8(const unsigned char* src, unsigned char* dst, const lbc_warp_params* params_dev, int N, int SH, int SW, int C,
+                              int H, int W, lbc_stream_t stream);
 int lbc_augment_rgb_u8(unsigned char* images, const lbc_aug_params* params_dev, float* scratch, int N, int H, int W, int any_blur,
                        lbc_stream_t stream);
 

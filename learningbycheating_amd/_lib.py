@@ -96,6 +96,7 @@ _SIGNATURES = {
     "lbc_stem_wgrad_workspace": (c_size_t, [c_int] * 4),
     "lbc_stem_wgrad": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p]),
     "lbc_birdview_crop_u8": (c_int, [c_void_p, c_void_p] + [c_int] * 8 + [c_void_p]),
+    "lbc_birdview_warp_crop_u8": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 6 + [c_void_p]),
     "lbc_augment_rgb_u8": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 4 + [c_void_p]),
     "lbc_config_set": (c_int, [c_char_p, ctypes.c_longlong]),
     "lbc_config_get": (ctypes.c_longlong, [c_char_p]),

@@ -40,6 +40,27 @@ def world_to_pixel(x, y, ox, oy, ori_ox, ori_oy, offset=(-80, 160), size=320, an
     return np.array([pixel_x, pixel_y]) + offset
 
 
+def warp_params(delta_angle, dx, dy, crop_size=192, center=(160, 260)):
+    """lbc_warp_params of one sample as 7 float64 (6 matrix entries + the two int32 origins packed into the 7th): the INVERSE of
+    cv2.getRotationMatrix2D(center, delta_angle, 1.0) exactly as cv2.warpAffine derives it (imgwarp.cpp: D = M0 M4 - M1 M3, ...), and the
+    window origin of birdview_lmdb.py:116-121 (rows dy + 164 - 96 .., columns dx + 160 - 96 ..)"""
+    a = np.deg2rad(np.float64(delta_angle))
+    alpha, beta = np.cos(a), np.sin(a)
+    cx, cy = np.float64(center[0]), np.float64(center[1])
+    m = np.array([alpha, beta, (1 - alpha) * cx - beta * cy, -beta, alpha, beta * cx + (1 - alpha) * cy], np.float64)
+    D = m[0] * m[4] - m[1] * m[3]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = m[4] * D, m[0] * D
+    m0, m1, m3, m4 = A11, m[1] * -D, m[3] * -D, A22
+    b1 = -m0 * m[2] - m1 * m[5]
+    b2 = -m3 * m[2] - m4 * m[5]
+    out = np.empty(7, np.float64)
+    out[:6] = (m0, m1, b1, m3, m4, b2)
+    center_y = center[1] - crop_size // 2
+    out[6:7].view(np.int32)[:] = (int(dy) + center_y - crop_size // 2, int(dx) + center[0] - crop_size // 2)
+    return out
+
+
 class ImageDataset(torch.utils.data.Dataset):
     """reference image_lmdb.py:59-222 (same constructor arguments)"""
 
@@ -67,9 +88,11 @@ class ImageDataset(torch.utils.data.Dataset):
     def __len__(self):
         return len(self.file_map)
 
-    def raw(self, idx):
+    def raw(self, idx, delta_angle=0, dx=0, dy=-PIXEL_OFFSET):
         """the stored bytes of sample idx as zero-copy uint8 views + the derived targets:
-        (rgb (160,384,3) u8, birdview (320,320,7) u8, locations (n_step,2) f64 pixels of the 192-crop, cmd f32, speed f32)"""
+        (rgb (160,384,3) u8, birdview (320,320,7) u8, locations (n_step,2) f64 pixels of the 192-crop, cmd f32, speed f32).
+        delta_angle (degrees) / dx / dy: the rotation and window jitter of the privileged agent's loader (reference
+        birdview_lmdb.py:103-151; image_lmdb.py fixes them at 0 / 0 / -PIXEL_OFFSET) -- the waypoints follow, the caller warps the map"""
         env = self.envs[self.file_map[idx]]
         index = self.idx_map[idx]
         bird_view = np.frombuffer(env.get("birdview_%04d" % index), np.uint8).reshape(320, 320, 7)
@@ -77,8 +100,7 @@ class ImageDataset(torch.utils.data.Dataset):
         rgb_image = np.frombuffer(env.get("rgb_%04d" % index), np.uint8).reshape(160, 384, 3)
         ox, oy, oz, ori_ox, ori_oy, vx, vy, vz, ax, ay, az, cmd, steer, throttle, brake, manual, gear = measurement
         speed = np.linalg.norm([vx, vy, vz])
-        dx, dy = 0, -PIXEL_OFFSET
-        angle = np.arctan2(ori_oy, ori_ox)                       # delta_angle = 0 (image_lmdb.py:146,165-166)
+        angle = np.arctan2(ori_oy, ori_ox) + np.deg2rad(delta_angle)      # (image_lmdb.py:146,165-166 with delta_angle = 0)
         ori_ox, ori_oy = np.cos(angle), np.sin(angle)
         locations = []
         for dt in range(self.gap, self.gap * (self.n_step + 1), self.gap):
@@ -144,11 +166,15 @@ class DeviceLoader:
         import os
         pin = (lambda t: t.pin_memory()) if (cuda and os.environ.get("LBC_PIN_STAGING") == "1") else (lambda t: t)
         B = batch_size
+        # per-sample rotation / window jitter (BirdViewDataset): parameters of lbc_birdview_warp_crop_u8, 56 bytes per image
+        self.jitter = bool(getattr(dataset, "angle_jitter", 0) or getattr(dataset, "crop_x_jitter", 0) or getattr(dataset, "crop_y_jitter", 0))
         self.stage = [{"rgb": pin(torch.empty((B, 160, 384, 3), dtype=torch.uint8)), "bv": pin(torch.empty((B, 320, 320, 7), dtype=torch.uint8)),
-                       "loc": pin(torch.empty((B, dataset.n_step, 2))), "speed": pin(torch.empty(B)), "cmd": torch.empty(B)} for _ in range(2)]
+                       "loc": pin(torch.empty((B, dataset.n_step, 2))), "speed": pin(torch.empty(B)), "cmd": torch.empty(B),
+                       "warp": pin(torch.zeros((B, 7), dtype=torch.float64))} for _ in range(2)]
         self.dev = [{"rgb": torch.empty((B, 160, 384, 3), dtype=torch.uint8, device=self.device),
                      "bv": torch.empty((B, 320, 320, 7), dtype=torch.uint8, device=self.device),
-                     "loc": torch.empty((B, dataset.n_step, 2), device=self.device), "speed": torch.empty(B, device=self.device)} for _ in range(2)]
+                     "loc": torch.empty((B, dataset.n_step, 2), device=self.device), "speed": torch.empty(B, device=self.device),
+                     "warp": torch.zeros((B, 7), dtype=torch.float64, device=self.device)} for _ in range(2)]
         self.copy = torch.cuda.Stream(device=self.device) if cuda else None
         self.ready = [torch.cuda.Event(), torch.cuda.Event()] if cuda else None
         self.free = [torch.cuda.Event(), torch.cuda.Event()] if cuda else None
@@ -161,21 +187,29 @@ class DeviceLoader:
         if self.ready is not None:
             self.ready[k].synchronize()          # the previous H2D out of this staging slot is done
         rgb_np, bv_np = st["rgb"].numpy(), st["bv"].numpy()
-        for i, idx in enumerate(self.rng.randint(len(self.data), size=self.batch)):
-            rgb, bv, loc, cmd, speed = self.data.raw(int(idx))
+        draw = getattr(self.data, "sample_index", None)          # command-biased sampling (BiasedBirdViewDataset), else uniform with replacement
+        indices = [draw(self.rng) for _ in range(self.batch)] if draw else self.rng.randint(len(self.data), size=self.batch)
+        for i, idx in enumerate(indices):
+            if self.jitter:
+                delta_angle, dx, dy = self.data.draw_jitter(self.rng)
+                rgb, bv, loc, cmd, speed = self.data.raw(int(idx), delta_angle, dx, dy)
+                st["warp"][i] = torch.from_numpy(warp_params(delta_angle, dx, dy, self.data.crop_size))
+            else:
+                rgb, bv, loc, cmd, speed = self.data.raw(int(idx))
             np.copyto(rgb_np[i], rgb)
             np.copyto(bv_np[i], bv)
             st["loc"][i] = torch.from_numpy(loc.astype(np.float32))
             st["cmd"][i] = float(cmd)
             st["speed"][i] = float(speed)
         d = self.dev[k]
+        keys = ("rgb", "bv", "loc", "speed", "warp") if self.jitter else ("rgb", "bv", "loc", "speed")
         if self.copy is None:
-            for key in ("rgb", "bv", "loc", "speed"):
+            for key in keys:
                 d[key].copy_(st[key])
             return
         with torch.cuda.stream(self.copy):
             self.copy.wait_event(self.free[k])
-            for key in ("rgb", "bv", "loc", "speed"):
+            for key in keys:
                 d[key].copy_(st[key], non_blocking=True)
             self.ready[k].record(self.copy)
 
@@ -193,8 +227,12 @@ class DeviceLoader:
                 torch.cuda.current_stream(self.device).wait_event(self.ready[k])
             n = self.batch
             bv = torch.empty((n, self.data.crop_size, self.data.crop_size, 7), dtype=torch.uint8, device=self.device)
-            _lib.check(_lib.get().lbc_birdview_crop_u8(_lib.ptr(d["bv"]), _lib.ptr(bv), n, 320, 320, 7, CROP_Y0, CROP_X0, self.data.crop_size,
-                                                       self.data.crop_size, _lib.stream_for(bv)), "birdview_crop_u8")
+            if self.jitter:
+                _lib.check(_lib.get().lbc_birdview_warp_crop_u8(_lib.ptr(d["bv"]), _lib.ptr(bv), _lib.ptr(d["warp"]), n, 320, 320, 7, self.data.crop_size,
+                                                                self.data.crop_size, _lib.stream_for(bv)), "birdview_warp_crop_u8")
+            else:
+                _lib.check(_lib.get().lbc_birdview_crop_u8(_lib.ptr(d["bv"]), _lib.ptr(bv), n, 320, 320, 7, CROP_Y0, CROP_X0, self.data.crop_size,
+                                                           self.data.crop_size, _lib.stream_for(bv)), "birdview_crop_u8")
             rgb, loc, speed, cmd = d["rgb"], d["loc"], d["speed"], st["cmd"].clone()
             if self.batch_aug > 1:               # reference train_image_phase1.py:131-154,183-189: every frame batch_aug times, back to back
                 r = self.batch_aug

@@ -255,6 +255,13 @@ int lbc_birdview_crop_u8(const unsigned char* src, unsigned char* dst, int N, in
     return lbc_crop_u8(src, dst, N, SH, SW, C, y0, x0, H, W, (hipStream_t)stream);
 }
 
+int lbc_birdview_warp_crop_u8(const unsigned char* src, unsigned char* dst, const lbc_warp_params* params_dev, int N, int SH, int SW, int C,
+                              int H, int W, lbc_stream_t stream)
+{
+    static_assert(sizeof(lbc_warp_params) == sizeof(WarpParams), "warp parameter layout");
+    return lbc_warp_crop_u8(src, dst, reinterpret_cast<const WarpParams*>(params_dev), N, SH, SW, C, H, W, (hipStream_t)stream);
+}
+
 int lbc_augment_rgb_u8(unsigned char* images, const lbc_aug_params* params_dev, float* scratch, int N, int H, int W, int any_blur,
                        lbc_stream_t stream)
 {

@@ -40,6 +40,53 @@ __global__ __launch_bounds__(256) void crop_u8_k(const unsigned char* __restrict
     }
 }
 
+// Bird-view rotation + crop, one pass: dst[n] = crop(warpAffine(src[n], M_n)) as the reference's privileged-agent loader does per sample
+// on the CPU (bird_view/utils/datasets/birdview_lmdb.py:103-125: cv2.warpAffine(bird_view, cv2.getRotationMatrix2D((160, 260), delta_angle,
+// 1.0), (320, 320), flags=cv2.INTER_LINEAR), then the jittered 192 x 192 window).  The arithmetic restates OpenCV's 8-bit bilinear
+// warpAffine (imgwarp.cpp, remap with INTER_BITS = 5): source coordinates in 1/1024 fixed point from the INVERTED matrix (rounded half to
+// even like cvRound, + 16, >> 5 -> 1/32 pixel), a 32 x 32 table of 15-bit weights whose four entries are forced to sum to 32768 (the
+// deficit goes to the largest, an excess comes off the smallest), (sum + 16384) >> 15, zero outside the image (BORDER_CONSTANT).
+// p.im = the inverted matrix (iM0, iM1, b1, iM3, iM4, b2) in double, p.y0 / p.x0 the window origin in the warped image.
+__global__ __launch_bounds__(256) void warp_crop_u8_k(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, const WarpParams* __restrict__ params,
+                                                      int N, int SH, int SW, int C, int H, int W)
+{
+    const long long total = (long long)N * H * W;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+        const int n = (int)(i / ((long long)H * W));
+        const int pix = (int)(i - (long long)n * H * W);
+        const WarpParams p = params[n];
+        const int y = p.y0 + pix / W, x = p.x0 + pix % W;
+        const int adelta = (int)rint(p.im[0] * x * 1024.0), bdelta = (int)rint(p.im[3] * x * 1024.0);
+        const int X0 = (int)rint((p.im[1] * y + p.im[2]) * 1024.0) + 16, Y0 = (int)rint((p.im[4] * y + p.im[5]) * 1024.0) + 16;
+        const int X = (X0 + adelta) >> 5, Y = (Y0 + bdelta) >> 5;
+        const int sx = X >> 5, sy = Y >> 5, fx = X & 31, fy = Y & 31;
+        // the weights of table entry (fy, fx)
+        const float ax = (float)fx * (1.f / 32.f), ay = (float)fy * (1.f / 32.f);
+        const float wf[4] = {(1.f - ay) * (1.f - ax), (1.f - ay) * ax, ay * (1.f - ax), ay * ax};
+        int w[4], isum = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { w[k] = (int)rintf(wf[k] * 32768.f); isum += w[k]; }
+        if (isum != 32768) {
+            int mn = 0, mx = 0;
+#pragma unroll
+            for (int k = 1; k < 4; ++k) { if (w[k] < w[mn]) mn = k; if (w[k] > w[mx]) mx = k; }
+            const int diff = isum - 32768;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) if (k == (diff < 0 ? mx : mn)) w[k] -= diff;
+        }
+        const bool in00 = (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW, in01 = (unsigned)sy < (unsigned)SH && (unsigned)(sx + 1) < (unsigned)SW;
+        const bool in10 = (unsigned)(sy + 1) < (unsigned)SH && (unsigned)sx < (unsigned)SW, in11 = (unsigned)(sy + 1) < (unsigned)SH && (unsigned)(sx + 1) < (unsigned)SW;
+        const unsigned char* s0 = src + (((long long)n * SH + sy) * SW + sx) * C;
+        unsigned char* d = dst + i * C;
+        for (int c = 0; c < C; ++c) {
+            const int v00 = in00 ? s0[c] : 0, v01 = in01 ? s0[C + c] : 0, v10 = in10 ? s0[(long long)SW * C + c] : 0, v11 = in11 ? s0[(long long)SW * C + C + c] : 0;
+            const int v = (v00 * w[0] + v01 * w[1] + v10 * w[2] + v11 * w[3] + (1 << 14)) >> 15;
+            d[c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+        }
+    }
+}
+
 // pointwise operators of the per-image sequence order[first[n] .. last[n])
 __global__ __launch_bounds__(256) void aug_pointwise_k(unsigned char* __restrict__ img, const AugParams* __restrict__ params, int N, int H, int W,
                                                        int stage)
@@ -158,6 +205,14 @@ int lbc_crop_u8(const unsigned char* src, unsigned char* dst, int N, int SH, int
     LbcProfScope prof("crop_u8", 0.0, 2.0 * N * H * (double)W * C, s);
     hipLaunchKernelGGL(crop_u8_k, dim3((unsigned)grid_1d((long long)N * H * W * C)), dim3(256), 0, s, src, dst, N, SH, SW, C, y0, x0, H, W);
     return lbc_check_launch("crop_u8");
+}
+
+int lbc_warp_crop_u8(const unsigned char* src, unsigned char* dst, const WarpParams* params_dev, int N, int SH, int SW, int C, int H, int W, hipStream_t s)
+{
+    LBC_REQUIRE(src && dst && params_dev && N > 0 && SH > 1 && SW > 1 && C > 0 && H > 0 && W > 0, "warp_crop_u8: bad arguments");
+    LbcProfScope prof("warp_crop_u8", 0.0, 5.0 * N * H * (double)W * C, s);
+    hipLaunchKernelGGL(warp_crop_u8_k, dim3((unsigned)grid_1d((long long)N * H * W)), dim3(256), 0, s, src, dst, params_dev, N, SH, SW, C, H, W);
+    return lbc_check_launch("warp_crop_u8");
 }
 
 int lbc_augment_u8(unsigned char* img, const AugParams* params_dev, float* tmp, int N, int H, int W, int any_blur, hipStream_t s)

@@ -194,6 +194,11 @@ int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s);
 
 // ---- device-side input pipeline (data.hip) ----------------------------------------------------------------
 enum { kAugBlur = 0, kAugNoise = 1, kAugCoarseDropout = 2, kAugDropout = 3, kAugAdd = 4, kAugMultiply = 5, kAugContrast = 6 };
+struct WarpParams {              // one per image; layout = lbc_warp_params of include/lbc_hip.h
+    double im[6];                // the inverted 2 x 3 matrix: source (X, Y) = (im0 x + im1 y + im2, im3 x + im4 y + im5)
+    int y0, x0;                  // origin of the output window in the warped image
+};
+int lbc_warp_crop_u8(const unsigned char* src, unsigned char* dst, const WarpParams* params_dev, int N, int SH, int SW, int C, int H, int W, hipStream_t s);
 struct AugParams {               // one per image; layout = lbc_aug_params of include/lbc_hip.h
     int order[8];                // operator ids in application order (n_ops valid entries)
     int n_ops;

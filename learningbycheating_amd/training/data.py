@@ -37,15 +37,14 @@ def make_loaders(config, device, rank=0, world=1):
     val_iters = max(1, iters // 100)
     augment, batch_aug = da.get("augment"), int(da.get("batch_aug", 1) or 1)
     if da.get("dataset_dir"):
-        # train_birdview's loader flags (reference bird_view/utils/datasets/birdview_lmdb.py:103-125,169-199: random rotation with
-        # cv2.warpAffine, crop jitter with the waypoints shifted to match, command-biased sampling, a frame cap).  The device loader
-        # implements the un-jittered sample only (the fixed 58:250 x 64:256 window = birdview_lmdb.py with zero jitter); training
-        # WITHOUT the augmentation the flags ask for must not happen silently.
-        asked = {k: da[k] for k in ("crop_x_jitter", "crop_y_jitter", "angle_jitter", "cmd_biased", "max_frames") if da.get(k)}
-        if asked:
-            raise ValueError("--dataset_dir: the on-device bird-view loader has no rotation / crop jitter / command-biased sampling / frame cap "
-                             "yet (asked for: %s).  Pass --x_jitter 0 --y_jitter 0 --angle_jitter 0 (and neither --cmd-biased nor --max_frames) "
-                             "to train on the un-jittered samples, or use --synthetic." % asked)
+        if any(k in da for k in ("crop_x_jitter", "crop_y_jitter", "angle_jitter", "cmd_biased", "max_frames")):
+            # train_birdview's loader (reference bird_view/utils/datasets/birdview_lmdb.py:247-285): rotation / window jitter with the
+            # waypoints following, command-biased sampling, a frame cap -- the rotation runs on the GPU (lbc_birdview_warp_crop_u8)
+            from ..bird_view.utils.datasets.birdview_lmdb import get_birdview_device
+            return get_birdview_device(da["dataset_dir"], bs, device, crop_x_jitter=da.get("crop_x_jitter", 0) or 0,
+                                       crop_y_jitter=da.get("crop_y_jitter", 0) or 0, angle_jitter=da.get("angle_jitter", 0) or 0,
+                                       n_step=da.get("n_step", 5), gap=da.get("gap", 5), max_frames=da.get("max_frames"),
+                                       cmd_biased=bool(da.get("cmd_biased")), samples=(iters, val_iters), seed=0, rank=rank)
         from ..bird_view.utils.datasets.image_lmdb import get_image_device
         return get_image_device(da["dataset_dir"], bs, device, augment=augment, n_step=da.get("n_step", 5), gap=da.get("gap", 5),
                                 batch_aug=batch_aug, samples=(iters, val_iters), seed=0, rank=rank)

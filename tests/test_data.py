@@ -154,6 +154,111 @@ def test_device_loader_batches_crop_and_batch_aug(env, dataset_dir, where):
     assert torch.equal(cmd[:3], cmd[:1].expand(3))
 
 
+# ---- the privileged agent's loader: rotation + window jitter (reference birdview_lmdb.py:33-199) --------------------------------
+def _warp_affine_u8(src, im, y0, x0, H, W):
+    """numpy restatement of OpenCV's 8-bit bilinear cv2.warpAffine (imgwarp.cpp: 1/1024 fixed-point coordinates from the inverted matrix,
+    cvRound, + 16, >> 5; 32 x 32 table of 15-bit weights forced to sum to 32768; (sum + 16384) >> 15; constant zero border) on the window
+    [y0, y0 + H) x [x0, x0 + W) of the destination.  cv2 is not installed here: this twin, like the kernel, follows the published
+    algorithm -- PARITY UNPINNED against cv2 itself."""
+    SH, SW, C = src.shape
+    ys, xs = np.arange(y0, y0 + H)[:, None].astype(np.float64), np.arange(x0, x0 + W)[None, :].astype(np.float64)
+    adelta, bdelta = np.rint(im[0] * xs * 1024.0).astype(np.int64), np.rint(im[3] * xs * 1024.0).astype(np.int64)
+    X0 = np.rint((im[1] * ys + im[2]) * 1024.0).astype(np.int64) + 16
+    Y0 = np.rint((im[4] * ys + im[5]) * 1024.0).astype(np.int64) + 16
+    X, Y = (X0 + adelta) >> 5, (Y0 + bdelta) >> 5
+    sx, sy, fx, fy = X >> 5, Y >> 5, X & 31, Y & 31
+    ax, ay = fx.astype(np.float32) * np.float32(1 / 32), fy.astype(np.float32) * np.float32(1 / 32)
+    wf = np.stack([(1 - ay) * (1 - ax), (1 - ay) * ax, ay * (1 - ax), ay * ax], -1).astype(np.float32)
+    w = np.rint(wf * np.float32(32768)).astype(np.int64)
+    diff = w.sum(-1) - 32768
+    mn, mx = w.argmin(-1), w.argmax(-1)                # (first occurrence, as the scan with strict comparisons)
+    fix = np.where(diff < 0, mx, mn)
+    np.put_along_axis(w, fix[..., None], np.take_along_axis(w, fix[..., None], -1) - diff[..., None], -1)
+    out = np.zeros((H, W, C), np.int64)
+    for k, (oy, ox) in enumerate(((0, 0), (0, 1), (1, 0), (1, 1))):
+        yy, xx = sy + oy, sx + ox
+        ok = (yy >= 0) & (yy < SH) & (xx >= 0) & (xx < SW)
+        v = src[np.clip(yy, 0, SH - 1), np.clip(xx, 0, SW - 1)].astype(np.int64) * ok[..., None]
+        out += v * w[..., k:k + 1]
+    return np.clip((out + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+@pytest.mark.parametrize("where", ["emulator", pytest.param("mi355x", marks=gpu)])
+def test_birdview_warp_crop_kernel(env, where):
+    """lbc_birdview_warp_crop_u8 = the numpy restatement bit for bit (rotations up to +-15 degrees about the ego pixel, windows that reach
+    the zero border); angle 0 = the plain window"""
+    import ctypes
+    from learningbycheating_amd import _lib
+    dev, _ = env
+    rng = np.random.RandomState(11)
+    N = 6
+    src = rng.randint(0, 256, size=(N, 320, 320, 7)).astype(np.uint8)
+    cases = [(0, 0, -10), (5, 3, -8), (-5, -5, -10), (15, 0, -5), (-15, 5, -10), (3, -60, 40)]      # the last: the window leaves the image
+    params = np.stack([D.warp_params(a, dx, dy) for a, dx, dy in cases])
+    d_src, d_par = torch.from_numpy(src).to(dev), torch.from_numpy(params).to(dev)
+    out = torch.empty((N, 192, 192, 7), dtype=torch.uint8, device=dev)
+    _lib.check(_lib.get().lbc_birdview_warp_crop_u8(_lib.ptr(d_src), _lib.ptr(out), _lib.ptr(d_par), N, 320, 320, 7, 192, 192, _lib.stream_for(out)))
+    out = out.cpu().numpy()
+    for n in range(N):
+        y0, x0 = params[n, 6:7].view(np.int32)
+        want = _warp_affine_u8(src[n], params[n, :6], int(y0), int(x0), 192, 192)
+        assert np.array_equal(out[n], want), (cases[n], np.abs(out[n].astype(int) - want.astype(int)).max())
+    assert np.array_equal(out[0], src[0, 58:250, 64:256])
+
+
+def test_birdview_dataset_jitter_cap_and_biased_sampling(dataset_dir):
+    from learningbycheating_amd.bird_view.utils.datasets import birdview_lmdb as B
+    ds = B.BirdViewDataset(os.path.join(dataset_dir, "train"), crop_x_jitter=5, crop_y_jitter=4, angle_jitter=5)
+    base = D.ImageDataset(os.path.join(dataset_dir, "train"))
+    assert len(ds) == len(base)
+    # window jitter alone moves the waypoints with the window (birdview_lmdb.py:139-140)
+    _, _, l0, c0, s0 = ds.raw(3)
+    _, _, l1, _, _ = ds.raw(3, 0, 4, -7)
+    assert np.allclose(l1, l0 - np.array([4, 3]))
+    # rotation: a marker painted at a waypoint of the stored map lands on the rotated sample's waypoint (the map turns about the ego pixel
+    # (160, 260), the waypoints with the ego orientation: birdview_lmdb.py:107-125 -- our warp direction must be the one that agrees)
+    for theta in (5, -5):
+        _, _, lr, _, _ = ds.raw(3, theta, 0, -D.PIXEL_OFFSET)
+        full = np.zeros((320, 320, 1), np.uint8)
+        px, py = l0[2, 0] + 64, l0[2, 1] + 58                 # third waypoint in stored-map pixels (x right, y down)
+        full[int(round(py)) - 1:int(round(py)) + 2, int(round(px)) - 1:int(round(px)) + 2] = 255
+        p = D.warp_params(theta, 0, -D.PIXEL_OFFSET)
+        y0, x0 = p[6:7].view(np.int32)
+        w = _warp_affine_u8(full, p[:6], int(y0), int(x0), 192, 192)[..., 0].astype(np.float64)
+        cy, cx = (w * np.arange(192)[:, None]).sum() / w.sum(), (w * np.arange(192)[None, :]).sum() / w.sum()
+        assert abs(cx - lr[2, 0]) < 1.5 and abs(cy - lr[2, 1]) < 1.5, (theta, cx, cy, lr[2])
+    rng = np.random.RandomState(3)
+    js = np.array([ds.draw_jitter(rng) for _ in range(400)])
+    assert js[:, 0].min() == -5 and js[:, 0].max() == 5 and js[:, 1].min() == -5 and js[:, 1].max() == 5 and js[:, 2].min() == -10 and js[:, 2].max() == -6
+    # frame cap: episodes in reverse-sorted order until max_frames frames are listed (birdview_lmdb.py:64-83)
+    capped = B.BirdViewDataset(os.path.join(dataset_dir, "train"), max_frames=20)
+    assert len(capped) == 20 and len(capped.envs) == 2 and capped.file_map[0] == 0
+    # command-biased sampling: the command is drawn with the given ratios, then a frame of it
+    biased = B.BiasedBirdViewDataset(os.path.join(dataset_dir, "train"), left_ratio=0.0, right_ratio=0.0, straight_ratio=0.0)
+    assert sum(len(v) for v in biased.cmd_map.values()) == len(biased)
+    picks = [biased.sample_index(rng) for _ in range(50)]
+    assert all(p in biased.cmd_map[4] for p in picks)
+
+
+@pytest.mark.parametrize("where", ["emulator", pytest.param("mi355x", marks=gpu)])
+def test_device_loader_with_birdview_jitter(env, dataset_dir, where):
+    """the loader draws (angle, dx, dy) per sample, shifts / rotates the waypoints on the host and warps the stored map on the device"""
+    from learningbycheating_amd.bird_view.utils.datasets import birdview_lmdb as B
+    dev, _ = env
+    ds = B.BirdViewDataset(os.path.join(dataset_dir, "train"), crop_x_jitter=5, crop_y_jitter=0, angle_jitter=5)
+    ld = D.DeviceLoader(ds, batch_size=3, samples=2, device=dev, seed=7)
+    ref_rng = np.random.RandomState(7 * 9973)
+    for rgb, bv, loc, cmd, speed in ld:
+        idx = ref_rng.randint(len(ds), size=3)
+        for i, j in enumerate(idx):
+            a, dx, dy = ds.draw_jitter(ref_rng)
+            _, b_u8, l, c, s = ds.raw(int(j), a, dx, dy)
+            p = D.warp_params(a, dx, dy)
+            y0, x0 = p[6:7].view(np.int32)
+            assert np.array_equal(bv[i].cpu().numpy(), _warp_affine_u8(b_u8, p[:6], int(y0), int(x0), 192, 192))
+            assert torch.allclose(loc[i].cpu(), torch.from_numpy(l).float()) and float(cmd[i]) == float(c)
+
+
 # ---- augmentation: numpy twin of csrc/data.hip ---------------------------------------------------------------------
 def _h32(x):
     x = np.asarray(x, dtype=np.uint64) & 0xFFFFFFFF

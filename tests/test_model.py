@@ -1058,10 +1058,9 @@ def test_training_scripts_birdview_phase2_and_lmdb_dataset(env, tmp_path):
     data = write_synthetic_dataset(str(tmp_path / "data"), episodes=2, frames=48, seed=1)
     common = ["--batch_size", "4", "--iters_per_epoch", "3", "--max_epoch", "1", "--log_iterations", "1"]
     db = tmp_path / "bv"
-    # the reference's default jitter flags (5 px / 5 degrees) are not implemented by the on-device loader: it must refuse, not ignore them
-    with pytest.raises(ValueError, match="jitter"):
-        train_birdview.main(["--log_dir", str(db), "--dataset_dir", data] + common)
-    train_birdview.main(["--log_dir", str(db), "--dataset_dir", data, "--x_jitter", "0", "--y_jitter", "0", "--angle_jitter", "0"] + common)
+    # the reference's default flags (5 px / 5 degrees of jitter: rotation + window on the GPU), then with the frame cap
+    train_birdview.main(["--log_dir", str(db), "--dataset_dir", data] + common)
+    train_birdview.main(["--log_dir", str(db), "--dataset_dir", data, "--x_jitter", "0", "--y_jitter", "3", "--angle_jitter", "0", "--max_frames", "20"] + common)
     sd = torch.load(str(db / "model-1.th"), map_location="cpu")
     assert [(k, tuple(v.shape)) for k, v in sd.items()] == [(k, tuple(s)) for k, s in O.state_dict_layout("birdview", "resnet18")]
     assert all(torch.isfinite(v.float()).all() for v in sd.values())
