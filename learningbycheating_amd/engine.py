@@ -135,6 +135,17 @@ class PolicyEngine:
         for name, t in (("image", image), ("velocity", velocity), ("command", command)):
             if t.device != self.workspace.device:
                 raise RuntimeError("engine.forward: %s lives on %s, the engine on %s" % (name, t.device, self.workspace.device))
+        if train and getattr(self, "_sync", None) is not None and n not in self._sync_batches:
+            # synchronized BatchNorm counts batch x world elements: a rank with another batch (a ragged last batch) would get silently wrong
+            # statistics.  One small all-reduce the first time a batch size is seen
+            import torch.distributed as dist
+            group, world = self._sync_group
+            probe = torch.tensor([float(n), float(-n)], device=image.device if dist.get_backend(group) == "nccl" else "cpu")
+            dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
+            if probe[0].item() != n or probe[1].item() != -n:
+                raise RuntimeError("engine.forward: synchronized BatchNorm needs the same batch on every rank (this rank %d, group %d..%d)"
+                                   % (n, int(-probe[1].item()), int(probe[0].item())))
+            self._sync_batches.add(n)
         pred_sel = torch.empty((n, 5, 2), dtype=torch.float32, device=image.device)
         pred_all = torch.empty((n, 4, 5, 2), dtype=torch.float32, device=image.device)
         _lib.check(fn(self.handle, n, int(train), _lib.ptr(image), _lib.ptr(velocity), _lib.ptr(command),
@@ -186,6 +197,9 @@ class PolicyEngine:
         world = dist.get_world_size(group)
         dev = self.workspace.device
         buf = torch.zeros(SYNC_FLOATS, dtype=torch.float32, device=dev)
+        # only the per-channel SUMS travel; the element count is taken as batch x world: every rank must run the same batch
+        # (forward() verifies each new batch size once across the group)
+        self._sync_group, self._sync_batches = (group, world), set()
         if native is None:      # (gloo ranks may share one GPU in self-tests: RCCL refuses two ranks on one device)
             native = dev.type == "cuda" and dist.get_backend(group) == "nccl"
         if native:
