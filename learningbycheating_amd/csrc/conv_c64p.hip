@@ -22,7 +22,11 @@
 namespace {
 
 // EPI: 0 = plain (affine / bias / ReLU / statistics), 1 = + residual, 2 = fused BatchNorm-backward reduce (IgemmArgs::bnb_*)
-template <int MODE, int EPI>
+// PRE (forward only): BatchNorm + ReLU of the producer applied to the input (IgemmArgs::pre_*) -- a DMA cannot transform what it stages, so
+// the landed halo is transformed IN PLACE once per tile (450 rows x 128 bytes: seven 16-byte chunks per thread, one extra barrier) before the
+// nine taps read it; rows that came from the zero page stay zero.  conv2 of the 64-channel layer reads y1 this way instead of going to
+// conv_halo.hip's register-staged kernel (147 us per launch at 256 images).
+template <int MODE, int EPI, bool PRE = false>
 __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw)
 {
     constexpr int BM = 256, BN = 64, WM = 4, WN = 2, MT = 2;
@@ -132,6 +136,29 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
         // flight); then everybody's are visible -- and nobody reads the other buffer any more
         if (stores_pending) LBC_WAIT_VM(NSTEP); else LBC_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
+        if constexpr (PRE) {
+            // thread -> channel group tid & 7 (its scale / shift: loaded here, through an address the compiler cannot hoist out of the tile
+            // loop -- 16 more registers across the K loop would spill), halo rows tid >> 3, + 64, ...; LDS slot of (row, group) = group ^ swizzle(row)
+            int cg = tid & 7;
+#ifndef LBC_HIP_EMULATED_FOR_TESTS
+            asm volatile("" : "+v"(cg));
+#endif
+            const f32x8 ps8 = ParamVec<8>::ld(a.pre_scale + cg * 8), pt8 = ParamVec<8>::ld(a.pre_shift + cg * 8);
+            const float floor8 = a.pre_relu ? 0.f : -INFINITY;
+            const int HR = BM + 2 * W + 2;
+            for (int hr = tid >> 3; hr < HR; hr += 64) {
+                const int q = m0 - (W + 1) + hr;
+                if (q >= 0 && q < a.M) {
+                    bf16x8* p = reinterpret_cast<bf16x8*>(smem + buf * ABYTES + hr * 128 + ((cg ^ ((hr >> 1) & 7)) << 4));
+                    f32x8 v = __builtin_convertvector(*p, f32x8) * ps8 + pt8;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], floor8);
+                    *p = __builtin_convertvector(v, bf16x8);
+                }
+            }
+            LBC_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+        }
         if (a.stats && it > 0 && tid < BN) {                    // the previous tile's statistics row
             const float* rp = red + ((it - 1) & 1) * (WM * 2 * BN);
             float u1 = 0.f, u2 = 0.f;
@@ -293,7 +320,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
 // are per 256-pixel tile
 int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
 {
-    LBC_REQUIRE(a.C == 64 && a.K == 64 && !a.post_scale == !a.post_shift && !a.pre_scale && (mode == 0 || mode == 1), "conv_c64p: shape");
+    LBC_REQUIRE(a.C == 64 && a.K == 64 && !a.post_scale == !a.post_shift && (mode == 0 || mode == 1), "conv_c64p: shape");
+    LBC_REQUIRE(!a.pre_scale || (mode == 0 && a.pre_shift && !a.resid && !a.bnb_y), "conv_c64p: BatchNorm-on-load serves plain forward launches");
     LBC_REQUIRE(256 + 2 * a.W + 2 < 456, "conv_c64p: image too wide for the halo buffer");
     LBC_REQUIRE(!a.bnb_y || (mode == 1 && !a.resid), "conv_c64p: the fused BatchNorm-backward reduce serves input gradients without a residual");
     const void* zero = nullptr;
@@ -305,6 +333,10 @@ int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
     const dim3 grid((unsigned)lbc_cdiv(ntiles, tpw));
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
 #define LBC_C6(MODEv, EPIv) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw)
+    if (mode == 0 && a.pre_scale) {
+        hipLaunchKernelGGL((conv_c64p_k<0, 0, true>), grid, dim3(512), 0, s, a, zero, ntiles, tpw);
+        return lbc_check_launch("conv_c64p");
+    }
     if (mode == 0) { if (epi == 1) LBC_C6(0, 1); else LBC_C6(0, 0); }
     else { if (epi == 2) LBC_C6(1, 2); else if (epi == 1) LBC_C6(1, 1); else LBC_C6(1, 0); }
 #undef LBC_C6

@@ -379,7 +379,9 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     if (lbc_opt_on(kOptNoHdma) || lbc_opt_on(kOptNoGemm256) || lbc_opt_on(kOptGldsV1)) return -1;
     if (!(a.w_bf16 && a.act_bf16) || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
     // BatchNorm-on-load as an in-LDS transform of the halo: forward only, behind LBC_HDMA_PROLOGUE=1 until it is measured
-    if (a.pre_scale && (mode != 0 || !lbc_opt_on(kOptHdmaPrologue) || (a.C == 64 && a.K == 64))) return -1;
+    // (the 64-channel layer's persistent kernel has it always: conv_c64p_k<0, 0, true>; LBC_NO_C64P_PRE=1 sends those launches back to conv_halo.hip)
+    const bool c64 = a.C == 64 && a.K == 64;
+    if (a.pre_scale && (mode != 0 || (c64 ? (lbc_opt_on(kOptNoC64pPre) || a.resid != nullptr) : !lbc_opt_on(kOptHdmaPrologue)))) return -1;
     if (a.KH != 3 || a.KW != 3 || a.P != 1 || a.S != 1 || a.C % 64 || (mode != 0 && mode != 1)) return -1;
     if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || (long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return -1;
     if ((long long)a.K * 9 * a.C >= (1ll << 31)) return -1;

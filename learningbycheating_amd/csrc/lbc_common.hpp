@@ -70,6 +70,7 @@ enum LbcOpt {
     kOptWgradTr2MinWgs,    // LBC_WGRAD_TR2_MIN_WGS: the stride-2 tap-fused weight gradient takes a launch that yields at least this many workgroups of 16 chunks (default 192)
     kOptWgradTr2Blocks,    // LBC_WGRAD_TR2_BLOCKS: workgroups per launch the split count aims at (default 256)
     kOptGlds4w,            // LBC_GLDS_4W: the four-wave (two workgroups per CU) shapes of conv_glds2_k: 0 = never, 1 = wherever they fit, unset = measured policy
+    kOptNoC64pPre,         // LBC_NO_C64P_PRE: 1 = forward launches of the 64-channel layer with BatchNorm-on-load stay on conv_halo.hip (A/B)
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptCount
 };

@@ -548,6 +548,20 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         lbc_config("LBC_HDMA_PROLOGUE", 0)
         yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
         assert relerr(yp, yq) < 2.0 ** -7
+    if C == 64 and K == 64 and cfgid in (3, -1):
+        # the 64-channel persistent kernel transforms its staged halo in place (conv_c64p_k<0, 0, true>): against the reference, and against
+        # the register-staged kernel it replaces (LBC_NO_C64P_PRE=1 -> conv_halo.hip); same rounding points
+        ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        xin = rbf(F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)))
+        refp = F.conv2d(xin, rbf(w), None, 1, 1)
+        yp, stp = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
+        assert stp.shape[0] == -(-M // 256)             # (its statistics rows: the kernel under test ran)
+        assert relerr(yp, refp) < 5e-4 + OUT_TOL[2]
+        assert torch.allclose(stp[:, 0].sum(0), refp.sum((0, 2, 3)), rtol=2e-3, atol=2e-2)
+        lbc_config("LBC_NO_C64P_PRE", 1)
+        yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
+        assert relerr(yp, yq) < 2.0 ** -7
+        lbc_config("LBC_NO_C64P_PRE", 0)
     # LBC_HDMA_EARLY=1 (fragment reads issued a full depth step ahead, hand-counted lgkmcnt waits): the same MFMAs in the same
     # order -> bit-identical (the emulator checks its address pipeline, the GPU its wait counts)
     if cfgid not in (3, 4) and early_reads_checked(dev):
