@@ -662,6 +662,22 @@ def test_conv3x3_c64_random_shapes(env, shape, force_cfg):
     assert relerr(dx, x.grad) < 1e-4 + OUT_TOL[2]
 
 
+@pytest.mark.parametrize("shape", _rand_shapes(76, 8, 12, 48, 4))
+def test_conv_wgrad_stride2_tap_fused_random_shapes(env, shape, lbc_config):
+    """the stride-2 tap-fused weight gradient on random (images, output rows, output width % 4 == 0 >= 12): pixel counts that do not fill
+    the last 32-pixel chunk, output rows ending anywhere inside a 16-pixel group, ring wrap after a few chunks"""
+    dev, _ = env
+    lbc_config("LBC_WGRAD_TR2_MIN_WGS", 1)
+    N, OH, OW = shape
+    H, W = 2 * OH, 2 * OW
+    x, w = make((N, H, W, 64, 128, 3, 2, 1), 77 + OH * 19 + OW)
+    x = rbf(x)
+    dy = rbf(torch.randn((N, 128, OH, OW), generator=torch.Generator().manual_seed(78)))
+    w1 = w.clone().requires_grad_(True)
+    F.conv2d(x, w1, None, 2, 1).backward(dy)
+    assert relerr(Conv(dev).wgrad(x, dy, 3, 2, 1, bf16=2), w1.grad) < 1e-4
+
+
 @pytest.mark.parametrize("shape", _rand_shapes(73, 6, 8, 24))
 def test_conv_wgrad_tap_fused_random_shapes(env, shape):
     """widths with W % 8 == 0, W % 4 == 0 and neither; pixel counts that do not fill the last 64-pixel chunk"""
