@@ -642,6 +642,33 @@ def test_bn_backward_reduce_fused_into_dgrad_epilogue(env, kind, backbone, h, w,
     assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
 
 
+@pytest.mark.parametrize("precision", [0, 2])
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 16, marks=gpu)])
+def test_staged_backward_equals_the_single_call(env, kind, backbone, h, w, n, precision, lbc_config):
+    """the data-parallel trainer calls the backward stage by stage (head + decoder | layer 4 | ... | stem) and all-reduces a stage's
+    gradient range behind each call: every stage's call must leave exactly what the one-call backward leaves -- in the bf16 mode a
+    stage's weight gradients are deferred to the END of its call (grouped launches), in the f32 modes they ride a side stream"""
+    dev, _ = env
+    if precision == 2:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+    sd = O.make_state_dict(kind, backbone, 19, h, w)
+    x, speed, cmd = _inputs(kind, n, h, w, 13)
+    g = torch.Generator().manual_seed(14)
+    d_all = torch.randn((n, 4, 5, 2), generator=g)
+    grads = []
+    for staged in (False, True):
+        eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
+        eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
+        if staged:
+            for st in range(6):
+                eng.backward(None, d_all.to(dev), st)
+        else:
+            eng.backward(None, d_all.to(dev))
+        grads.append({k: v.detach().cpu().clone() for k, v in eng.grad_views.items()})
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
 @pytest.mark.parametrize("kind,backbone,h,w,nmax,n", [("image", "resnet18", 64, 128, 6, 2), pytest.param("image", "resnet34", 160, 384, 64, 24, marks=gpu)])
 def test_batch_below_the_planned_maximum(env, kind, backbone, h, w, nmax, n, lbc_config):
     """bf16 mode: the workspace (dY arena, split-K slabs) is planned at max_batch, kernel choice and split counts follow the batch of the
