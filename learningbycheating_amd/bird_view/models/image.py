@@ -27,7 +27,10 @@ class ImagePolicyModelSS(common.PolicyBase):
         self.c = {"resnet18": 512, "resnet34": 512}[backbone]
         self.warp = warp
         self.deconv = common.spatial_softmax_decoder()
-        ow, oh = 96, 40
+        # input_hw: not a reference argument (the reference swallows unknown keywords, image.py:23) -- reduced frame sizes for the
+        # CPU-emulated tests; the SpatialSoftmax grid is a quarter of the frame (96 x 40 for the reference's 160 x 384)
+        self.input_hw = tuple(kwargs.get("input_hw", (160, 384)))
+        ow, oh = self.input_hw[1] // 4, self.input_hw[0] // 4
         self.location_pred = nn.ModuleList([
             nn.Sequential(nn.BatchNorm2d(64), nn.Conv2d(64, STEPS, 1, 1, 0), common.SpatialSoftmax(ow, oh, STEPS))
             for _ in range(COMMANDS)])
@@ -35,9 +38,9 @@ class ImagePolicyModelSS(common.PolicyBase):
         self._finish_init()
 
     def forward(self, image, velocity, command):
-        if tuple(image.shape[2:]) != (160, 384):
-            raise ValueError("ImagePolicyModelSS expects 160x384 frames (SpatialSoftmax(96,40) at reference image.py:52,58); "
-                             "got %s" % (tuple(image.shape[2:]),))
+        if tuple(image.shape[2:]) != self.input_hw:
+            raise ValueError("ImagePolicyModelSS expects %dx%d frames (SpatialSoftmax(96,40) at reference image.py:52,58 for 160x384); "
+                             "got %s" % (self.input_hw + (tuple(image.shape[2:]),)))
         location_pred, location_preds = self._run(image, velocity, command)
         if self.all_branch:
             return location_pred, location_preds

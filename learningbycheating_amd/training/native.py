@@ -27,7 +27,7 @@ class NativeTrainer:
     given normalised targets; used to warm-start synthetic benchmarks below the horizon)."""
 
     def __init__(self, student, teacher, batch, image_shape, device, phase=1, lr=1e-4, world_size=1, group=None, camera=None, grad_dtype=None,
-                 sync_bn=False):
+                 sync_bn=False, teacher_shape=(7, 192, 192)):
         self.student, self.teacher, self.phase, self.batch, self.world = student, teacher, phase, batch, world_size
         self.device = device
         student.train()
@@ -35,7 +35,7 @@ class NativeTrainer:
         self.teng = None
         if teacher is not None:
             teacher.eval()
-            self.teng = teacher.engine((batch, 7, 192, 192), device, max_batch=batch, with_grads=False)
+            self.teng = teacher.engine((batch,) + tuple(teacher_shape), device, max_batch=batch, with_grads=False)
         self.cam = camera or camera_struct()
         self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
         self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group, grad_dtype=grad_dtype)   # grad_dtype: see parallel.py
@@ -60,10 +60,11 @@ class NativeTrainer:
         _lib.check(_lib.get().lbc_loss(kind, ctypes.byref(self.cam), _lib.ptr(pred), _lib.ptr(target), n, rows,
                                        1.0 / (n * self.world), _lib.ptr(self.loss), _lib.ptr(dpred), _lib.stream_for(pred)), "loss")
 
-    def step(self, x, speed, command, birdview=None, target=None, update=True, train_mode=True):
+    def step(self, x, speed, command, birdview=None, target=None, update=True, train_mode=True, on_forward=None):
         """x: student input, float32 (N,C,H,W) in [0,1] or the dataset's uint8 (N,H,W,C) frames; command one-hot (N,4);
         returns the per-sample loss (device tensor).  update=False: forward + loss only.  train_mode=False: the student runs
-        in eval mode (running statistics, no buffer update) -- the reference's validation pass (train_image_phase1.py:162-165,256)."""
+        in eval mode (running statistics, no buffer update) -- the reference's validation pass (train_image_phase1.py:162-165,256).
+        on_forward (parity tests): called with the trainer after the student's forward, before the loss and the backward."""
         if not train_mode and update:
             raise ValueError("an eval-mode step cannot update (backward through running-statistics BatchNorm is not implemented)")
         n = x.shape[0]
@@ -85,6 +86,9 @@ class NativeTrainer:
         p_sel, p_all = self.eng.forward(x, speed, command, bool(train_mode))
         if self.phase in (0, 1) and self.side is not None and self.overlap_teacher:
             torch.cuda.current_stream(self.device).wait_stream(self.side)      # the loss reads the teacher's waypoints
+        self.last_pred = (p_sel, p_all)
+        if on_forward is not None:
+            on_forward(self)
         d_sel = d_all = None
         if self.phase == 1:
             self._loss(1, p_all, t_all, 20, self.dpred_all); d_all = self.dpred_all[:n]
@@ -102,5 +106,4 @@ class NativeTrainer:
                 self.reducer.launch(st)
             self.reducer.wait()
             self.opt.step()
-        self.last_pred = (p_sel, p_all)
         return self.loss[:n]
