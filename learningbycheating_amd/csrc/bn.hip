@@ -19,9 +19,10 @@ namespace {
 
 // ---- partial-row pre-reduction: in[rows][cols] -> out[R][cols] ---------------
 __global__ __launch_bounds__(256) void partial_reduce_k(const float* __restrict__ in, int rows, int cols, float* __restrict__ out,
-                                                        float* __restrict__ copy_lo, float* __restrict__ copy_hi)
+                                                        float* __restrict__ copy_lo, float* __restrict__ copy_hi, float tail)
 {
     const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c == 0 && blockIdx.y == 0 && tail >= 0.f) out[cols] = tail;
     if (c >= cols) return;
     // four independent accumulators keep four loads in flight (the loop is latency bound otherwise); fixed order -> deterministic
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(1024) void bn_finalize_k(BnFinalizeArgs a)
     if (c >= a.C || !lead) return;
     float mean, invstd;
     if (a.train) {
-        const double n = (double)a.count;
+        const double n = a.nsum ? (double)a.count / (double)a.n_local * (double)*a.nsum : (double)a.count;
         const double m = s1 / n;
         double var = s2 / n - m * m;
         if (var < 0.0) var = 0.0;
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
     if (a.dbeta) a.dbeta[c] = (float)s1;
     if (a.dgamma) a.dgamma[c] = (float)s2;
     if (a.coefA) {
-        const double n = (double)a.count;
+        const double n = a.nsum ? (double)a.count / (double)a.n_local * (double)*a.nsum : (double)a.count;
         const double g = a.gamma ? (double)a.gamma[c] : 1.0;
         const double inv = (double)a.invstd[c];
         const double mean = (double)a.mean[c];
@@ -381,12 +382,13 @@ int lbc_copy_f32(const float* src, float* dst, long long n, hipStream_t s)
     return lbc_check_launch("copy_f32");
 }
 
-int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s, float* copy_lo, float* copy_hi)
+int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s, float* copy_lo, float* copy_hi, float tail)
 {
     LBC_REQUIRE((!copy_lo && !copy_hi) || (out_rows == 1 && cols % 2 == 0), "partial_reduce: the copy outputs need one output row");
+    LBC_REQUIRE(tail < 0.f || out_rows == 1, "partial_reduce: the tail value needs one output row");
     dim3 grid((unsigned)lbc_cdiv(cols, 256), (unsigned)out_rows);
     LbcProfScope prof("partial_reduce", 0.0, 4.0 * (double)rows * cols, s);
-    hipLaunchKernelGGL(partial_reduce_k, grid, dim3(256), 0, s, in, rows, cols, out, copy_lo, copy_hi);
+    hipLaunchKernelGGL(partial_reduce_k, grid, dim3(256), 0, s, in, rows, cols, out, copy_lo, copy_hi, tail);
     return lbc_check_launch("partial_reduce");
 }
 

@@ -380,16 +380,18 @@ int Net::set_sync_bn(lbc_allreduce_fn fn, void* ctx, int world, float* buf, int 
     return LBC_OK;
 }
 
-int Net::sync_rows(const float*& part, int& rows, int width, hipStream_t s, float* local_lo, float* local_hi)
+int Net::sync_rows(const float*& part, int& rows, int width, int n_local, hipStream_t s, float* local_lo, float* local_hi)
 {
     if (!sync_fn_) return LBC_OK;
-    LBC_REQUIRE(width <= kSyncFloats, "net: %d sums do not fit the SyncBN buffer", width);
+    LBC_REQUIRE(width + 1 <= kSyncFloats, "net: %d sums do not fit the SyncBN buffer", width);
     if (rows > kLbcFinalizeRows) {      // (one thread per column walking thousands of rows would be the longest kernel of the layer)
         LBC_TRY(lbc_partial_reduce(part, rows, width, W(partial2_), 64, s));
         part = W(partial2_); rows = 64;
     }
-    LBC_TRY(lbc_partial_reduce(part, rows, width, sync_buf_, 1, s, local_lo, local_hi));
-    if (sync_fn_(sync_ctx_, sync_buf_, width, s) != 0) {
+    // element `width` = this rank's batch size: its sum over the ranks gives every finalize the global element count, so no rank
+    // has to know (or verify with a collective of its own) what batch the others run
+    LBC_TRY(lbc_partial_reduce(part, rows, width, sync_buf_, 1, s, local_lo, local_hi, (float)n_local));
+    if (sync_fn_(sync_ctx_, sync_buf_, width + 1, s) != 0) {
         lbc_set_error("net: the SyncBN all-reduce callback failed");
         return LBC_ELAUNCH;
     }
@@ -397,14 +399,15 @@ int Net::sync_rows(const float*& part, int& rows, int width, hipStream_t s, floa
     return LBC_OK;
 }
 
-int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running, const float* synced)
+int Net::bn_finalize(const BN& bn, int rows, long long count, int n_local, int train, hipStream_t s, bool update_running, const float* synced)
 {
     const float* part = W(partial_);
+    const float* nsum = nullptr;
     if (train && synced) {
-        part = synced; rows = 1; count *= sync_world_;
+        part = synced; rows = 1; nsum = synced + 2 * bn.C;
     } else if (train && sync_fn_) {
-        LBC_TRY(sync_rows(part, rows, 2 * bn.C, s));
-        count *= sync_world_;
+        LBC_TRY(sync_rows(part, rows, 2 * bn.C, n_local, s));
+        nsum = part + 2 * bn.C;
     } else if (train && rows > kLbcFinalizeRows) {
         LBC_TRY(lbc_partial_reduce(W(partial_), rows, 2 * bn.C, W(partial2_), 64, s));
         part = W(partial2_);
@@ -412,7 +415,7 @@ int Net::bn_finalize(const BN& bn, int rows, long long count, int train, hipStre
     }
     BnFinalizeArgs f;
     memset(&f, 0, sizeof(f));
-    f.partial = part; f.rows = rows; f.C = bn.C; f.count = count;
+    f.partial = part; f.rows = rows; f.C = bn.C; f.count = count; f.nsum = nsum; f.n_local = n_local;
     f.gamma = P(bn.g); f.beta = P(bn.b);
     f.running_mean = (train && !update_running) ? nullptr : P(bn.rm);
     f.running_var = (train && !update_running) ? nullptr : P(bn.rv);
@@ -451,7 +454,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
     st.xp = W(xp_); st.xp_bf16 = bf16_; st.w = P(stem_w_); st.y = W(y0_); st.stats = tr ? W(partial_) : nullptr;
     st.N = N; st.H = H0; st.W = W0; st.Cin = Cin; st.act_bf16 = act_bf16_; st.bf16 = bf16_;
     LBC_TRY(lbc_stem_fwd(st, s));
-    if (tr) LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), train, s));
+    if (tr) LBC_TRY(bn_finalize(stem_bn_, lbc_stem_rows(st), (long long)N * (H0 / 2) * (W0 / 2), N, train, s));
     PoolFwdArgs pf;
     pf.y = W(y0_); pf.scale = W(stem_bn_.scale); pf.shift = W(stem_bn_.shift); pf.p = W(p0_);
     pf.idx = reinterpret_cast<unsigned char*>(W(idx_));
@@ -476,7 +479,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             continue;
         }
         LBC_TRY(conv_fwd(b.c1, x, N, tr, &rows, s));
-        LBC_TRY(bn_finalize(b.b1, rows, pix, train, s));
+        LBC_TRY(bn_finalize(b.b1, rows, pix, N, train, s));
         BnApplyArgs ap;
         if (b.fuse_z1) {
             LBC_TRY(conv_fwd(b.c2, W(b.c1.y), N, tr, &rows, s, &b.b1));
@@ -487,13 +490,13 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             LBC_TRY(lbc_bn_apply(ap, s));
             LBC_TRY(conv_fwd(b.c2, W(b.z1), N, tr, &rows, s));
         }
-        LBC_TRY(bn_finalize(b.b2, rows, pix, train, s));
+        LBC_TRY(bn_finalize(b.b2, rows, pix, N, train, s));
         memset(&ap, 0, sizeof(ap));
         ap.x = W(b.c2.y); ap.y = W(b.out); ap.pixels = pix; ap.C = b.c2.Cout;
         ap.scale = W(b.b2.scale); ap.shift = W(b.b2.shift); ap.relu = 1; ap.act_bf16 = act_bf16_;
         if (b.has_ds) {
             LBC_TRY(conv_fwd(b.ds, x, N, tr, &rows, s));
-            LBC_TRY(bn_finalize(b.bd, rows, pix, train, s));
+            LBC_TRY(bn_finalize(b.bd, rows, pix, N, train, s));
             ap.resid = W(b.ds.y); ap.rscale = W(b.bd.scale); ap.rshift = W(b.bd.shift);
         } else {
             ap.resid = x;
@@ -513,7 +516,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         LBC_TRY(lbc_chan_reduce(cr, 0, s));
         rows = lbc_chan_reduce_rows(cr.pixels, 640);
     }
-    if (tr) LBC_TRY(bn_finalize(dec_[0].bn, rows, (long long)N * th * tw, train, s));
+    if (tr) LBC_TRY(bn_finalize(dec_[0].bn, rows, (long long)N * th * tw, N, train, s));
     const float* din = W(hcat_);
     for (int i = 0; i < 3; ++i) {
         Deconv& D = dec_[i];
@@ -561,13 +564,13 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         if (!tr) {
             // eval: statistics come from bn_eval_prep
         } else if (i < 2) {
-            LBC_TRY(bn_finalize(dec_[i + 1].bn, 4 * per, opix, train, s));
+            LBC_TRY(bn_finalize(dec_[i + 1].bn, 4 * per, opix, N, train, s));
         } else {
             // image.py:54-60: the four branch BatchNorms see the same tensor -> same batch statistics
             const float* part = W(partial_);
             int prow = 4 * per;
-            LBC_TRY(sync_rows(part, prow, 2 * 64, s));     // SyncBN: one all-reduce serves the four finalizes
-            for (int b = 0; b < 4; ++b) LBC_TRY(bn_finalize(head_bn_[b], 4 * per, opix, train, s, true, sync_fn_ ? part : nullptr));
+            LBC_TRY(sync_rows(part, prow, 2 * 64, N, s));     // SyncBN: one all-reduce serves the four finalizes
+            for (int b = 0; b < 4; ++b) LBC_TRY(bn_finalize(head_bn_[b], 4 * per, opix, N, train, s, true, sync_fn_ ? part : nullptr));
         }
         din = W(D.u);
     }
@@ -598,8 +601,8 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
 int Net::bn_bwd_finalize(BnBwdFinalizeArgs f, hipStream_t s)
 {
     if (sync_fn_) {
-        LBC_TRY(sync_rows(f.partial, f.rows, 2 * f.C, s, f.dbeta, f.dgamma));
-        f.count *= sync_world_;
+        LBC_TRY(sync_rows(f.partial, f.rows, 2 * f.C, lastN_, s, f.dbeta, f.dgamma));
+        f.nsum = f.partial + 2 * f.C; f.n_local = lastN_;
         f.dgamma = nullptr; f.dbeta = nullptr;
     }
     return lbc_bn_bwd_finalize(f, s);
@@ -907,8 +910,8 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
         hf.mean = W(head_bn_[0].mean); hf.invstd = W(head_bn_[0].invstd); hf.chan_coef = W(head_coef_);
         LBC_TRY(lbc_head_bwd_finalize(hf, s));
         if (sync_fn_) {      // second pass on the global sums: only the per-channel coefficients of the input gradient
-            LBC_TRY(sync_rows(hf.s_partial, hf.rows, 20 * 65, s));
-            hf.count *= sync_world_; hf.coef_only = 1;
+            LBC_TRY(sync_rows(hf.s_partial, hf.rows, 20 * 65, N, s));
+            hf.nsum = hf.s_partial + 20 * 65; hf.n_local = N; hf.coef_only = 1;
             LBC_TRY(lbc_head_bwd_finalize(hf, s));
         }
         LBC_TRY(lbc_head_bwd_apply(hb, s));   // E = dU3

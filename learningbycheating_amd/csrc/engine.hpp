@@ -87,7 +87,7 @@ public:
     // Synchronized BatchNorm for data parallelism: every BatchNorm's batch sums (forward) and gradient sums (backward) are
     // all-reduced through `fn` before they are finalized, so the ranks normalise with the statistics of the global batch.
     // buf: device scratch of >= kSyncFloats floats the callback reduces in place.  fn == nullptr: local BatchNorm.
-    static const int kSyncFloats = 1536;
+    static const int kSyncFloats = 1536;     // >= 20 * 65 + 1 (head) and 2 * 640 + 1 (the widest BatchNorm) sums + the batch size
     int set_sync_bn(lbc_allreduce_fn fn, void* ctx, int world, float* buf, int buf_floats);
 
 private:
@@ -114,11 +114,12 @@ private:
     int weight_prep(hipStream_t s);
     bool conv_takes_glds(const Conv& c, int N, bool with_prologue = false) const;
     // synced: partial_ rows were all-reduced already by sync_rows() (several BatchNorms finalized from the same sums)
-    int bn_finalize(const BN& bn, int rows, long long count, int train, hipStream_t s, bool update_running = true,
+    int bn_finalize(const BN& bn, int rows, long long count, int n_local, int train, hipStream_t s, bool update_running = true,
                     const float* synced = nullptr);
     // SyncBN: part[rows][width] -> one row summed over every rank (in sync_buf_); no-op (returns part) when not enabled
     // local_lo / local_hi (nullable): the halves of this rank's own row are also written there, before the exchange
-    int sync_rows(const float*& part, int& rows, int width, hipStream_t s, float* local_lo = nullptr, float* local_hi = nullptr);
+    // the batch size of this rank travels behind the sums (element `width` of the all-reduced row): finalizes divide by the GLOBAL count
+    int sync_rows(const float*& part, int& rows, int width, int n_local, hipStream_t s, float* local_lo = nullptr, float* local_hi = nullptr);
     int bn_bwd_finalize(BnBwdFinalizeArgs f, hipStream_t s);
     lbc_allreduce_fn sync_fn_ = nullptr;
     void* sync_ctx_ = nullptr;

@@ -394,7 +394,8 @@ __global__ __launch_bounds__(256) void head_bwd_finalize_k(HeadBwdFinalizeArgs a
             k1 += (double)a.gamma[b][tid] * (double)sDB[b * 64 + tid];
             k2 += (double)a.gamma[b][tid] * (double)sDG[b * 64 + tid];
         }
-        k1 /= (double)a.count; k2 /= (double)a.count;
+        const double n = a.nsum ? (double)a.count / (double)a.n_local * (double)*a.nsum : (double)a.count;
+        k1 /= n; k2 /= n;
         const double inv = (double)a.invstd[tid];
         a.chan_coef[tid] = (float)(inv * k1);
         a.chan_coef[64 + tid] = (float)(inv * k2);

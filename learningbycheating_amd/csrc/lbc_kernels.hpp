@@ -10,6 +10,9 @@ struct BnFinalizeArgs {
     const float* partial;        // [rows][2][C] (sum, sum^2); unused in eval
     int rows, C;
     long long count;             // N*H*W
+    // SyncBN (nullable): *nsum = the batch size summed over all ranks (one float behind the all-reduced sums), n_local = this
+    // rank's batch: the statistics are over count / n_local * *nsum elements -- ranks may run different batch sizes
+    const float* nsum; int n_local;
     const float* gamma;          // nullable (=1)
     const float* beta;           // nullable (=0)
     float* running_mean;         // train: updated (nullable); eval: read
@@ -36,8 +39,9 @@ struct BnEvalArgs {
 };
 int lbc_bn_eval_prep(const BnEvalArgs& a, hipStream_t s);
 // copy_lo / copy_hi (nullable, out_rows == 1 only): the first / second half of the output row is also written there
+// tail >= 0 (out_rows == 1 only): out[cols] = tail (SyncBN: this rank's batch size travels behind the sums)
 int lbc_partial_reduce(const float* in, int rows, int cols, float* out, int out_rows, hipStream_t s, float* copy_lo = nullptr,
-                       float* copy_hi = nullptr);
+                       float* copy_hi = nullptr, float tail = -1.f);
 int lbc_bn_finalize(const BnFinalizeArgs& a, hipStream_t s);
 
 struct BnApplyArgs {
@@ -72,6 +76,7 @@ int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s);
 
 struct BnBwdFinalizeArgs {
     const float* partial; int rows, C; long long count;
+    const float* nsum; int n_local;       // SyncBN (nullable): as BnFinalizeArgs
     const float* gamma; const float* mean; const float* invstd;
     int train;
     float* dgamma; float* dbeta;          // nullable
@@ -183,6 +188,7 @@ int lbc_head_bwd_max_rows(int max_batch);      // bound of the above over N <= m
 int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s);
 struct HeadBwdFinalizeArgs {
     const float* s_partial; int rows; long long count;   // count = N*HW
+    const float* nsum; int n_local;                      // SyncBN (nullable): as BnFinalizeArgs
     const float* gamma[4]; const float* beta[4]; const float* w[4];
     const float* mean; const float* invstd;              // shared batch statistics [64]
     float* dgamma[4]; float* dbeta[4]; float* dw[4]; float* dbias[4];

@@ -135,21 +135,12 @@ class PolicyEngine:
         for name, t in (("image", image), ("velocity", velocity), ("command", command)):
             if t.device != self.workspace.device:
                 raise RuntimeError("engine.forward: %s lives on %s, the engine on %s" % (name, t.device, self.workspace.device))
-        if train and getattr(self, "_sync", None) is not None and n not in self._sync_batches:
-            # synchronized BatchNorm counts batch x world elements: a rank with another batch (a ragged last batch) would get silently wrong
-            # statistics.  One small all-reduce the first time a batch size is seen
-            import torch.distributed as dist
-            group, world = self._sync_group
-            probe = torch.tensor([float(n), float(-n)], device=image.device if dist.get_backend(group) == "nccl" else "cpu")
-            dist.all_reduce(probe, op=dist.ReduceOp.MAX, group=group)
-            if probe[0].item() != n or probe[1].item() != -n:
-                raise RuntimeError("engine.forward: synchronized BatchNorm needs the same batch on every rank (this rank %d, group %d..%d)"
-                                   % (n, int(-probe[1].item()), int(probe[0].item())))
-            self._sync_batches.add(n)
+        # (synchronized BatchNorm: every all-reduced row of sums carries this rank's batch size behind it, and the finalize kernels
+        #  divide by the summed count -- ranks may run different batch sizes, and no rank enters a collective the others might skip)
         pred_sel = torch.empty((n, 5, 2), dtype=torch.float32, device=image.device)
         pred_all = torch.empty((n, 4, 5, 2), dtype=torch.float32, device=image.device)
-        _lib.check(fn(self.handle, n, int(train), _lib.ptr(image), _lib.ptr(velocity), _lib.ptr(command),
-                      _lib.ptr(pred_sel), _lib.ptr(pred_all), _lib.stream_for(image)), "net_forward")
+        self._check(fn(self.handle, n, int(train), _lib.ptr(image), _lib.ptr(velocity), _lib.ptr(command),
+                       _lib.ptr(pred_sel), _lib.ptr(pred_all), _lib.stream_for(image)), "net_forward")
         self.generation += 1
         self.last_batch = n
         return pred_sel, pred_all
@@ -160,7 +151,17 @@ class PolicyEngine:
             if t is not None and (t.dtype != torch.float32 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.workspace.device):
                 raise RuntimeError("engine.backward: %s must be a contiguous float32 %s tensor on %s (the last forward ran %d samples), got %s %s on %s"
                                    % (name, shape, self.workspace.device, self.last_batch, t.dtype, tuple(t.shape), t.device))
-        _lib.check(_lib.get().lbc_net_backward(self.handle, _lib.ptr(d_sel), _lib.ptr(d_all), stage, _lib.stream_for(ref)), "net_backward")
+        self._check(_lib.get().lbc_net_backward(self.handle, _lib.ptr(d_sel), _lib.ptr(d_all), stage, _lib.stream_for(ref)), "net_backward")
+
+    def _check(self, rc, what):
+        """_lib.check, with the exception a SyncBN all-reduce callback caught (it must not unwind through the C frames) as the cause"""
+        sync = getattr(self, "_sync", None)
+        err = sync.get("error") if sync else None
+        if rc != 0 and err is not None:
+            sync["error"] = None
+            raise RuntimeError("lbc_hip %s failed (%d): the synchronized-BatchNorm all-reduce raised %s: %s"
+                               % (what, rc, type(err).__name__, err)) from err
+        _lib.check(rc, what)
 
     # ---- introspection (parity tests) ------------------------------------------------------
     def activations(self):
@@ -197,9 +198,8 @@ class PolicyEngine:
         world = dist.get_world_size(group)
         dev = self.workspace.device
         buf = torch.zeros(SYNC_FLOATS, dtype=torch.float32, device=dev)
-        # only the per-channel SUMS travel; the element count is taken as batch x world: every rank must run the same batch
-        # (forward() verifies each new batch size once across the group)
-        self._sync_group, self._sync_batches = (group, world), set()
+        # the per-channel sums travel with this rank's batch size behind them (csrc/engine.cpp Net::sync_rows)
+        self._sync_group = (group, world)
         if native is None:      # (gloo ranks may share one GPU in self-tests: RCCL refuses two ranks on one device)
             native = dev.type == "cuda" and dist.get_backend(group) == "nccl"
         if native:

@@ -70,6 +70,15 @@ class StageAllReducer:
         else:
             self._reduce(lo, hi)
 
+    def fence(self):
+        """the current stream waits for everything launched on the communication stream so far (gloo / CPU: launches are synchronous
+        or waited for here)"""
+        for w in self.pending:
+            w.wait()
+        self.pending = []
+        if self.comm is not None:
+            torch.cuda.current_stream().wait_stream(self.comm)
+
     def wait(self):
         for w in self.pending:
             w.wait()

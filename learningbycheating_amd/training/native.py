@@ -39,6 +39,7 @@ class NativeTrainer:
         self.cam = camera or camera_struct()
         self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
         self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group, grad_dtype=grad_dtype)   # grad_dtype: see parallel.py
+        self.sync_bn = bool(sync_bn and world_size > 1)
         if sync_bn and world_size > 1:
             # BatchNorm over the global batch (not in the reference: it trains 256 images on one device, which is what this
             # restores for 8 x 32).  On a GPU the reductions run on the library's own RCCL communicator (`group` only carries
@@ -104,6 +105,12 @@ class NativeTrainer:
             for st in range(self.nstages):
                 self.eng.backward(d_sel, d_all, st)
                 self.reducer.launch(st)
+                if self.sync_bn:
+                    # two communicators (the buckets' and the BatchNorm rows') must meet in ONE order on every rank: kernels of two
+                    # RCCL communicators that become resident in different orders on two devices can wait for each other forever.
+                    # With synchronized BatchNorm the next stage's rows therefore queue behind this stage's bucket (no overlap of the
+                    # bucket with the backward in this mode; local BatchNorm -- the default -- has a single communicator and keeps it)
+                    self.reducer.fence()
             self.reducer.wait()
             self.opt.step()
         return self.loss[:n]

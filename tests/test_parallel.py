@@ -221,9 +221,9 @@ def test_data_parallel_gradients_emulated_gloo_world2():
     assert err <= 1e-6 * scale + 1e-12, (err, scale)
 
 
-def _syncbn_worker(rank, world, port, q):
-    """SyncBN: two ranks x n images must reproduce ONE process on the 2n-image batch -- waypoints of the rank's shard, running
-    statistics, and (after the gradient all-reduce) every parameter gradient"""
+def _syncbn_worker(rank, world, port, q, sizes=None):
+    """SyncBN: the ranks' shards (sizes[r] images on rank r; default 2 each) must reproduce ONE process on the whole batch -- waypoints
+    of the rank's shard, running statistics, and (after the gradient all-reduce) every parameter gradient"""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -235,17 +235,19 @@ def _syncbn_worker(rank, world, port, q):
     from learningbycheating_amd.training.native import camera_struct
     from oracle import lbc_oracle as O
     from tests.helpers import engine_from_state_dict
-    h, w, n = 32, 64, 2
+    h, w = 32, 64
+    sizes = list(sizes) if sizes else [2] * world
+    total, n, first = sum(sizes), sizes[rank], sum(sizes[:rank])
     # (seeds: with 43/51 one pre-activation of the second decoder stage lands within rounding of the ReLU kink and the 4-image
     # single-process run masks it differently from torch autograd AND from the two-rank run: a 13% difference in one
     # weight-gradient element that says nothing about either path)
     sd = O.make_state_dict("image", "resnet18", 44, h, w)
     g = torch.Generator().manual_seed(52)
-    x = torch.rand((world * n, 3, h, w), generator=g)
-    x[n:] = x[n:] * 0.5 + 0.4            # the shards differ in their statistics: local BatchNorm would not match
-    speed = torch.rand(world * n, generator=g) * 10
-    cmd = O.one_hot(torch.randint(1, 5, (world * n,), generator=g).float())
-    tgt = torch.rand((world * n, 4, 5, 2), generator=g) * 2 - 1
+    x = torch.rand((total, 3, h, w), generator=g)
+    x[sizes[0]:] = x[sizes[0]:] * 0.5 + 0.4            # the shards differ in their statistics: local BatchNorm would not match
+    speed = torch.rand(total, generator=g) * 10
+    cmd = O.one_hot(torch.randint(1, 5, (total,), generator=g).float())
+    tgt = torch.rand((total, 4, 5, 2), generator=g) * 2 - 1
     cam = camera_struct()
     lib = _lib.get()
 
@@ -257,10 +259,11 @@ def _syncbn_worker(rank, world, port, q):
         loss = torch.zeros(batch)
         d = torch.zeros((batch, 4, 5, 2))
         t = tgt[sl].contiguous()
-        _lib.check(lib.lbc_loss(3, ctypes.byref(cam), _lib.ptr(pa), _lib.ptr(t), batch, 20, 1.0 / (n * world), _lib.ptr(loss), _lib.ptr(d), None))
+        # (the sum over ranks of the shard gradients = the gradient of the mean over the WHOLE batch, whatever the shard sizes)
+        _lib.check(lib.lbc_loss(3, ctypes.byref(cam), _lib.ptr(pa), _lib.ptr(t), batch, 20, 1.0 / total, _lib.ptr(loss), _lib.ptr(d), None))
         return eng, tens, pa, d
 
-    sl = slice(rank * n, (rank + 1) * n)
+    sl = slice(first, first + n)
     eng, tens, pa, d = run(sl, n, True)
     red = StageAllReducer(eng.grad_flat, eng.grad_spans)
     for st in range(6):
@@ -272,19 +275,23 @@ def _syncbn_worker(rank, world, port, q):
     eng.set_sync_bn(enable=False)
     _, pa_local = eng.forward(x[sl].contiguous(), speed[sl].contiguous(), cmd[sl].contiguous(), True)
     if rank == 0:
-        e1, t1, pa1, d1 = run(slice(0, world * n), world * n, False)
+        e1, t1, pa1, d1 = run(slice(0, total), total, False)
         e1.backward(None, d1)
         rel = lambda a, b: float((a - b).abs().max() / (b.abs().max() + 1e-30))
         stats = max(rel(tens[k], t1[k]) for k in tens if k.endswith(("running_mean", "running_var")))
         nbt = all(int(tens[k]) == int(t1[k]) for k in tens if k.endswith("num_batches_tracked"))
         worst_name, worst = "", 0.0
         floor = 1e-3 * float(e1.grad_flat.abs().max())    # (the head's conv biases have a mathematically zero gradient: softmax shift invariance)
+        allr = []
         for name, (off, cnt) in eng.grad_offsets.items():
             o1 = e1.grad_offsets[name][0]
             a, b = eng.grad_flat[off:off + cnt], e1.grad_flat[o1:o1 + cnt]
             r = float((a - b).abs().max() / (b.abs().max() + floor))
+            allr.append((r, name))
             if r > worst:
                 worst_name, worst = name, r
+        if os.environ.get("LBC_TEST_VERBOSE"):
+            worst_name += " | " + " ".join("%s=%.1e" % (nm, rr) for rr, nm in sorted(allr, reverse=True)[:12])
         q.put((rel(pa, pa1[sl]), stats, nbt, worst, worst_name, rel(pa_local, pa1[sl])))
     dist.barrier()
     dist.destroy_process_group()
@@ -296,6 +303,69 @@ def test_sync_batchnorm_matches_single_process_global_batch_gloo_world2():
     assert stats <= 2e-5 and nbt, (stats, nbt)
     assert grad <= 2e-4, (grad, name)
     assert local > 1e-3, local       # the control: local statistics on this shard give different waypoints
+
+
+def test_sync_batchnorm_ragged_shards_gloo_world2():
+    """ranks with DIFFERENT batch sizes (3 and 2 images; with 2 and 3 one layer-4 pre-activation sits on its ReLU kink, see the seed note in _syncbn_worker): every all-reduced row of sums carries the rank's batch size behind it and
+    the finalize kernels divide by the summed count (Net::sync_rows), so the global statistics -- and with the loss scaled by the
+    global batch, all gradients -- equal ONE process on the 5-image batch.  No rank enters a collective the other may skip (the
+    per-batch-size probe this replaces deadlocked RCCL when only one rank saw a new size)."""
+    (pred, stats, nbt, grad, name, local), = _run_world(_syncbn_worker, 2, extra=([3, 2],), results=1, timeout=900)
+    assert pred <= 2e-5, pred
+    assert stats <= 2e-5 and nbt, (stats, nbt)
+    assert grad <= 2e-4, (grad, name)
+
+
+def test_sync_batchnorm_and_gradient_buckets_gloo_world4():
+    """four ranks (the 4-GPU line of the scaling run): SyncBN rows and the six staged gradient buckets through one step"""
+    (pred, stats, nbt, grad, name, local), = _run_world(_syncbn_worker, 4, extra=([1, 1, 1, 1],), results=1, timeout=1200)
+    assert pred <= 2e-5, pred
+    assert stats <= 2e-5 and nbt, (stats, nbt)
+    assert grad <= 2e-4, (grad, name)
+
+
+def test_data_parallel_gradients_emulated_gloo_world4():
+    (err, scale), = _run_world(_dp_worker, 4, results=1, timeout=900)
+    assert err <= 1e-6 * scale + 1e-12, (err, scale)
+
+
+def _sync_error_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import emu
+    emu.activate()
+    from oracle import lbc_oracle as O
+    from tests.helpers import engine_from_state_dict
+    h, w, n = 32, 64, 2
+    sd = O.make_state_dict("image", "resnet18", 44, h, w)
+    eng, _ = engine_from_state_dict(sd, "image", "resnet18", h, w, n, torch.device("cpu"))
+    eng.set_sync_bn(dist.new_group(), native=False)
+    real = dist.all_reduce
+
+    def broken(*a, **k):
+        raise ValueError("link down (injected)")
+    dist.all_reduce = broken
+    msg, cause = "", ""
+    try:
+        eng.forward(torch.rand(n, 3, h, w), torch.rand(n), O.one_hot(torch.tensor([1.0, 2.0])), True)
+    except RuntimeError as e:
+        msg, cause = str(e), repr(e.__cause__)
+    finally:
+        dist.all_reduce = real
+    # the executor is usable again afterwards
+    eng.set_sync_bn(enable=False)
+    eng.forward(torch.rand(n, 3, h, w), torch.rand(n), O.one_hot(torch.tensor([1.0, 2.0])), True)
+    q.put((msg, cause))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sync_batchnorm_callback_error_reaches_the_caller():
+    """an exception inside the torch.distributed callback cannot unwind through the C frames: it is kept and re-raised as the
+    cause of the RuntimeError the failed lbc_net_forward call turns into"""
+    (msg, cause), = _run_world(_sync_error_worker, 1, results=1, timeout=300)
+    assert "synchronized-BatchNorm all-reduce raised ValueError" in msg and "link down (injected)" in cause, (msg, cause)
 
 
 @pytest.mark.gpu
