@@ -63,9 +63,18 @@ __device__ __forceinline__ void fold_branch(const HeadArgs& a, int b, float* sW 
     for (int idx = tid; idx < 320; idx += nthr) {
         const int c = idx & 63;
         const float wf = a.w[b][idx] * a.gamma[b][c] * inv[c];
-        // bf16 activations: the forward multiplies on the bf16 MFMA, so the folded weight is a bf16 value everywhere
-        // (forward, and the backward's recomputation of the logits) -- the saved soft-max statistics stay consistent
-        sW[idx] = a.act_bf16 ? (float)(__bf16)wf : wf;
+        // bf16 activations: the forward multiplies on the bf16 MFMA, so the folded weight is a value that MFMA can multiply with
+        // everywhere (forward, and the backward's recomputation of the logits) -- the saved soft-max statistics stay consistent.
+        // wsplit (default): the sum of a bf16 high part and a bf16 low part (two MFMAs per k-block: ~16 significant bits, the
+        // head is as accurate as the f32 kernels on the same bf16 decoder output; it streams h from HBM, the second MFMA is
+        // free); otherwise one bf16 value (2^-9 relative: a FIXED perturbation of the 64 -> 5 projection that no master-weight
+        // update below half a bf16 ulp can reach)
+        float v = wf;
+        if (a.act_bf16) {
+            const float hi = (float)(__bf16)wf;
+            v = a.wsplit ? hi + (float)(__bf16)(wf - hi) : hi;
+        }
+        sW[idx] = v;
     }
     if (tid < 5) {
         float t = a.bias[b][tid];
@@ -165,11 +174,16 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(HeadArgs a)
     __syncthreads();
     const bool colok = l31 < 20;
     const int cb = colok ? l31 / 5 : 0, cs = colok ? l31 - 5 * cb : 0;     // branch and step of this lane's column
-    bf16x8 wb[4];
+    bf16x8 wb[4], wl[4];            // high and low bf16 parts of the folded weights (wl = 0 without wsplit)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wb[g][j] = (__bf16)(colok ? sWf[cb * 320 + cs * 64 + g * 16 + kh * 8 + j] : 0.f);
+        for (int j = 0; j < 8; ++j) {
+            const float v = colok ? sWf[cb * 320 + cs * 64 + g * 16 + kh * 8 + j] : 0.f;
+            wb[g][j] = (__bf16)v;
+            wl[g][j] = (__bf16)(v - (float)wb[g][j]);
+        }
+    const bool split = a.wsplit != 0;
     const float bias = colok ? sBf[cb * 8 + cs] : 0.f;
     const float* posx = a.pos_x[cb];
     const float* posy = a.pos_y[cb];
@@ -188,6 +202,10 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(HeadArgs a)
         for (int g = 0; g < 4; ++g) af[g] = *reinterpret_cast<const bf16x8*>(h + (size_t)pl * 64 + (size_t)(g * 16 + kh * 8));
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], wb[g], acc, 0, 0, 0);
+        if (split) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], wl[g], acc, 0, 0, 0);
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * kh;
@@ -522,11 +540,16 @@ __global__ __launch_bounds__(256, 2) void head_bwd_reduce_mfma_k(HeadBwdArgs a, 
     __syncthreads();
     const bool colok = l31 < 20;
     const int cb = colok ? l31 / 5 : 0, cs = colok ? l31 - 5 * cb : 0;
-    bf16x8 wb[4];
+    bf16x8 wb[4], wl[4];
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wb[g][j] = (__bf16)(colok ? sWf[cb * 320 + cs * 64 + g * 16 + kh * 8 + j] : 0.f);
+        for (int j = 0; j < 8; ++j) {
+            const float v = colok ? sWf[cb * 320 + cs * 64 + g * 16 + kh * 8 + j] : 0.f;
+            wb[g][j] = (__bf16)v;
+            wl[g][j] = (__bf16)(v - (float)wb[g][j]);
+        }
+    const bool split = a.f.wsplit != 0;
     const float k0 = colok ? sRow[l31 * 4 + 0] : 0.f, gx = colok ? sRow[l31 * 4 + 1] : 0.f;
     const float gy = colok ? sRow[l31 * 4 + 2] : 0.f, cst = colok ? sRow[l31 * 4 + 3] : 0.f;
     const float* posx = a.f.pos_x[cb];
@@ -554,6 +577,10 @@ __global__ __launch_bounds__(256, 2) void head_bwd_reduce_mfma_k(HeadBwdArgs a, 
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], wb[g], acc, 0, 0, 0);
+        if (split) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], wl[g], acc, 0, 0, 0);
+        }
         bf16x8 db[2];
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
@@ -616,11 +643,16 @@ __global__ __launch_bounds__(256, 2) void head_bwd_apply_mfma_k(HeadBwdArgs a, i
     // A operand of logits^T: row bs = l31, 8 consecutive channels
     const bool rowok = l31 < 20;
     const int rb = rowok ? l31 / 5 : 0, rs = rowok ? l31 - 5 * rb : 0;
-    bf16x8 wa[4];
+    bf16x8 wa[4], wal[4];           // high / low parts: the recomputed logits must be the forward's (the saved soft-max statistics)
 #pragma unroll
     for (int g = 0; g < 4; ++g)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) wa[g][j] = (__bf16)(rowok ? sWf[rb * 320 + rs * 64 + g * 16 + kh * 8 + j] : 0.f);
+        for (int j = 0; j < 8; ++j) {
+            const float v = rowok ? sWf[rb * 320 + rs * 64 + g * 16 + kh * 8 + j] : 0.f;
+            wa[g][j] = (__bf16)v;
+            wal[g][j] = (__bf16)(v - (float)wa[g][j]);
+        }
+    const bool split = a.f.wsplit != 0;
     // per accumulator row e of logits^T (bs = (e & 3) + 8 (e >> 2) + 4 kh; e < 12 covers every bs < 20): row constants
     float ck0[12], cgx[12], cgy[12], ccst[12];
     int ebr[12];
@@ -684,6 +716,10 @@ __global__ __launch_bounds__(256, 2) void head_bwd_apply_mfma_k(HeadBwdArgs a, i
         for (int e = 0; e < 16; ++e) acc[e] = 0.f;
 #pragma unroll
         for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[g], hb[g], acc, 0, 0, 0);
+        if (split) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wal[g], hb[g], acc, 0, 0, 0);
+        }
         bf16x8 db[2];
 #pragma unroll
         for (int e = 0; e < 12; ++e) {
@@ -734,9 +770,10 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
     LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
     LbcProfScope prof("head_fwd", 2.0 * a.N * a.OH * a.OW * 64.0 * 20, 4.0 * a.N * (double)a.OH * a.OW * 64, s);
     const bool no_mfma = lbc_opt_on(kOptHeadNoMfma);   // A/B switch
+    const int wsplit = (a.act_bf16 && !lbc_opt_on(kOptHeadNoSplit)) ? 1 : 0;
     if (a.act_bf16 && !no_mfma) {
         HeadArgs b = a;
-        b.nslice = 1;
+        b.nslice = 1; b.wsplit = wsplit;
         if (a.scratch && a.N < 128) {                    // fill the chip at small batch: 2..16 slices per image
             b.nslice = (256 + a.N - 1) / a.N;
             if (b.nslice > 16) b.nslice = 16;
@@ -744,7 +781,7 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
         hipLaunchKernelGGL(head_fwd_mfma_k, dim3((unsigned)a.N, (unsigned)b.nslice), dim3(256), 0, s, b);
         if (b.nslice > 1) hipLaunchKernelGGL(head_merge_k, dim3((unsigned)lbc_cdiv(a.N * 20, 256)), dim3(256), 0, s, b);
     }
-    else if (a.act_bf16) hipLaunchKernelGGL((head_fwd_k<__bf16>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
+    else if (a.act_bf16) { HeadArgs b = a; b.wsplit = wsplit; hipLaunchKernelGGL((head_fwd_k<__bf16>), dim3((unsigned)a.N, 4), dim3(256), 0, s, b); }
     else hipLaunchKernelGGL((head_fwd_k<float>), dim3((unsigned)a.N, 4), dim3(256), 0, s, a);
     int rc = lbc_check_launch("head_fwd");
     if (rc) return rc;
@@ -759,8 +796,10 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
 int lbc_head_bwd_rows(const HeadArgs& f) { return head_bwd_mfma(f) ? f.N * head_bwd_slices(f.N, f.OH * f.OW) : f.N; }
 int lbc_head_bwd_max_rows(int max_batch) { return max_batch + 1024; }
 
-int lbc_head_bwd_reduce(const HeadBwdArgs& a, hipStream_t s)
+int lbc_head_bwd_reduce(const HeadBwdArgs& a0, hipStream_t s)
 {
+    HeadBwdArgs a = a0;
+    a.f.wsplit = (a.f.act_bf16 && !lbc_opt_on(kOptHeadNoSplit)) ? 1 : 0;
     LBC_REQUIRE(a.f.mean[0] == a.f.mean[1] && a.f.mean[0] == a.f.mean[2] && a.f.mean[0] == a.f.mean[3],
                 "head backward requires training-mode (shared batch) statistics");
     LbcProfScope prof("head_bwd_reduce", 4.0 * a.f.N * a.f.OH * a.f.OW * 64.0 * 20, 4.0 * a.f.N * (double)a.f.OH * a.f.OW * 64, s);
@@ -782,8 +821,10 @@ int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s)
     return lbc_check_launch("head_bwd_finalize");
 }
 
-int lbc_head_bwd_apply(const HeadBwdArgs& a, hipStream_t s)
+int lbc_head_bwd_apply(const HeadBwdArgs& a0, hipStream_t s)
 {
+    HeadBwdArgs a = a0;
+    a.f.wsplit = (a.f.act_bf16 && !lbc_opt_on(kOptHeadNoSplit)) ? 1 : 0;
     const int HW = a.f.OH * a.f.OW;
     LbcProfScope prof("head_bwd_apply", 4.0 * a.f.N * (double)HW * 64.0 * 20, 8.0 * a.f.N * (double)HW * 64, s);
     if (head_bwd_mfma(a.f)) {

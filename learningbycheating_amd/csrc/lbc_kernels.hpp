@@ -173,6 +173,7 @@ struct HeadArgs {
     int N, OH, OW;               // softmax map is OH x OW (pos_x over OW, pos_y over OH)
     float* scratch;              // >= N * 16 * 20 * 4 floats: per-slice soft-argmax partials of small-batch launches (nullable)
     int nslice;                  // set by lbc_head_fwd
+    int wsplit;                  // set by the launchers (bf16 activations): folded weights as a bf16 high + low pair (see fold_branch)
 };
 int lbc_head_fwd(const HeadArgs& a, hipStream_t s);
 struct HeadBwdArgs {

@@ -167,16 +167,17 @@ def frozen_decisions(eng):
     return fz
 
 
-def _frozen_gradient_check(dev, kind, backbone, h, w, n, precision, tol, head_tol=None, seed=3):
+def _frozen_gradient_check(dev, kind, backbone, h, w, n, precision, tol, head_tol=None, seed=3, sd=None):
     """Gradient parity with the branch decisions frozen.  The float64 oracle is run with the ReLU masks and max-pool choices
     the executor's own forward took (frozen_decisions), so both sides differentiate the SAME piecewise-linear function and the
     comparison is not blurred by kink flips (two float32 evaluations of a 34-layer ReLU network take different branches for a
     few of ~1e8 elements; each flip moves rel-to-max gradient entries by 1e-3..1e-2).  A mis-scaled term in any of the
     BatchNorm / convolution / pooling backward kernels shows up as an O(1e-2..1) error in the tensors upstream of it.
     Returns the sorted per-tensor errors (max |g - g64| / max |g64|)."""
-    sd = O.make_state_dict(kind, backbone, seed, h, w)
     x, speed, cmd = _inputs(kind, n, h, w, seed + 1)
-    O.calibrate_running_stats(sd, kind, backbone, x, speed, cmd)
+    if sd is None:                       # (sd given: a trained-like checkpoint the caller prepared)
+        sd = O.make_state_dict(kind, backbone, seed, h, w)
+        O.calibrate_running_stats(sd, kind, backbone, x, speed, cmd)
     eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
     ps, pa = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
     fz = frozen_decisions(eng)           # (before the backward pass reuses any buffer)
@@ -234,6 +235,41 @@ def test_gradients_with_frozen_decisions_full_size(env, kind, backbone, h, w, n)
     dev, _ = env
     es = _frozen_gradient_check(dev, kind, backbone, h, w, n, 0, 3e-4)
     assert es[len(es) // 2] < 1e-4, es[len(es) // 2]
+
+
+@gpu
+def test_bf16_gradients_with_frozen_decisions_full_size(env):
+    """The shipped bf16 mode (BASELINE.json config 3) at the reference's size, N = 32 = the per-GPU batch of the 8-GPU run, on a
+    trained-like (warm-started) ResNet-34: every parameter gradient against the float64 oracle that takes the executor's own
+    ReLU / max-pool decisions AND rounds where the executor rounds (MFMA operands, stored activations and activation gradients to
+    bf16: oracle flags MFMA_BF16 / ACT_BF16) -- an ABSOLUTE statement about the mode, next to the autocast-relative one below.
+    Bound: every tensor within BF16_FROZEN_MAX of its largest entry, the median tensor within BF16_FROZEN_MEDIAN (each stored tensor
+    carries 2^-9 relative rounding noise and ~1e6 such terms meet in one weight-gradient entry; the two evaluations round the same
+    quantities but not bit-identical ones, so the noise does not cancel).  Measured values: the frozen-decision line in profiles/."""
+    from learningbycheating_amd.bird_view.models import ImagePolicyModelSS
+    from learningbycheating_amd.training.native import NativeTrainer
+    dev, _ = env
+    n = 32
+    rgb, speed, cmd = seeded_inputs("image", n, 71)
+    onehot = O.one_hot(cmd)
+    g = torch.Generator().manual_seed(73)
+    tgt = torch.rand((n, 4, 5, 2), generator=g)
+    tgt[..., 0] = tgt[..., 0] * 1.2 - 0.6
+    tgt[..., 1] = tgt[..., 1] * 0.5 + 0.3
+    torch.manual_seed(74)
+    student = ImagePolicyModelSS("resnet34", all_branch=True).to(dev)
+    warm = NativeTrainer(student, None, n, (3, 160, 384), dev, phase="l1_all", lr=1e-3)
+    for _ in range(40):
+        warm.step(rgb.to(dev), speed.to(dev), onehot.to(dev), target=tgt.to(dev))
+    torch.cuda.synchronize()
+    del warm
+    sd = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+    es = _frozen_gradient_check(dev, "image", "resnet34", 160, 384, n, 2, BF16_FROZEN_MAX, sd=sd, seed=75)
+    assert es[len(es) // 2] < BF16_FROZEN_MEDIAN, es[len(es) // 2]
+
+
+#: bounds of test_bf16_gradients_with_frozen_decisions_full_size (rel-to-max per tensor; set from the measured values with ~2x margin)
+BF16_FROZEN_MAX, BF16_FROZEN_MEDIAN = 0.25, 6e-2
 
 
 @gpu
