@@ -136,7 +136,17 @@ def build_models(device, kind, seed=0):
     return student, teacher
 
 
-def cpu_baseline(kind, seconds_budget=25.0, batch=8):
+def cpu_baseline(kind):
+    """the oracle's step on the host cores at batch 8 (BASELINE config 1's batch: `value`) and at batch 64 (BASELINE.md section 3 asks
+    for both), each a bounded sample; `cores` = the intra-op threads used, `host_cores` = what the box has"""
+    small = cpu_baseline_at(kind, 8, 14.0, 40)
+    large = cpu_baseline_at(kind, 64, 16.0, 5)
+    small["host_cores"] = os.cpu_count()
+    small["batch64"] = {k: large[k] for k in ("value", "unit", "sample")}
+    return small
+
+
+def cpu_baseline_at(kind, batch, seconds_budget, max_steps):
     """oracle (port of the reference step onto torch-CPU functional ops) timed on the host cores"""
     from oracle import lbc_oracle as O
     # intra-op threads: all cores up to 64 (a 23 M-parameter CNN at batch 8 stops scaling, and slows down, far below
@@ -174,7 +184,7 @@ def cpu_baseline(kind, seconds_budget=25.0, batch=8):
     step()
     t0 = time.time()
     n = 0
-    while n < 2 or (time.time() - t0 < seconds_budget and n < 40):
+    while n < 2 or (time.time() - t0 < seconds_budget and n < max_steps):
         step()
         n += 1
     dt = time.time() - t0
@@ -198,10 +208,10 @@ def self_spawn(args):
 
 
 def read_traffic():
-    """HBM bytes per launch of the convolution family from the committed PMC passes of THIS round's code: profiles/r03_pmc_traffic.json,
-    written by scripts/pmc_traffic.py from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_r03_evidence.sh (counters need
-    their own runs: they cannot be collected inside this process)"""
-    for name in ("r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    """HBM bytes per launch of the convolution family from the committed PMC passes of THIS round's code: profiles/r04_pmc_traffic.json,
+    written by scripts/pmc_traffic.py from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_evidence.sh (counters need
+    their own runs: they cannot be collected inside this process); an older round's file is a fallback and says so in its `source`"""
+    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -214,8 +224,8 @@ def read_traffic():
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=50)       # >= 50 timed steps after >= 10 warm-up steps
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--workload", choices=sorted(WORKLOADS), default="phase1_bs256_bf16")
     ap.add_argument("--global-batch", type=int, default=None, help="default: the workload's batch")
     ap.add_argument("--dtype", choices=["f32", "bf16_mfma", "bf16"], default=None,
@@ -406,7 +416,10 @@ def main():
         feed = ("ONE device-resident batch re-fed every step" if args.resident else
                 "%d-frame pinned host dataset per rank, uint8 H2D of every batch (%.1f MB) double-buffered inside the timed region" % (pool.n, pool.bytes_per_step / 1e6))
         out = {"metric": wl["metric"], "value": round(value, 2), "unit": "images/sec",
-               "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1, "steps": args.steps, "warmup": args.warmup,
+               "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
+               # ranks of the communicator the gradient buckets actually travelled on (None: one process, nothing travels)
+               "rccl_ranks": (dist.get_world_size() if (world > 1 and args.dist_backend == "nccl") else None),
+               "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
                "config": {"workload": "%s [%s], 160x384 RGB + 7x192x192 bird-view uint8 NHWC frames as the dataset stores them (%s), global batch %d "
@@ -423,7 +436,7 @@ def main():
         # the exact-f32 parity path on the same workload, a short run reported next to the headline number
         del tr
         torch.cuda.empty_cache()
-        asteps = max(3, args.steps // 2)
+        asteps = max(3, min(20, args.steps // 2))
         atr, adt, aloss = timed_run("f32", asteps, 2)
         aroof, ahbm, _ = instrumented_step(atr, "f32")
         also = {"dtype": "f32", "value": round(global_batch * asteps / adt, 2), "ms_per_step": round(1e3 * adt / asteps, 3),

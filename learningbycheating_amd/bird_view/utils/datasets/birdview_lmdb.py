@@ -15,6 +15,7 @@ from .lmdb_format import LmdbReader
 
 class BirdViewDataset(ImageDataset):
     """reference birdview_lmdb.py:33-166 (same constructor arguments; episodes in reverse-sorted order, frame cap as there)"""
+    needs_rgb = False        # reference birdview_lmdb.py:107: rgb_image = None -- raw() does not read it, DeviceLoader does not upload it
 
     def __init__(self, dataset_path, img_size=320, crop_size=192, gap=5, n_step=5, crop_x_jitter=5, crop_y_jitter=5, angle_jitter=5,
                  down_ratio=4, gaussian_radius=1.0, max_frames=None):
@@ -42,6 +43,12 @@ class BirdViewDataset(ImageDataset):
         if not self.envs:
             raise RuntimeError("no LMDB episodes under %s" % dataset_path)
         print("%s: %d frames, %d episodes." % (dataset_path, len(self), n_episodes))
+
+    def __getitem__(self, idx):
+        # the reference's per-sample path (birdview_lmdb.py:95-151) rotates and crops the map with cv2 on a CPU worker; here that is
+        # one GPU kernel over the batch (lbc_birdview_warp_crop_u8), so a single CPU sample is not what this class hands out
+        raise NotImplementedError("BirdViewDataset yields batches through DeviceLoader (get_birdview_device): the rotation + crop of the "
+                                  "map runs on the GPU; use raw(idx, delta_angle, dx, dy) for the stored bytes and the jittered waypoints")
 
     def draw_jitter(self, rng):
         """(delta_angle, dx, dy) as birdview_lmdb.py:103-105 draws them (integers; dy carries the fixed -PIXEL_OFFSET)"""

@@ -97,7 +97,8 @@ class ImageDataset(torch.utils.data.Dataset):
         index = self.idx_map[idx]
         bird_view = np.frombuffer(env.get("birdview_%04d" % index), np.uint8).reshape(320, 320, 7)
         measurement = np.frombuffer(env.get("measurements_%04d" % index), np.float32)
-        rgb_image = np.frombuffer(env.get("rgb_%04d" % index), np.uint8).reshape(160, 384, 3)
+        # (the privileged agent never looks at the camera frame: reference birdview_lmdb.py:107 sets rgb_image = None)
+        rgb_image = np.frombuffer(env.get("rgb_%04d" % index), np.uint8).reshape(160, 384, 3) if getattr(self, "needs_rgb", True) else None
         ox, oy, oz, ori_ox, ori_oy, vx, vy, vz, ax, ay, az, cmd, steer, throttle, brake, manual, gear = measurement
         speed = np.linalg.norm([vx, vy, vz])
         angle = np.arctan2(ori_oy, ori_ox) + np.deg2rad(delta_angle)      # (image_lmdb.py:146,165-166 with delta_angle = 0)
@@ -168,10 +169,12 @@ class DeviceLoader:
         B = batch_size
         # per-sample rotation / window jitter (BirdViewDataset): parameters of lbc_birdview_warp_crop_u8, 56 bytes per image
         self.jitter = bool(getattr(dataset, "angle_jitter", 0) or getattr(dataset, "crop_x_jitter", 0) or getattr(dataset, "crop_y_jitter", 0))
-        self.stage = [{"rgb": pin(torch.empty((B, 160, 384, 3), dtype=torch.uint8)), "bv": pin(torch.empty((B, 320, 320, 7), dtype=torch.uint8)),
+        self.with_rgb = bool(getattr(dataset, "needs_rgb", True))     # bird-view datasets: no camera frame is read, staged or uploaded
+        rgb_b = B if self.with_rgb else 0
+        self.stage = [{"rgb": pin(torch.empty((rgb_b, 160, 384, 3), dtype=torch.uint8)), "bv": pin(torch.empty((B, 320, 320, 7), dtype=torch.uint8)),
                        "loc": pin(torch.empty((B, dataset.n_step, 2))), "speed": pin(torch.empty(B)), "cmd": torch.empty(B),
                        "warp": pin(torch.zeros((B, 7), dtype=torch.float64))} for _ in range(2)]
-        self.dev = [{"rgb": torch.empty((B, 160, 384, 3), dtype=torch.uint8, device=self.device),
+        self.dev = [{"rgb": torch.empty((rgb_b, 160, 384, 3), dtype=torch.uint8, device=self.device),
                      "bv": torch.empty((B, 320, 320, 7), dtype=torch.uint8, device=self.device),
                      "loc": torch.empty((B, dataset.n_step, 2), device=self.device), "speed": torch.empty(B, device=self.device),
                      "warp": torch.zeros((B, 7), dtype=torch.float64, device=self.device)} for _ in range(2)]
@@ -196,13 +199,14 @@ class DeviceLoader:
                 st["warp"][i] = torch.from_numpy(warp_params(delta_angle, dx, dy, self.data.crop_size))
             else:
                 rgb, bv, loc, cmd, speed = self.data.raw(int(idx))
-            np.copyto(rgb_np[i], rgb)
+            if self.with_rgb:
+                np.copyto(rgb_np[i], rgb)
             np.copyto(bv_np[i], bv)
             st["loc"][i] = torch.from_numpy(loc.astype(np.float32))
             st["cmd"][i] = float(cmd)
             st["speed"][i] = float(speed)
         d = self.dev[k]
-        keys = ("rgb", "bv", "loc", "speed", "warp") if self.jitter else ("rgb", "bv", "loc", "speed")
+        keys = (("rgb",) if self.with_rgb else ()) + (("bv", "loc", "speed", "warp") if self.jitter else ("bv", "loc", "speed"))
         if self.copy is None:
             for key in keys:
                 d[key].copy_(st[key])
@@ -233,14 +237,15 @@ class DeviceLoader:
             else:
                 _lib.check(_lib.get().lbc_birdview_crop_u8(_lib.ptr(d["bv"]), _lib.ptr(bv), n, 320, 320, 7, CROP_Y0, CROP_X0, self.data.crop_size,
                                                            self.data.crop_size, _lib.stream_for(bv)), "birdview_crop_u8")
-            rgb, loc, speed, cmd = d["rgb"], d["loc"], d["speed"], st["cmd"].clone()
+            rgb, loc, speed, cmd = (d["rgb"] if self.with_rgb else None), d["loc"], d["speed"], st["cmd"].clone()
             if self.batch_aug > 1:               # reference train_image_phase1.py:131-154,183-189: every frame batch_aug times, back to back
                 r = self.batch_aug
-                rgb, bv, loc, speed, cmd = (t.repeat_interleave(r, dim=0) for t in (rgb, bv, loc, speed, cmd))
+                bv, loc, speed, cmd = (t.repeat_interleave(r, dim=0) for t in (bv, loc, speed, cmd))
+                rgb = rgb.repeat_interleave(r, dim=0) if rgb is not None else None
             else:
-                rgb = rgb.clone()                # the augmentation works in place; the slot is refilled by the copy stream
+                rgb = rgb.clone() if rgb is not None else None     # the augmentation works in place; the slot is refilled by the copy stream
                 loc, speed = loc.clone(), speed.clone()
-            if self.strategy is not None:
+            if self.strategy is not None and rgb is not None:
                 self.aug.recipe = self.strategy(self.images_seen)       # strength schedule by images read (image_lmdb.py:138,220)
                 self.aug.augment_batch(rgb)
             self.images_seen += n * self.batch_aug

@@ -414,7 +414,9 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     // two workgroups per CU (conv_hdmap.hpp) instead of the 64 x 64 register-staged tiles of conv_igemm.hip (31 us per 9-GFLOP launch)
     if ((forced < 0 || forced == 4) && !a.pre_scale && a.K % 64 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4)) {
         const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64);
-        const long long small_fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 48;
+        // (its own knob; LBC_GEMM256_MIN_TILES -- the per-tap kernel's threshold, which tests set to 1 -- still applies when this one is unset)
+        const long long small_fill = lbc_opt(kOptHdmaSmallMinTiles) > 0 ? lbc_opt(kOptHdmaSmallMinTiles)
+                                     : (lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : 48);
         if (tiles >= small_fill) return kLbcCfgHdma + 4;
     }
     return -1;

@@ -330,6 +330,8 @@ int lbc_wgrad_tr_group_launch(const WgradArgs& a0, const WgradGroup& g_in, hipSt
         LBC_REQUIRE(g.p[i] && g.q[i] && g.out[i] && (g.q_scale[i] != nullptr) == (a.q_scale != nullptr) && (g.q_shift[i] != nullptr) == (a.q_scale != nullptr),
                     "wgrad_tr: group member %d incomplete", i);
     const long long M = (long long)a.N * a.H * a.W;
+    // (32-bit element offsets in the kernel: the executor's deferred launches come here directly, not through lbc_wgrad_launch)
+    LBC_REQUIRE(M * a.CP < (1ll << 31) && M * a.CQ < (1ll << 31) && a.nsplit >= 1, "wgrad_tr: tensors too large for 32-bit indexing");
     const long long chunks = (M + 63) / 64;
     const int rows_per_split = (int)((chunks + a.nsplit - 1) / a.nsplit) * 64;
     const unsigned blocks = (unsigned)((a.CP / 64) * (a.CQ / 64) * a.nsplit * g.n);

@@ -44,8 +44,8 @@ __global__ __launch_bounds__(256) void crop_u8_k(const unsigned char* __restrict
 // on the CPU (bird_view/utils/datasets/birdview_lmdb.py:103-125: cv2.warpAffine(bird_view, cv2.getRotationMatrix2D((160, 260), delta_angle,
 // 1.0), (320, 320), flags=cv2.INTER_LINEAR), then the jittered 192 x 192 window).  The arithmetic restates OpenCV's 8-bit bilinear
 // warpAffine (imgwarp.cpp, remap with INTER_BITS = 5): source coordinates in 1/1024 fixed point from the INVERTED matrix (rounded half to
-// even like cvRound, + 16, >> 5 -> 1/32 pixel), a 32 x 32 table of 15-bit weights whose four entries are forced to sum to 32768 (the
-// deficit goes to the largest, an excess comes off the smallest), (sum + 16384) >> 15, zero outside the image (BORDER_CONSTANT).
+// even like cvRound, + 16, >> 5 -> 1/32 pixel), a 32 x 32 table of 15-bit weights whose four entries sum to 32768,
+// (sum + 16384) >> 15, zero outside the image (BORDER_CONSTANT).
 // p.im = the inverted matrix (iM0, iM1, b1, iM3, iM4, b2) in double, p.y0 / p.x0 the window origin in the warped image.
 __global__ __launch_bounds__(256) void warp_crop_u8_k(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, const WarpParams* __restrict__ params,
                                                       int N, int SH, int SW, int C, int H, int W)
@@ -64,17 +64,11 @@ __global__ __launch_bounds__(256) void warp_crop_u8_k(const unsigned char* __res
         // the weights of table entry (fy, fx)
         const float ax = (float)fx * (1.f / 32.f), ay = (float)fy * (1.f / 32.f);
         const float wf[4] = {(1.f - ay) * (1.f - ax), (1.f - ay) * ax, ay * (1.f - ax), ay * ax};
-        int w[4], isum = 0;
+        // (bilinear weights are products of two multiples of 1/32: every w[k] is an exact multiple of 32 and the four sum to 32768
+        //  exactly -- OpenCV's fix-up of the table sum can never fire for INTER_LINEAR, it is not restated)
+        int w[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) { w[k] = (int)rintf(wf[k] * 32768.f); isum += w[k]; }
-        if (isum != 32768) {
-            int mn = 0, mx = 0;
-#pragma unroll
-            for (int k = 1; k < 4; ++k) { if (w[k] < w[mn]) mn = k; if (w[k] > w[mx]) mx = k; }
-            const int diff = isum - 32768;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) if (k == (diff < 0 ? mx : mn)) w[k] -= diff;
-        }
+        for (int k = 0; k < 4; ++k) w[k] = (int)rintf(wf[k] * 32768.f);
         const bool in00 = (unsigned)sy < (unsigned)SH && (unsigned)sx < (unsigned)SW, in01 = (unsigned)sy < (unsigned)SH && (unsigned)(sx + 1) < (unsigned)SW;
         const bool in10 = (unsigned)(sy + 1) < (unsigned)SH && (unsigned)sx < (unsigned)SW, in11 = (unsigned)(sy + 1) < (unsigned)SH && (unsigned)(sx + 1) < (unsigned)SW;
         const unsigned char* s0 = src + (((long long)n * SH + sy) * SW + sx) * C;

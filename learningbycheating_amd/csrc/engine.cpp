@@ -430,6 +430,9 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
 {
     LBC_REQUIRE(N >= 1 && N <= d_.max_batch, "net.forward: batch %d outside [1,%d]", N, d_.max_batch);
     LBC_REQUIRE(image && velocity && command && pred_all, "net.forward: null argument");
+    // the timing-experiment switches select kernels with parts left out: a network must never run on them
+    LBC_REQUIRE(lbc_opt(kOptHdmaDiag) <= 0 && lbc_opt(kOptGldsDiag) <= 0,
+                "net.forward: LBC_HDMA_DIAG / LBC_GLDS_DIAG are set -- diagnostic kernels compute wrong results (per-kernel timing scripts only)");
     LBC_TRY(check_bound(false));
     lastN_ = N; last_train_ = train; ++generation_;
     const int H0 = d_.H, W0 = d_.W, Cin = d_.in_channels;
