@@ -115,6 +115,106 @@ __global__ __launch_bounds__(1024) void bn_finalize_k(BnFinalizeArgs a)
     a.shift[c] = b - mean * sc;
 }
 
+// ---- folded finalize: the consumer's workgroup derives the coefficients itself -------------------------------------------------
+// sums the `rows` partial rows of column pair (c, C + c) for every channel: 256 threads = (256 / Cp) row-lanes x Cp channels per
+// pass (Cp = min(C, 256)), eight rows in flight per lane, lanes combined through LDS in a fixed order.  o1 / o2 valid where
+// lane == 0.  Every workgroup of a launch runs the same code on the same rows: all of them get the same bits.
+constexpr int kFoldMaxC = 640;
+__device__ __forceinline__ void fold_sum_rows(const float* __restrict__ partial, int rows, int C, int c, int lane, int nlanes, double* red,
+                                              double& o1, double& o2)
+{
+    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
+    const size_t rs = (size_t)2 * C;
+    int r = lane;
+    for (; r + 3 * nlanes < rows; r += 4 * nlanes) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            a[u] += (double)partial[(size_t)(r + u * nlanes) * rs + c];
+            b[u] += (double)partial[(size_t)(r + u * nlanes) * rs + C + c];
+        }
+    }
+    for (; r < rows; r += nlanes) { a[0] += (double)partial[(size_t)r * rs + c]; b[0] += (double)partial[(size_t)r * rs + C + c]; }
+    double v1 = (a[0] + a[1]) + (a[2] + a[3]), v2 = (b[0] + b[1]) + (b[2] + b[3]);
+    if (nlanes > 1) {
+        red[threadIdx.x] = v1; red[256 + threadIdx.x] = v2;
+        __syncthreads();
+        if (lane == 0) {
+            const int cp = 256 / nlanes;
+            for (int k = 1; k < nlanes; ++k) { v1 += red[k * cp + threadIdx.x]; v2 += red[256 + k * cp + threadIdx.x]; }
+        }
+        __syncthreads();
+    }
+    o1 = v1; o2 = v2;
+}
+
+// the forward finalize of one BatchNorm inside a consumer: scale / shift of all C channels -> sc[], sh[] (LDS); `writer` (workgroup 0)
+// also does bn_finalize_k's global writes.  Ends with a barrier.
+__device__ __forceinline__ void fold_finalize(const BnFinalizeArgs& f, float* sc, float* sh, double* red, bool writer)
+{
+    const int C = f.C;
+    const int cp = C < 256 ? C : 256, nlanes = 256 / cp;
+    if (writer && threadIdx.x == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
+    for (int c0 = 0; c0 < C; c0 += cp) {
+        const int cl = threadIdx.x % cp, lane = threadIdx.x / cp;
+        const int c = c0 + cl;
+        double s1 = 0.0, s2 = 0.0;
+        const bool ok = c < C && lane < nlanes;
+        fold_sum_rows(f.partial, ok ? f.rows : 0, C, ok ? c : 0, ok ? lane : 1, nlanes, red, s1, s2);
+        if (ok && lane == 0) {
+            const double n = (double)f.count;
+            const double m = s1 / n;
+            double var = s2 / n - m * m;
+            if (var < 0.0) var = 0.0;
+            const float mean = (float)m;
+            const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+            const float g = f.gamma ? f.gamma[c] : 1.f;
+            const float b = f.beta ? f.beta[c] : 0.f;
+            const float scv = g * invstd;
+            sc[c] = scv;
+            sh[c] = b - mean * scv;
+            if (writer) {
+                if (f.running_mean) {
+                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                    f.running_mean[c] = (float)((1.0 - f.momentum) * (double)f.running_mean[c] + f.momentum * m);
+                    f.running_var[c] = (float)((1.0 - f.momentum) * (double)f.running_var[c] + f.momentum * unb);
+                }
+                if (f.save_mean) { f.save_mean[c] = mean; f.save_invstd[c] = invstd; }
+                f.scale[c] = scv;
+                f.shift[c] = b - mean * scv;
+            }
+        }
+    }
+    __syncthreads();
+}
+
+// the backward finalize inside bn_bwd_apply: A, k1, k2 of all C channels -> LDS; workgroup 0 writes dgamma / dbeta (and the
+// coefficient vectors, which nothing else reads in this form but the introspection / tests may)
+__device__ __forceinline__ void fold_bwd_finalize(const BnBwdFinalizeArgs& f, float* sA, float* sK1, float* sK2, double* red, bool writer)
+{
+    const int C = f.C;
+    const int cp = C < 256 ? C : 256, nlanes = 256 / cp;
+    for (int c0 = 0; c0 < C; c0 += cp) {
+        const int cl = threadIdx.x % cp, lane = threadIdx.x / cp;
+        const int c = c0 + cl;
+        double s1 = 0.0, s2 = 0.0;
+        const bool ok = c < C && lane < nlanes;
+        fold_sum_rows(f.partial, ok ? f.rows : 0, C, ok ? c : 0, ok ? lane : 1, nlanes, red, s1, s2);
+        if (ok && lane == 0) {
+            const double n = (double)f.count;
+            const double g = f.gamma ? (double)f.gamma[c] : 1.0;
+            const float A = (float)(g * (double)f.invstd[c]);
+            const float k1 = f.train ? (float)(s1 / n) : 0.f, k2 = f.train ? (float)(s2 / n) : 0.f;
+            sA[c] = A; sK1[c] = k1; sK2[c] = k2;
+            if (writer) {
+                if (f.dbeta) f.dbeta[c] = (float)s1;
+                if (f.dgamma) f.dgamma[c] = (float)s2;
+                if (f.coefA) { f.coefA[c] = A; f.coefB[c] = k1; f.coefD[c] = k2; }
+            }
+        }
+    }
+    __syncthreads();
+}
+
 // ---- eval mode: every BatchNorm of the network in one launch (blockIdx.x = BatchNorm, threads stride channels) ----------
 __global__ __launch_bounds__(256) void bn_eval_prep_k(BnEvalArgs a)
 {
@@ -137,7 +237,7 @@ __global__ __launch_bounds__(256) void bn_eval_prep_k(BnEvalArgs a)
 // loaded once (per iteration they were 4 + 4 more 16-byte loads next to the 1 + 1 that carry data), and both data loads of an
 // iteration are issued before either is used (RES is a template flag: a runtime `if (resid)` between them split the loop body and
 // put an `s_waitcnt vmcnt(0)` behind each load -- one memory latency per 16 bytes and wave, ~4.5 TB/s with every wave slot taken).
-template <typename T, bool RES>
+template <typename T, bool RES, bool FOLD = false>
 __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
 {
     constexpr int V = Act<T>::kVec;          // 16-byte accesses: 4 f32 or 8 bf16 channels per thread
@@ -151,9 +251,17 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
     const long long stride = (long long)gridDim.x * blockDim.x;      // a multiple of cvn (lbc_bn_apply)
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int c = (int)(i0 % cvn) * V;
-    const vec sc = PV::ld(a.scale + c), sh = PV::ld(a.shift + c);
+    const float* scp = a.scale; const float* shp = a.shift; const float* rscp = a.rscale; const float* rshp = a.rshift;
+    if constexpr (FOLD) {
+        // this launch is also the finalize of its BatchNorm(s): coefficients from the partial rows, per workgroup (lbc_kernels.hpp)
+        __shared__ __attribute__((aligned(16))) float fsc[2][kFoldMaxC], fsh[2][kFoldMaxC];
+        __shared__ double fred[512];
+        if (a.fold) { fold_finalize(a.fin, fsc[0], fsh[0], fred, blockIdx.x == 0); scp = fsc[0]; shp = fsh[0]; }
+        if (RES && a.rfold) { fold_finalize(a.rfin, fsc[1], fsh[1], fred, blockIdx.x == 0); rscp = fsc[1]; rshp = fsh[1]; }
+    }
+    const vec sc = PV::ld(scp + c), sh = PV::ld(shp + c);
     vec rsc = PV::splat(1.f), rsh = PV::splat(0.f);
-    if (RES && a.rscale) { rsc = PV::ld(a.rscale + c); rsh = PV::ld(a.rshift + c); }
+    if (RES && rscp) { rsc = PV::ld(rscp + c); rsh = PV::ld(rshp + c); }
     const bool relu = a.relu != 0;
     for (long long i = i0; i < total; i += stride) {
         vec v = Act<T>::ldv(x + i * V);
@@ -286,8 +394,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize_k(BnBwdFinalizeArgs a)
 // Same structure as bn_apply_k: grid stride = whole pixels (of the Cout / V output groups), the five coefficient vectors loaded
 // once (they were 10 of the 12 loads of an iteration in the bf16 kernel), no 64-bit division per iteration, and every data load of
 // an iteration issued before the first use (MASK / ACCUM are template flags).
-template <typename T, bool MASK, bool ACCUM>
-__global__ __launch_bounds__(256, (MASK || ACCUM) ? 1 : 8) void bn_bwd_apply_k(BnBwdApplyArgs a)
+template <typename T, bool MASK, bool ACCUM, bool FOLD = false>
+__global__ __launch_bounds__(256, (MASK || ACCUM || FOLD) ? 1 : 8) void bn_bwd_apply_k(BnBwdApplyArgs a)
 // (8 waves per SIMD = at most 64 VGPRs for the plain variant: its bf16 form sits at 66 without the bound and fits without scratch with it;
 // the MASK / ACCUM forms would spill and keep 6-7 waves)
 {
@@ -304,7 +412,14 @@ __global__ __launch_bounds__(256, (MASK || ACCUM) ? 1 : 8) void bn_bwd_apply_k(B
     const long long stride = (long long)gridDim.x * blockDim.x;      // a multiple of ovn (lbc_bn_bwd_apply)
     const long long i0 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     const int cg = (int)(i0 % ovn), c = cg * V;
-    const vec cA = PV::ld(a.coefA + c), k1 = PV::ld(a.coefB + c), k2 = PV::ld(a.coefD + c);
+    const float* pA = a.coefA; const float* pK1 = a.coefB; const float* pK2 = a.coefD;
+    if constexpr (FOLD) {
+        __shared__ __attribute__((aligned(16))) float fA[kFoldMaxC], fK1[kFoldMaxC], fK2[kFoldMaxC];
+        __shared__ double fred[512];
+        fold_bwd_finalize(a.fin, fA, fK1, fK2, fred, blockIdx.x == 0);
+        pA = fA; pK1 = fK1; pK2 = fK2;
+    }
+    const vec cA = PV::ld(pA + c), k1 = PV::ld(pK1 + c), k2 = PV::ld(pK2 + c);
     const vec mean = PV::ld(a.mean + c), inv = PV::ld(a.invstd + c);
     long long j = ((i0 / ovn) * cvn + cg) * V;                       // element offset in the C-channel tensors
     const long long dj = (stride / ovn) * cvn * V;
@@ -408,23 +523,57 @@ int lbc_bn_eval_prep(const BnEvalArgs& a, hipStream_t s)
     return lbc_check_launch("bn_eval_prep");
 }
 
+// Folding a finalize into its consumer: every workgroup reads rows x 2C floats from L2 (64 B / clk / CU) -- worth it where that is
+// a microsecond and the consumer's grid is small, i.e. where launches are the cost
+constexpr long long kFoldBytes = 128 * 1024;
+constexpr int kFoldGrid = 512;           // workgroups of a folding consumer (two per CU)
+int lbc_bn_fold_max_rows(int C) { return (int)(kFoldBytes / (8ll * C)); }
+bool lbc_bn_fold_ok(int rows, int C)
+{
+    return !lbc_opt_on(kOptNoBnFold) && C <= kFoldMaxC && (C < 256 ? 256 % C == 0 : true) && rows >= 1 && rows <= lbc_bn_fold_max_rows(C);
+}
+
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 8 == 0 && a.pixels > 0, "bn_apply: bad shape");
+    const bool fold = a.fold || a.rfold;
+    LBC_REQUIRE(!fold || ((!a.fold || lbc_bn_fold_ok(a.fin.rows, a.C)) && (!a.rfold || (a.resid && lbc_bn_fold_ok(a.rfin.rows, a.C)))),
+                "bn_apply: folded finalize outside its limits");
+    LBC_REQUIRE(!fold || ((!a.fold || (a.fin.C == a.C && a.fin.train && !a.fin.nsum)) && (!a.rfold || (a.rfin.C == a.C && a.rfin.train && !a.rfin.nsum))),
+                "bn_apply: folded finalize needs a local training-mode BatchNorm of the same width");
     LbcProfScope prof("bn_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * a.C * (a.resid ? 3 : 2), s);
     const int groups = a.C / (a.act_bf16 ? 8 : 4);
-#define LBC_K(T, g)                                                                                              \
-    do {                                                                                                         \
-        if (a.resid) hipLaunchKernelGGL((bn_apply_k<T, true>), dim3((unsigned)(g)), dim3(256), 0, s, a);         \
-        else         hipLaunchKernelGGL((bn_apply_k<T, false>), dim3((unsigned)(g)), dim3(256), 0, s, a);        \
+    int grid = grid_for_groups(a.pixels * groups, groups);
+    if (fold && grid > kFoldGrid) {          // (a multiple of the channel-group unit below the cap)
+        int g = 256, r = groups;
+        while (r) { const int t = g % r; g = r; r = t; }
+        const int unit = groups / g;
+        grid = kFoldGrid / unit * unit;
+        if (grid < unit) grid = unit;
+    }
+#define LBC_K(T, g)                                                                                                          \
+    do {                                                                                                                     \
+        if (fold) {                                                                                                          \
+            if (a.resid) hipLaunchKernelGGL((bn_apply_k<T, true, true>), dim3((unsigned)(g)), dim3(256), 0, s, a);           \
+            else         hipLaunchKernelGGL((bn_apply_k<T, false, true>), dim3((unsigned)(g)), dim3(256), 0, s, a);          \
+        } else {                                                                                                             \
+            if (a.resid) hipLaunchKernelGGL((bn_apply_k<T, true>), dim3((unsigned)(g)), dim3(256), 0, s, a);                 \
+            else         hipLaunchKernelGGL((bn_apply_k<T, false>), dim3((unsigned)(g)), dim3(256), 0, s, a);                \
+        }                                                                                                                    \
     } while (0)
-    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid_for_groups(a.pixels * groups, groups));
+    LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid);
 #undef LBC_K
     return lbc_check_launch("bn_apply");
 }
 
-int lbc_chan_reduce_rows(long long pixels, int C)
+int lbc_chan_reduce_rows(long long pixels, int C, int max_rows)
 {
+    if (max_rows > 0) {          // a consumer folds the finalize (lbc_bn_fold_ok): few rows, whole pixel-lane groups per workgroup
+        const int rl0 = 256 / (C / 4);
+        long long rows0 = (pixels + rl0 - 1) / rl0;
+        if (rows0 > max_rows) rows0 = max_rows;
+        return (int)(rows0 < 1 ? 1 : rows0);
+    }
     const int rl = 256 / (C / 4);
     // at most 1024 workgroups, at least 8 pixels per pixel-lane; small tensors still get >= ~512 workgroups when they can
     long long ppb = (long long)rl * 64;
@@ -442,7 +591,7 @@ int lbc_chan_reduce_rows(long long pixels, int C)
 int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 8 == 0 && a.C / 4 <= 256, "chan_reduce: C=%d unsupported", a.C);
-    const int rows = lbc_chan_reduce_rows(a.pixels, a.C);
+    const int rows = lbc_chan_reduce_rows(a.pixels, a.C, a.max_rows);
     a.pix_per_block = (a.pixels + rows - 1) / rows;
     LbcProfScope prof(op == 0 ? "channel_stats" : "bn_bwd_reduce", 0.0,
                       (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * a.C * (op == 0 ? 1 : (1 + (a.mask ? 1 : 0) + (a.x ? 1 : 0) + (a.g_out ? 1 : 0))), s);
@@ -483,6 +632,23 @@ int lbc_bn_bwd_finalize(const BnBwdFinalizeArgs& a, hipStream_t s)
 int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s)
 {
     LBC_REQUIRE(a.C % 8 == 0 && a.Cout % 8 == 0 && a.Cout <= a.C, "bn_bwd_apply: bad channels");
+    if (a.fold) {
+        LBC_REQUIRE(!a.mask && !a.accum && a.fin.C == a.C && !a.fin.nsum && lbc_bn_fold_ok(a.fin.rows, a.C), "bn_bwd_apply: folded finalize outside its limits");
+        LbcProfScope prof("bn_bwd_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * (a.C * 2.0 + a.Cout), s);
+        const int groups = a.Cout / (a.act_bf16 ? 8 : 4);
+        int grid = grid_for_groups(a.pixels * groups, groups);
+        if (grid > kFoldGrid) {
+            int g = 256, r = groups;
+            while (r) { const int t = g % r; g = r; r = t; }
+            const int unit = groups / g;
+            grid = kFoldGrid / unit * unit;
+            if (grid < unit) grid = unit;
+        }
+#define LBC_K(T, g) hipLaunchKernelGGL((bn_bwd_apply_k<T, false, false, true>), dim3((unsigned)(g)), dim3(256), 0, s, a)
+        LBC_DISPATCH_ACT(a.act_bf16, LBC_K, grid);
+#undef LBC_K
+        return lbc_check_launch("bn_bwd_apply");
+    }
     LbcProfScope prof("bn_bwd_apply", 0.0, (a.act_bf16 ? 2.0 : 4.0) * (double)a.pixels * (a.C * (a.mask ? 3.0 : 2.0) + a.Cout * (a.accum ? 2.0 : 1.0)), s);
     const int groups = a.Cout / (a.act_bf16 ? 8 : 4);
 #define LBC_K(T, g)                                                                                                      \

@@ -291,7 +291,7 @@ int Net::check_bound(bool need_grads) const
 
 // ---------------------------------------------------------------------------------------
 int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre, const BN* post,
-                  const float* resid, bool relu, float* out)
+                  const float* resid, bool relu, float* out, float* stats_buf)
 {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -307,7 +307,7 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     if (act_bf16_) { a.w = W(c.wn); a.w_bf16 = 1; }
     const int cfg = lbc_igemm_pick_for(a, 0);
     *rows = lbc_igemm_rows(a, cfg);
-    a.stats = stats ? W(partial_) : nullptr;
+    a.stats = stats ? (stats_buf ? stats_buf : W(partial_)) : nullptr;
     return lbc_igemm_launch(a, 1, 0, cfg, s);
 }
 
@@ -413,16 +413,24 @@ int Net::bn_finalize(const BN& bn, int rows, long long count, int n_local, int t
         part = W(partial2_);
         rows = 64;
     }
+    BnFinalizeArgs f = fin_args(bn, part, rows, count, update_running);
+    f.nsum = nsum; f.n_local = n_local; f.train = train;
+    if (!train) { f.running_mean = P(bn.rm); f.running_var = P(bn.rv); f.num_batches_tracked = nullptr; }
+    return lbc_bn_finalize(f, s);
+}
+
+BnFinalizeArgs Net::fin_args(const BN& bn, const float* part, int rows, long long count, bool update_running) const
+{
     BnFinalizeArgs f;
     memset(&f, 0, sizeof(f));
-    f.partial = part; f.rows = rows; f.C = bn.C; f.count = count; f.nsum = nsum; f.n_local = n_local;
+    f.partial = part; f.rows = rows; f.C = bn.C; f.count = count;
     f.gamma = P(bn.g); f.beta = P(bn.b);
-    f.running_mean = (train && !update_running) ? nullptr : P(bn.rm);
-    f.running_var = (train && !update_running) ? nullptr : P(bn.rv);
-    f.num_batches_tracked = (train && update_running) ? static_cast<long long*>(t_[bn.nbt].ptr) : nullptr;
-    f.momentum = kBnMomentum; f.eps = kBnEps; f.train = train;
+    f.running_mean = update_running ? P(bn.rm) : nullptr;
+    f.running_var = update_running ? P(bn.rv) : nullptr;
+    f.num_batches_tracked = update_running ? static_cast<long long*>(t_[bn.nbt].ptr) : nullptr;
+    f.momentum = kBnMomentum; f.eps = kBnEps; f.train = 1;
     f.scale = W(bn.scale); f.shift = W(bn.shift); f.save_mean = W(bn.mean); f.save_invstd = W(bn.invstd);
-    return lbc_bn_finalize(f, s);
+    return f;
 }
 
 int Net::forward(int N, int train, const void* image, int image_u8, const float* velocity, const float* command, float* pred_sel,
@@ -481,8 +489,11 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             x = W(b.out);
             continue;
         }
+        // Where a BatchNorm's partial rows are few (small per-GPU batches) the elementwise pass that consumes its coefficients also
+        // does its finalize (BnApplyArgs::fold): bn1 in the z1 pass, bn2 and the downsample's BatchNorm in the block-output pass
         LBC_TRY(conv_fwd(b.c1, x, N, tr, &rows, s));
-        LBC_TRY(bn_finalize(b.b1, rows, pix, N, train, s));
+        const bool fold1 = !b.fuse_z1 && can_fold(rows, b.b1.C);
+        if (!fold1) LBC_TRY(bn_finalize(b.b1, rows, pix, N, train, s));
         BnApplyArgs ap;
         if (b.fuse_z1) {
             LBC_TRY(conv_fwd(b.c2, W(b.c1.y), N, tr, &rows, s, &b.b1));
@@ -490,16 +501,27 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             memset(&ap, 0, sizeof(ap));
             ap.x = W(b.c1.y); ap.y = W(b.z1); ap.pixels = pix; ap.C = b.c1.Cout;
             ap.scale = W(b.b1.scale); ap.shift = W(b.b1.shift); ap.relu = 1; ap.act_bf16 = act_bf16_;
+            if (fold1) { ap.fold = 1; ap.fin = fin_args(b.b1, W(partial_), rows, pix); }
             LBC_TRY(lbc_bn_apply(ap, s));
             LBC_TRY(conv_fwd(b.c2, W(b.z1), N, tr, &rows, s));
         }
-        LBC_TRY(bn_finalize(b.b2, rows, pix, N, train, s));
+        // (the downsample's rows must not overwrite conv2's before the folded pass has read them: they go to partial2_ -- idle while
+        //  no row count needs pre-reduction -- when they are certain to fit; otherwise bn2 is finalized by its own launch as before)
+        const size_t p2_floats = (size_t)64 * 2 * 640;
+        const bool fold2 = can_fold(rows, b.b2.C) && (!b.has_ds || (size_t)lbc_cdiv(pix, 64) * 2 * b.bd.C <= p2_floats);
+        const int rows2 = rows;
+        if (!fold2) LBC_TRY(bn_finalize(b.b2, rows, pix, N, train, s));
         memset(&ap, 0, sizeof(ap));
         ap.x = W(b.c2.y); ap.y = W(b.out); ap.pixels = pix; ap.C = b.c2.Cout;
         ap.scale = W(b.b2.scale); ap.shift = W(b.b2.shift); ap.relu = 1; ap.act_bf16 = act_bf16_;
+        if (fold2) { ap.fold = 1; ap.fin = fin_args(b.b2, W(partial_), rows2, pix); }
         if (b.has_ds) {
-            LBC_TRY(conv_fwd(b.ds, x, N, tr, &rows, s));
-            LBC_TRY(bn_finalize(b.bd, rows, pix, N, train, s));
+            float* dsp = fold2 ? W(partial2_) : W(partial_);
+            LBC_TRY(conv_fwd(b.ds, x, N, tr, &rows, s, nullptr, nullptr, nullptr, false, nullptr, dsp));
+            LBC_REQUIRE(!fold2 || (size_t)rows * 2 * b.bd.C <= p2_floats, "net.forward: downsample statistics rows exceed their buffer");
+            if (fold2 && can_fold(rows, b.bd.C)) { ap.rfold = 1; ap.rfin = fin_args(b.bd, dsp, rows, pix); }
+            else if (fold2) LBC_TRY(lbc_bn_finalize(fin_args(b.bd, dsp, rows, pix), s));     // (can_fold implies local statistics and <= 1024 rows)
+            else LBC_TRY(bn_finalize(b.bd, rows, pix, N, train, s));
             ap.resid = W(b.ds.y); ap.rscale = W(b.bd.scale); ap.rshift = W(b.bd.shift);
         } else {
             ap.resid = x;
@@ -516,10 +538,13 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         ChanReduceArgs cr;
         memset(&cr, 0, sizeof(cr));
         cr.x = W(hcat_); cr.partial = W(partial_); cr.pixels = (long long)N * th * tw; cr.C = 640; cr.act_bf16 = act_bf16_;
+        cr.max_rows = fold_rows_for(cr.pixels, 640);
         LBC_TRY(lbc_chan_reduce(cr, 0, s));
-        rows = lbc_chan_reduce_rows(cr.pixels, 640);
+        rows = lbc_chan_reduce_rows(cr.pixels, 640, cr.max_rows);
     }
-    if (tr) LBC_TRY(bn_finalize(dec_[0].bn, rows, (long long)N * th * tw, N, train, s));
+    // the finalize of stage i's BatchNorm is issued in iteration i: folded into the bn_apply pass over the stage's input where there is one
+    int pend_rows = rows;
+    long long pend_count = (long long)N * th * tw;
     const float* din = W(hcat_);
     for (int i = 0; i < 3; ++i) {
         Deconv& D = dec_[i];
@@ -557,17 +582,20 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
                 memset(&ap, 0, sizeof(ap));
                 ap.x = din; ap.y = W(gF_); ap.pixels = (long long)N * D.H * D.W; ap.C = D.Cin;
                 ap.scale = W(D.bn.scale); ap.shift = W(D.bn.shift); ap.relu = 0; ap.act_bf16 = 1;
+                if (tr && can_fold(pend_rows, D.Cin)) { ap.fold = 1; ap.fin = fin_args(D.bn, W(partial_), pend_rows, pend_count); pend_rows = 0; }
+                else if (tr) { LBC_TRY(bn_finalize(D.bn, pend_rows, pend_count, N, train, s)); pend_rows = 0; }
                 LBC_TRY(lbc_bn_apply(ap, s));
                 a = b; cfg = c2;
             }
         }
+        if (tr && pend_rows > 0) LBC_TRY(bn_finalize(D.bn, pend_rows, pend_count, N, train, s));
         const int per = lbc_igemm_rows(a, cfg);
         LBC_TRY(lbc_igemm_launch(a, wmajor, 1, cfg, s));
         const long long opix = (long long)N * 4 * D.H * D.W;
         if (!tr) {
             // eval: statistics come from bn_eval_prep
         } else if (i < 2) {
-            LBC_TRY(bn_finalize(dec_[i + 1].bn, 4 * per, opix, N, train, s));
+            pend_rows = 4 * per; pend_count = opix;
         } else {
             // image.py:54-60: the four branch BatchNorms see the same tensor -> same batch statistics
             const float* part = W(partial_);
@@ -622,8 +650,9 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
         r.x = x; r.dz = dz; r.mask = mask; r.g_out = g_out; r.mean = W(bn.mean); r.invstd = W(bn.invstd);
         if (mask_bn) { r.mask_scale = W(mask_bn->scale); r.mask_shift = W(mask_bn->shift); }
         r.partial = W(partial_); r.pixels = pixels; r.C = bn.C; r.act_bf16 = act_bf16_;
+        r.max_rows = fold_rows_for(pixels, bn.C);      // small tensors: few enough rows for the apply pass to fold the finalize
         LBC_TRY(lbc_chan_reduce(r, 1, s));
-        rows = lbc_chan_reduce_rows(pixels, bn.C);
+        rows = lbc_chan_reduce_rows(pixels, bn.C, r.max_rows);
     } else {
         mask = nullptr;          // dz is the masked gradient already
         g_out = const_cast<float*>(dz);
@@ -639,9 +668,12 @@ int Net::bn_backward(const BN& bn, const float* dz, const float* mask, float* g_
     f.gamma = P(bn.g); f.mean = W(bn.mean); f.invstd = W(bn.invstd); f.train = 1;
     f.dgamma = G(bn.g); f.dbeta = G(bn.b);
     f.coefA = W(bn.cA); f.coefB = W(bn.cB); f.coefD = W(bn.cD);
-    LBC_TRY(bn_bwd_finalize(f, s));
+    // few rows: the apply pass does the finalize itself (BnBwdApplyArgs::fold), one launch less per BatchNorm
+    const bool fold = can_fold(rows, bn.C) && (g_out || !mask);
+    if (!fold) LBC_TRY(bn_bwd_finalize(f, s));
     BnBwdApplyArgs ap;
     memset(&ap, 0, sizeof(ap));
+    if (fold) { ap.fold = 1; ap.fin = f; }
     ap.g = g_out ? g_out : dz; ap.mask = g_out ? nullptr : mask; ap.x = x;
     ap.coefA = W(bn.cA); ap.coefB = W(bn.cB); ap.coefD = W(bn.cD);
     ap.mean = W(bn.mean); ap.invstd = W(bn.invstd);

@@ -103,7 +103,19 @@ private:
     // pre: BatchNorm(+ReLU) of the producer applied on load.  Eval mode folds the consumer-side BatchNorm into the epilogue:
     // y = relu?(conv * post.scale + post.shift + resid), written to `out` (default: the layer's raw-output buffer).
     int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre = nullptr,
-                 const BN* post = nullptr, const float* resid = nullptr, bool relu = false, float* out = nullptr);
+                 const BN* post = nullptr, const float* resid = nullptr, bool relu = false, float* out = nullptr, float* stats_buf = nullptr);
+    // the arguments of a training-mode forward finalize of `bn` over `rows` partial rows at `part` (one launch of its own, or folded
+    // into the consuming bn_apply pass: BnApplyArgs::fold)
+    BnFinalizeArgs fin_args(const BN& bn, const float* part, int rows, long long count, bool update_running = true) const;
+    // may the consumer of this BatchNorm's coefficients do the finalize itself? (local statistics, few rows: lbc_bn_fold_ok)
+    bool can_fold(int rows, int C) const { return !sync_fn_ && rows <= kLbcFinalizeRows && lbc_bn_fold_ok(rows, C); }
+    // row cap for a statistics / gradient-sum reduction whose consumer may fold the finalize: only for tensors small enough that
+    // ~100 workgroups still stream them at launch-latency cost (8 MB); 0 = the reduction's own policy
+    int fold_rows_for(long long pixels, int C) const
+    {
+        if (sync_fn_ || pixels * C * (act_bf16_ ? 2 : 4) > (8ll << 20)) return 0;
+        return lbc_bn_fold_ok(1, C) ? lbc_bn_fold_max_rows(C) : 0;
+    }
     int bn_eval_prep(hipStream_t s);
     int conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s);
     bool dgrad_wt_ = false;  // optional: input-gradient GEMMs read a per-step transposed copy of the weights (measured: no gain)

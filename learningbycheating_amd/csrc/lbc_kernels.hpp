@@ -53,8 +53,18 @@ struct BnApplyArgs {
     const float* rshift;
     int relu;
     int act_bf16;
+    // Folded finalize (training mode, few partial rows: lbc_bn_fold_ok): the launch does the work of lbc_bn_finalize(fin) itself --
+    // every workgroup re-derives scale / shift of all C channels from the partial rows (a few KB from L2), workgroup 0 also writes
+    // what the finalize kernel writes (scale, shift, saved statistics, running statistics, counter).  One 8-us launch less per
+    // BatchNorm where launches, not bytes, are the cost (the per-GPU batch of the 8-GPU run).  rfold: same for the residual's BatchNorm.
+    int fold, rfold;
+    BnFinalizeArgs fin, rfin;
 };
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s);
+// may a consumer fold the finalize of `rows` partial rows of a C-channel BatchNorm? (LBC_NO_BN_FOLD=1: never)
+bool lbc_bn_fold_ok(int rows, int C);
+// the largest row count lbc_bn_fold_ok accepts for C channels (producers that choose their own row count aim below it)
+int lbc_bn_fold_max_rows(int C);
 
 // ---- per-channel reductions --------------------------------------------------------
 struct ChanReduceArgs {
@@ -70,8 +80,9 @@ struct ChanReduceArgs {
     long long pixels; int C;
     long long pix_per_block;     // filled by the launcher
     int act_bf16;
+    int max_rows;                // > 0: at most this many partial rows (the consumer folds the finalize); 0: the launcher's own policy
 };
-int lbc_chan_reduce_rows(long long pixels, int C);
+int lbc_chan_reduce_rows(long long pixels, int C, int max_rows = 0);
 int lbc_chan_reduce(ChanReduceArgs a, int op, hipStream_t s);
 
 struct BnBwdFinalizeArgs {
@@ -92,6 +103,9 @@ struct BnBwdApplyArgs {
     long long pixels; int C, Cout;
     int accum;                   // dx += ...
     int act_bf16;
+    // folded finalize (as BnApplyArgs::fold; plain form only: no mask, no accumulation): the launch does lbc_bn_bwd_finalize(fin)
+    int fold;
+    BnBwdFinalizeArgs fin;
 };
 int lbc_bn_bwd_apply(const BnBwdApplyArgs& a, hipStream_t s);
 

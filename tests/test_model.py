@@ -269,7 +269,8 @@ def test_bf16_gradients_with_frozen_decisions_full_size(env):
 
 
 #: bounds of test_bf16_gradients_with_frozen_decisions_full_size (rel-to-max per tensor; set from the measured values with ~2x margin)
-BF16_FROZEN_MAX, BF16_FROZEN_MEDIAN = 0.25, 6e-2
+# measured on MI355X (profiles/r04_*_grad_diag.txt): median 2.3e-2, 90th percentile 4.0e-2, max 6.1e-2 (a layer-4 BatchNorm bias)
+BF16_FROZEN_MAX, BF16_FROZEN_MEDIAN = 0.12, 4.5e-2
 
 
 @gpu
@@ -678,6 +679,74 @@ def test_bn_backward_reduce_fused_into_dgrad_epilogue(env, kind, backbone, h, w,
     assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
 
 
+def _launch_counts(fn):
+    """{kernel class: launches} of fn() under the library's launch profiler (lbc_profile_enable / lbc_profile_report)"""
+    lib = _lib.get()
+    lib.lbc_profile_enable(1)
+    try:
+        fn()
+    finally:
+        lib.lbc_profile_enable(0)
+    buf = ctypes.create_string_buffer(1 << 16)
+    nbytes = lib.lbc_profile_report(buf, len(buf))
+    return {ln.split()[0]: int(ln.split()[1]) for ln in buf.raw[:nbytes].decode().strip().splitlines()}
+
+
+@pytest.mark.parametrize("precision", [0, 2])
+@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), ("birdview", "resnet18", 64, 64, 3),
+                                                 pytest.param("image", "resnet34", 160, 384, 32, marks=gpu),
+                                                 pytest.param("image", "resnet34", 160, 384, 16, marks=gpu)])
+def test_batchnorm_finalize_folded_into_its_consumer(env, kind, backbone, h, w, n, precision, lbc_config):
+    """small per-GPU batches: where a BatchNorm's partial rows are few, the elementwise pass that consumes its coefficients does
+    the finalize itself (BnApplyArgs::fold / BnBwdApplyArgs::fold; reference arithmetic resnet.py:38-54 forward and autograd).
+    Against LBC_NO_BN_FOLD=1 (every finalize its own launch): fewer launches, and the same waypoints, running statistics, saved
+    coefficients and gradients up to the order of the float64 row sums (<= 1e-6; in the bf16 mode a last-bit change of a
+    coefficient can flip a bf16 rounding downstream: bounds of test_bn_backward_reduce_fused_into_dgrad_epilogue)."""
+    dev, _ = env
+    if precision == 2:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+    sd = O.make_state_dict(kind, backbone, 23, h, w)
+    x, speed, cmd = _inputs(kind, n, h, w, 24)
+    g = torch.Generator().manual_seed(25)
+    d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g), torch.randn((n, 5, 2), generator=g)
+    runs = []
+    for nofold in (1, 0):
+        lbc_config("LBC_NO_BN_FOLD", nofold)
+        eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=precision)
+        out = {}
+
+        def step():
+            out["pred"] = eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
+            eng.backward(d_sel.to(dev), d_all.to(dev))
+        counts = _launch_counts(step)
+        runs.append((counts, out["pred"][1].cpu().clone(), {k: v.detach().cpu().clone() for k, v in tens.items()},
+                     {k: v.detach().cpu().clone() for k, v in eng.grad_views.items()},
+                     {k: v.float().cpu().clone() for k, v in eng.activations().items() if k.endswith((".scale", ".shift"))}))
+    (c0, p0, t0, g0, a0), (c1, p1, t1, g1, a1) = runs
+    fin0 = c0.get("bn_finalize", 0) + c0.get("bn_bwd_finalize", 0)
+    fin1 = c1.get("bn_finalize", 0) + c1.get("bn_bwd_finalize", 0)
+    _diag(dev, "folded BatchNorm finalizes, precision %d %s %s %dx%d N=%d: finalize launches %d -> %d, all launches %d -> %d"
+          % (precision, kind, backbone, h, w, n, fin0, fin1, sum(c0.values()), sum(c1.values())))
+    assert fin1 <= fin0 - 20 and sum(c1.values()) <= sum(c0.values()) - 20, (c0, c1)
+    tight = precision == 0
+    assert (p0 - p1).abs().max().item() < (1e-6 if tight else 2e-2)
+    for k in a0:
+        assert torch.allclose(a0[k], a1[k], rtol=1e-6 if tight else 2e-2, atol=1e-7 if tight else 1e-3), k
+    for k in t0:
+        if k.endswith(("running_mean", "running_var")):
+            assert torch.allclose(t0[k], t1[k], rtol=1e-6 if tight else 1e-3, atol=1e-7 if tight else 1e-5), k
+        if k.endswith("num_batches_tracked"):
+            assert int(t0[k]) == int(t1[k]) == 1, k
+    floor = 1e-6 * max(v.abs().max().item() for v in g0.values())        # (the head's biases: analytically zero gradients, round-off only)
+    rels = sorted(((g0[k] - g1[k]).abs().max().item() / (g0[k].abs().max().item() + floor), k) for k in g0
+                  if not (k.startswith("location_pred") and k.endswith("bias")))
+    rel = [r for r, _ in rels]
+    if tight:
+        assert rel[-1] < 2e-5, rels[-3:]       # (ReLU decisions are taken on identical activations up to the last bit of a coefficient)
+    else:
+        assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
+
+
 @pytest.mark.parametrize("precision", [0, 2])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 16, marks=gpu)])
 def test_staged_backward_equals_the_single_call(env, kind, backbone, h, w, n, precision, lbc_config):
@@ -920,6 +989,73 @@ def test_bf16_mode_declared_accuracy(env):
           % (steps_b, f[0], tail(f), tail(c), tail(h), t_c, t_h, f[30:].max(), c[30:].max(), h[30:].max()))
     assert t_h >= 25 and t_h >= min(t_c, 25) - 3, ("bf16 leaves the f32 curve earlier than a 1e-3 input perturbation does", t_h, t_c)
     assert tail(h) < 0.5 * h[:5].mean().item() and h[-10:].mean() <= h[-60:-50].mean() * 1.5, ("bf16 run does not descend", tail(h), h[:5].mean().item())
+
+
+@gpu
+def test_bf16_phase1_fit_matches_f32_over_seeds(env):
+    """Does the bf16 mode FIT as well as f32?  Round 3 compared one seed (bf16 ended at 2.0x the f32 loss, the f32 head kernels at
+    0.96x) -- but the synthetic phase-1 objective is chaotic (1 / y unprojection, train_image_phase1.py:43-64, one fixed batch): over
+    three seeds EVERY arm, the exact-f32 run with 1e-3 input noise included, lands between 0.2x and 20x of the clean f32 run
+    (profiles/r04_run1_bf16_seeds.log), so a single ratio says nothing and "within 1.25x on every seed" holds for no arm at all.
+    What can be asserted is distributional.  Six seeds (weights, data, teacher reseeded), 200 steps from an f32 warm start, three
+    arms: f32, f32 + 1e-3 input noise (the control: what ANY rounding-sized perturbation does), bf16.  Every run must be finite and
+    descend; the bf16 arm's median tail-loss ratio to f32 must not exceed 2.5x the control's (the median of 6 log-ratios with
+    sigma ~ 1.1 has a standard error of e^0.55); and bf16 must beat-or-match f32 (<= 1.25x) on no fewer seeds than the control
+    does, minus two."""
+    from learningbycheating_amd.bird_view.models import ImagePolicyModelSS, BirdViewPolicyModelSS
+    from learningbycheating_amd.training.native import NativeTrainer
+    dev, _ = env
+    n, steps, nseeds = 32, 200, 6
+    tails = {"fp32": [], "fp32_eps": [], "bf16": []}
+    firsts = []
+    for seed in range(nseeds):
+        base = 1000 * seed
+        rgb, speed, cmd = seeded_inputs("image", n, base + 41)
+        bv, _, _ = seeded_inputs("birdview", n, base + 42)
+        onehot = O.one_hot(cmd).to(dev)
+        rgb, speed, bv = rgb.to(dev), speed.to(dev), bv.to(dev)
+        g = torch.Generator().manual_seed(base + 43)
+        tgt = torch.rand((n, 4, 5, 2), generator=g)
+        tgt[..., 0] = tgt[..., 0] * 1.2 - 0.6
+        tgt[..., 1] = tgt[..., 1] * 0.5 + 0.3
+        torch.manual_seed(base + 44)
+        student = ImagePolicyModelSS("resnet34", all_branch=True).to(dev)
+        torch.manual_seed(base + 45)
+        teacher = BirdViewPolicyModelSS("resnet18", all_branch=True).to(dev)
+        warm = NativeTrainer(student, None, n, (3, 160, 384), dev, phase="l1_all", lr=1e-3)
+        for _ in range(40):
+            warm.step(rgb, speed, onehot, target=tgt.to(dev))
+        torch.cuda.synchronize()
+        del warm
+        ckpt = {k: v.detach().cpu().clone() for k, v in student.state_dict().items()}
+        noise = (torch.rand(rgb.shape, generator=torch.Generator().manual_seed(base + 47)) * 2 - 1).to(dev) * 1e-3
+        for arm, prec, x in (("fp32", "fp32", rgb), ("fp32_eps", "fp32", (rgb + noise).clamp(0, 1)), ("bf16", "bf16", rgb)):
+            m = ImagePolicyModelSS("resnet34", all_branch=True)
+            m.load_state_dict(ckpt)
+            m.precision = prec
+            m = m.to(dev)
+            t = BirdViewPolicyModelSS("resnet18", all_branch=True)
+            t.load_state_dict(teacher.state_dict())
+            t.precision = prec
+            t.to(dev)
+            tr = NativeTrainer(m, t, n, (3, 160, 384), dev, phase=1, lr=1e-4)
+            curve = torch.stack([tr.step(x, speed, onehot, birdview=bv).mean() for _ in range(steps)]).cpu()
+            del tr
+            assert torch.isfinite(curve).all(), (seed, arm)
+            tails[arm].append(curve[-20:].median().item())
+            if arm == "fp32":
+                firsts.append(curve[:3].mean().item())
+    med = lambda z: sorted(z)[len(z) // 2]
+    rb = [b / f for b, f in zip(tails["bf16"], tails["fp32"])]
+    rc = [c / f for c, f in zip(tails["fp32_eps"], tails["fp32"])]
+    _diag(dev, "phase-1 fit over %d seeds, tail loss (median of the last 20 of %d steps): f32 %s | f32 + 1e-3 input noise %s (ratio to f32: %s, median %.2f) | "
+               "bf16 %s (ratio to f32: %s, median %.2f)"
+          % (nseeds, steps, " ".join("%.4f" % v for v in tails["fp32"]), " ".join("%.4f" % v for v in tails["fp32_eps"]), " ".join("%.2f" % v for v in rc), med(rc),
+             " ".join("%.4f" % v for v in tails["bf16"]), " ".join("%.2f" % v for v in rb), med(rb)))
+    for arm in tails:
+        assert all(t < 0.8 * f for t, f in zip(tails[arm], firsts)), (arm, tails[arm], firsts)       # every run descends
+    assert med(rb) <= 2.5 * max(1.0, med(rc)), (med(rb), med(rc))
+    assert sum(r <= 1.25 for r in rb) >= sum(r <= 1.25 for r in rc) - 2, (rb, rc)
 
 
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])

@@ -163,8 +163,11 @@ def _k_steps(dev, phase, small, k, n, grad_tol, head_tol, side_stream=True, lbc_
             sp_, sm_, sv_ = _adam_update(p0, gf, m0[nm], v0[nm], t)
             assert (p1 - sp_).abs().max().item() <= 2e-6 * LR / 1e-4 * (1 + p0.abs().max().item()), ("step %d: Adam update of %s" % (t, nm))
             # ... and lie where the oracle's update may lie given the gradient tolerance
-            lo, hi = _adam_update(p0, rf - d, m0[nm], v0[nm], t)[0], _adam_update(p0, rf + d, m0[nm], v0[nm], t)[0]
-            span = torch.maximum((lo - op).abs(), (hi - op).abs()) * 1.5 + 1e-7 * (1 + p0.abs())
+            # (m / sqrt(v) is not monotonic in g once the moments carry history: the range is taken over a grid of gradients in [g - d, g + d])
+            span = torch.zeros_like(op)
+            for frac in (-1.0, -0.75, -0.5, -0.25, 0.25, 0.5, 0.75, 1.0):
+                span = torch.maximum(span, (_adam_update(p0, rf + frac * d, m0[nm], v0[nm], t)[0] - op).abs())
+            span = span * 1.5 + 1e-7 * (1 + p0.abs()) + 1e-3 * LR
             out = ((p1 - op).abs() - span).clamp_min(0).max().item()
             worst["p_out_of_range"] = max(worst["p_out_of_range"], out / LR)
             assert out == 0.0, ("step %d: parameter %s outside the update range its gradient tolerance allows" % (t, nm), out)
