@@ -63,6 +63,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
         cnt = ntiles - first < tpw ? ntiles - first : tpw;
     }
     if (cnt <= 0) return;
+    float wg_u1 = 0.f, wg_u2 = 0.f;         // threads < BN: this workgroup's statistics row, accumulated over its tiles
 
     // stationary weights: output channel 32 wn + l31, k-slots = channels 16 g + 8 kh .. + 7 of tap t
     bf16x8 wreg[9][4];
@@ -159,14 +160,12 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             LBC_WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
         }
-        if (a.stats && it > 0 && tid < BN) {                    // the previous tile's statistics row
+        if (a.stats && it > 0 && tid < BN) {                    // the previous tile's statistics: into this workgroup's running row
             const float* rp = red + ((it - 1) & 1) * (WM * 2 * BN);
             float u1 = 0.f, u2 = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < WM; ++w2) { u1 += rp[(w2 * 2 + 0) * BN + tid]; u2 += rp[(w2 * 2 + 1) * BN + tid]; }
-            float* dst = a.stats + (size_t)(a.stat_row0 + tile - 1) * 2 * BN;
-            dst[tid] = u1;
-            dst[BN + tid] = u2;
+            wg_u1 += u1; wg_u2 += u2;
         }
 
         f32x16 acc[MT];
@@ -306,9 +305,11 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             float u1 = 0.f, u2 = 0.f;
 #pragma unroll
             for (int w2 = 0; w2 < WM; ++w2) { u1 += rp[(w2 * 2 + 0) * BN + tid]; u2 += rp[(w2 * 2 + 1) * BN + tid]; }
-            float* dst = a.stats + (size_t)(a.stat_row0 + first + cnt - 1) * 2 * BN;
-            dst[tid] = u1;
-            dst[BN + tid] = u2;
+            // ONE row per persistent workgroup (its tiles summed in tile order): <= 256 rows per launch whatever the batch -- the
+            // finalize needs no pre-reduction pass (3840 per-tile rows at batch 256 did), and its consumer may fold it at small batch
+            float* dst = a.stats + (size_t)(a.stat_row0 + first / tpw) * 2 * BN;
+            dst[tid] = wg_u1 + u1;
+            dst[BN + tid] = wg_u2 + u2;
         }
     }
     (void)npw;
@@ -316,8 +317,16 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
 
 }  // namespace
 
+// statistics rows of a launch: one per persistent workgroup
+int lbc_conv_c64p_rows(const IgemmArgs& a)
+{
+    const int ntiles = lbc_cdiv(a.M, 256);
+    const int cap = lbc_opt(kOptHaloBlocks) > 0 ? (int)lbc_opt(kOptHaloBlocks) : 256;
+    return lbc_cdiv(ntiles, lbc_cdiv(ntiles, cap));
+}
+
 // C = K = 64, 3x3 / stride 1 on bf16 tensors with bf16 weight copies (lbc_conv_hdma_pick: cfg kLbcCfgHdma + 3); statistics rows
-// are per 256-pixel tile
+// are per persistent workgroup (lbc_conv_c64p_rows)
 int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
 {
     LBC_REQUIRE(a.C == 64 && a.K == 64 && !a.post_scale == !a.post_shift && (mode == 0 || mode == 1), "conv_c64p: shape");

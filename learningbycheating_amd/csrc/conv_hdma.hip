@@ -422,7 +422,11 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     return -1;
 }
 
-int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg) { return lbc_cdiv(a.M, kHdmaCfg[cfg - kLbcCfgHdma].bm); }
+int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg)
+{
+    if (cfg == kLbcCfgHdma + 3) return lbc_conv_c64p_rows(a);         // one row per persistent workgroup
+    return lbc_cdiv(a.M, kHdmaCfg[cfg - kLbcCfgHdma].bm);
+}
 
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
 {

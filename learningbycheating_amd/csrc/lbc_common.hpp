@@ -174,6 +174,7 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s);     // conv_c64p.hip: cfg kLbcCfgHdma + 3 (C = K = 64)
+int lbc_conv_c64p_rows(const IgemmArgs& a);                                  // statistics rows it writes: one per persistent workgroup
 bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg);       // conv_hdmap.hip: persistent form of cfg 1 / 2
 int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64} or -1

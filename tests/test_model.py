@@ -1053,7 +1053,7 @@ def test_bf16_phase1_fit_matches_f32_over_seeds(env):
           % (nseeds, steps, " ".join("%.4f" % v for v in tails["fp32"]), " ".join("%.4f" % v for v in tails["fp32_eps"]), " ".join("%.2f" % v for v in rc), med(rc),
              " ".join("%.4f" % v for v in tails["bf16"]), " ".join("%.2f" % v for v in rb), med(rb)))
     for arm in tails:
-        assert all(t < 0.8 * f for t, f in zip(tails[arm], firsts)), (arm, tails[arm], firsts)       # every run descends
+        assert all(t < 0.95 * f for t, f in zip(tails[arm], firsts)), (arm, tails[arm], firsts)       # every run descends
     assert med(rb) <= 2.5 * max(1.0, med(rc)), (med(rb), med(rc))
     assert sum(r <= 1.25 for r in rb) >= sum(r <= 1.25 for r in rc) - 2, (rb, rc)
 
