@@ -86,7 +86,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_k(BnFinalizeArgs a)
 {
     const int c = blockIdx.x * kFinCh + (threadIdx.x & (kFinCh - 1));
     const bool lead = threadIdx.x < kFinCh;
-    if (c == 0 && lead && a.num_batches_tracked && a.train) *a.num_batches_tracked += 1;
+    if (c == 0 && lead && a.num_batches_tracked && a.train) {
+        *a.num_batches_tracked += 1;
+        for (int k = 0; k < 3 && a.more_num_batches_tracked[k]; ++k) *a.more_num_batches_tracked[k] += 1;
+    }
     double s1 = 0.0, s2 = 0.0;
     if (a.train) sum_rows2(a.partial, a.rows, a.C, c, c < a.C, s1, s2);
     if (c >= a.C || !lead) return;
@@ -102,6 +105,10 @@ __global__ __launch_bounds__(1024) void bn_finalize_k(BnFinalizeArgs a)
             const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
             a.running_mean[c] = (float)((1.0 - a.momentum) * (double)a.running_mean[c] + a.momentum * m);
             a.running_var[c] = (float)((1.0 - a.momentum) * (double)a.running_var[c] + a.momentum * unb);
+            for (int k = 0; k < 3 && a.more_running_mean[k]; ++k) {
+                a.more_running_mean[k][c] = (float)((1.0 - a.momentum) * (double)a.more_running_mean[k][c] + a.momentum * m);
+                a.more_running_var[k][c] = (float)((1.0 - a.momentum) * (double)a.more_running_var[k][c] + a.momentum * unb);
+            }
         }
     } else {
         mean = a.running_mean[c];
@@ -116,72 +123,78 @@ __global__ __launch_bounds__(1024) void bn_finalize_k(BnFinalizeArgs a)
 }
 
 // ---- folded finalize: the consumer's workgroup derives the coefficients itself -------------------------------------------------
-// sums the `rows` partial rows of column pair (c, C + c) for every channel: 256 threads = (256 / Cp) row-lanes x Cp channels per
-// pass (Cp = min(C, 256)), eight rows in flight per lane, lanes combined through LDS in a fixed order.  o1 / o2 valid where
-// lane == 0.  Every workgroup of a launch runs the same code on the same rows: all of them get the same bits.
+// Column sums of partial[rows][2C] -> colsum[2C] (double, LDS), by all 256 threads: a thread owns one 16-byte column group and a
+// row lane, loads up to 16 rows at once (every load of a batch in flight before the first use: at most two batches under the
+// lbc_bn_fold_ok limit of 128 KB per BatchNorm -- a dependent chain of row reads was the whole cost of a first version that walked
+// the rows four at a time), row lanes combined through LDS in a fixed order.  Every workgroup of a launch runs the same code on
+// the same rows: all of them get the same bits.  Ends with a barrier.
 constexpr int kFoldMaxC = 640;
-__device__ __forceinline__ void fold_sum_rows(const float* __restrict__ partial, int rows, int C, int c, int lane, int nlanes, double* red,
-                                              double& o1, double& o2)
+__device__ __forceinline__ void fold_colsums(const float* __restrict__ partial, int rows, int C, double* colsum, double* scratch /*[256 * 4]*/)
 {
-    double a[4] = {0.0, 0.0, 0.0, 0.0}, b[4] = {0.0, 0.0, 0.0, 0.0};
-    const size_t rs = (size_t)2 * C;
-    int r = lane;
-    for (; r + 3 * nlanes < rows; r += 4 * nlanes) {
+    const int ncg = (2 * C) / 4;
+    for (int cg0 = 0; cg0 < ncg; cg0 += 256) {
+        const int width = ncg - cg0 < 256 ? ncg - cg0 : 256;      // 32, 64, 128 or 256 (C = 640: 256 then 64)
+        const int nl = 256 / width;
+        const int cg = cg0 + (int)threadIdx.x % width, lane = (int)threadIdx.x / width;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+        const f32x4* base = reinterpret_cast<const f32x4*>(partial) + cg;
+        for (int r = lane; r < rows; r += 16 * nl) {
+            f32x4 v[16];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            a[u] += (double)partial[(size_t)(r + u * nlanes) * rs + c];
-            b[u] += (double)partial[(size_t)(r + u * nlanes) * rs + C + c];
+            for (int u = 0; u < 16; ++u) {
+                const int rr = r + u * nl;
+                v[u] = base[(size_t)(rr < rows ? rr : r) * ncg];       // (clamped: always a valid row; dropped below)
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                if (r + u * nl < rows) { a0 += (double)v[u][0]; a1 += (double)v[u][1]; a2 += (double)v[u][2]; a3 += (double)v[u][3]; }
+            }
         }
-    }
-    for (; r < rows; r += nlanes) { a[0] += (double)partial[(size_t)r * rs + c]; b[0] += (double)partial[(size_t)r * rs + C + c]; }
-    double v1 = (a[0] + a[1]) + (a[2] + a[3]), v2 = (b[0] + b[1]) + (b[2] + b[3]);
-    if (nlanes > 1) {
-        red[threadIdx.x] = v1; red[256 + threadIdx.x] = v2;
-        __syncthreads();
-        if (lane == 0) {
-            const int cp = 256 / nlanes;
-            for (int k = 1; k < nlanes; ++k) { v1 += red[k * cp + threadIdx.x]; v2 += red[256 + k * cp + threadIdx.x]; }
+        if (nl > 1) {
+            double* sp = scratch + (size_t)threadIdx.x * 4;
+            sp[0] = a0; sp[1] = a1; sp[2] = a2; sp[3] = a3;
+            __syncthreads();
+            if (lane == 0) {
+                for (int k = 1; k < nl; ++k) {
+                    const double* q = scratch + (size_t)(k * width + (int)threadIdx.x) * 4;
+                    a0 += q[0]; a1 += q[1]; a2 += q[2]; a3 += q[3];
+                }
+            }
         }
+        if (lane == 0) { double* d = colsum + (size_t)cg * 4; d[0] = a0; d[1] = a1; d[2] = a2; d[3] = a3; }
         __syncthreads();
     }
-    o1 = v1; o2 = v2;
 }
 
 // the forward finalize of one BatchNorm inside a consumer: scale / shift of all C channels -> sc[], sh[] (LDS); `writer` (workgroup 0)
 // also does bn_finalize_k's global writes.  Ends with a barrier.
-__device__ __forceinline__ void fold_finalize(const BnFinalizeArgs& f, float* sc, float* sh, double* red, bool writer)
+__device__ __forceinline__ void fold_finalize(const BnFinalizeArgs& f, float* sc, float* sh, double* colsum, double* scratch, bool writer)
 {
     const int C = f.C;
-    const int cp = C < 256 ? C : 256, nlanes = 256 / cp;
+    fold_colsums(f.partial, f.rows, C, colsum, scratch);
     if (writer && threadIdx.x == 0 && f.num_batches_tracked) *f.num_batches_tracked += 1;
-    for (int c0 = 0; c0 < C; c0 += cp) {
-        const int cl = threadIdx.x % cp, lane = threadIdx.x / cp;
-        const int c = c0 + cl;
-        double s1 = 0.0, s2 = 0.0;
-        const bool ok = c < C && lane < nlanes;
-        fold_sum_rows(f.partial, ok ? f.rows : 0, C, ok ? c : 0, ok ? lane : 1, nlanes, red, s1, s2);
-        if (ok && lane == 0) {
-            const double n = (double)f.count;
-            const double m = s1 / n;
-            double var = s2 / n - m * m;
-            if (var < 0.0) var = 0.0;
-            const float mean = (float)m;
-            const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
-            const float g = f.gamma ? f.gamma[c] : 1.f;
-            const float b = f.beta ? f.beta[c] : 0.f;
-            const float scv = g * invstd;
-            sc[c] = scv;
-            sh[c] = b - mean * scv;
-            if (writer) {
-                if (f.running_mean) {
-                    const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
-                    f.running_mean[c] = (float)((1.0 - f.momentum) * (double)f.running_mean[c] + f.momentum * m);
-                    f.running_var[c] = (float)((1.0 - f.momentum) * (double)f.running_var[c] + f.momentum * unb);
-                }
-                if (f.save_mean) { f.save_mean[c] = mean; f.save_invstd[c] = invstd; }
-                f.scale[c] = scv;
-                f.shift[c] = b - mean * scv;
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double s1 = colsum[c], s2 = colsum[C + c];
+        const double n = (double)f.count;
+        const double m = s1 / n;
+        double var = s2 / n - m * m;
+        if (var < 0.0) var = 0.0;
+        const float mean = (float)m;
+        const float invstd = (float)(1.0 / sqrt(var + (double)f.eps));
+        const float g = f.gamma ? f.gamma[c] : 1.f;
+        const float b = f.beta ? f.beta[c] : 0.f;
+        const float scv = g * invstd;
+        sc[c] = scv;
+        sh[c] = b - mean * scv;
+        if (writer) {
+            if (f.running_mean) {
+                const double unb = n > 1.0 ? var * n / (n - 1.0) : var;
+                f.running_mean[c] = (float)((1.0 - f.momentum) * (double)f.running_mean[c] + f.momentum * m);
+                f.running_var[c] = (float)((1.0 - f.momentum) * (double)f.running_var[c] + f.momentum * unb);
             }
+            if (f.save_mean) { f.save_mean[c] = mean; f.save_invstd[c] = invstd; }
+            f.scale[c] = scv;
+            f.shift[c] = b - mean * scv;
         }
     }
     __syncthreads();
@@ -189,27 +202,22 @@ __device__ __forceinline__ void fold_finalize(const BnFinalizeArgs& f, float* sc
 
 // the backward finalize inside bn_bwd_apply: A, k1, k2 of all C channels -> LDS; workgroup 0 writes dgamma / dbeta (and the
 // coefficient vectors, which nothing else reads in this form but the introspection / tests may)
-__device__ __forceinline__ void fold_bwd_finalize(const BnBwdFinalizeArgs& f, float* sA, float* sK1, float* sK2, double* red, bool writer)
+__device__ __forceinline__ void fold_bwd_finalize(const BnBwdFinalizeArgs& f, float* sA, float* sK1, float* sK2, double* colsum, double* scratch,
+                                                  bool writer)
 {
     const int C = f.C;
-    const int cp = C < 256 ? C : 256, nlanes = 256 / cp;
-    for (int c0 = 0; c0 < C; c0 += cp) {
-        const int cl = threadIdx.x % cp, lane = threadIdx.x / cp;
-        const int c = c0 + cl;
-        double s1 = 0.0, s2 = 0.0;
-        const bool ok = c < C && lane < nlanes;
-        fold_sum_rows(f.partial, ok ? f.rows : 0, C, ok ? c : 0, ok ? lane : 1, nlanes, red, s1, s2);
-        if (ok && lane == 0) {
-            const double n = (double)f.count;
-            const double g = f.gamma ? (double)f.gamma[c] : 1.0;
-            const float A = (float)(g * (double)f.invstd[c]);
-            const float k1 = f.train ? (float)(s1 / n) : 0.f, k2 = f.train ? (float)(s2 / n) : 0.f;
-            sA[c] = A; sK1[c] = k1; sK2[c] = k2;
-            if (writer) {
-                if (f.dbeta) f.dbeta[c] = (float)s1;
-                if (f.dgamma) f.dgamma[c] = (float)s2;
-                if (f.coefA) { f.coefA[c] = A; f.coefB[c] = k1; f.coefD[c] = k2; }
-            }
+    fold_colsums(f.partial, f.rows, C, colsum, scratch);
+    for (int c = threadIdx.x; c < C; c += 256) {
+        const double s1 = colsum[c], s2 = colsum[C + c];
+        const double n = (double)f.count;
+        const double g = f.gamma ? (double)f.gamma[c] : 1.0;
+        const float A = (float)(g * (double)f.invstd[c]);
+        const float k1 = f.train ? (float)(s1 / n) : 0.f, k2 = f.train ? (float)(s2 / n) : 0.f;
+        sA[c] = A; sK1[c] = k1; sK2[c] = k2;
+        if (writer) {
+            if (f.dbeta) f.dbeta[c] = (float)s1;
+            if (f.dgamma) f.dgamma[c] = (float)s2;
+            if (f.coefA) { f.coefA[c] = A; f.coefB[c] = k1; f.coefD[c] = k2; }
         }
     }
     __syncthreads();
@@ -255,9 +263,9 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
     if constexpr (FOLD) {
         // this launch is also the finalize of its BatchNorm(s): coefficients from the partial rows, per workgroup (lbc_kernels.hpp)
         __shared__ __attribute__((aligned(16))) float fsc[2][kFoldMaxC], fsh[2][kFoldMaxC];
-        __shared__ double fred[512];
-        if (a.fold) { fold_finalize(a.fin, fsc[0], fsh[0], fred, blockIdx.x == 0); scp = fsc[0]; shp = fsh[0]; }
-        if (RES && a.rfold) { fold_finalize(a.rfin, fsc[1], fsh[1], fred, blockIdx.x == 0); rscp = fsc[1]; rshp = fsh[1]; }
+        __shared__ double fcol[2 * kFoldMaxC], fscr[256 * 4];
+        if (a.fold) { fold_finalize(a.fin, fsc[0], fsh[0], fcol, fscr, blockIdx.x == 0); scp = fsc[0]; shp = fsh[0]; }
+        if (RES && a.rfold) { fold_finalize(a.rfin, fsc[1], fsh[1], fcol, fscr, blockIdx.x == 0); rscp = fsc[1]; rshp = fsh[1]; }
     }
     const vec sc = PV::ld(scp + c), sh = PV::ld(shp + c);
     vec rsc = PV::splat(1.f), rsh = PV::splat(0.f);
@@ -415,8 +423,8 @@ __global__ __launch_bounds__(256, (MASK || ACCUM || FOLD) ? 1 : 8) void bn_bwd_a
     const float* pA = a.coefA; const float* pK1 = a.coefB; const float* pK2 = a.coefD;
     if constexpr (FOLD) {
         __shared__ __attribute__((aligned(16))) float fA[kFoldMaxC], fK1[kFoldMaxC], fK2[kFoldMaxC];
-        __shared__ double fred[512];
-        fold_bwd_finalize(a.fin, fA, fK1, fK2, fred, blockIdx.x == 0);
+        __shared__ double fcol[2 * kFoldMaxC], fscr[256 * 4];
+        fold_bwd_finalize(a.fin, fA, fK1, fK2, fcol, fscr, blockIdx.x == 0);
         pA = fA; pK1 = fK1; pK2 = fK2;
     }
     const vec cA = PV::ld(pA + c), k1 = PV::ld(pK1 + c), k2 = PV::ld(pK2 + c);
@@ -530,7 +538,8 @@ constexpr int kFoldGrid = 512;           // workgroups of a folding consumer (tw
 int lbc_bn_fold_max_rows(int C) { return (int)(kFoldBytes / (8ll * C)); }
 bool lbc_bn_fold_ok(int rows, int C)
 {
-    return !lbc_opt_on(kOptNoBnFold) && C <= kFoldMaxC && (C < 256 ? 256 % C == 0 : true) && rows >= 1 && rows <= lbc_bn_fold_max_rows(C);
+    const int ncg = C / 2, tail = ncg % 256;          // 16-byte column groups of a row; every pass of fold_colsums needs a width that divides 256
+    return !lbc_opt_on(kOptNoBnFold) && C % 8 == 0 && C <= kFoldMaxC && (tail == 0 || 256 % tail == 0) && rows >= 1 && rows <= lbc_bn_fold_max_rows(C);
 }
 
 int lbc_bn_apply(const BnApplyArgs& a, hipStream_t s)

@@ -600,8 +600,22 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             // image.py:54-60: the four branch BatchNorms see the same tensor -> same batch statistics
             const float* part = W(partial_);
             int prow = 4 * per;
-            LBC_TRY(sync_rows(part, prow, 2 * 64, N, s));     // SyncBN: one all-reduce serves the four finalizes
-            for (int b = 0; b < 4; ++b) LBC_TRY(bn_finalize(head_bn_[b], 4 * per, opix, N, train, s, true, sync_fn_ ? part : nullptr));
+            // ONE finalize: the head kernels read the batch statistics of branch 0's slot (every branch folds its own gamma / beta
+            // into the projection); the other three branches only need their running statistics and counters moved along
+            LBC_TRY(sync_rows(part, prow, 2 * 64, N, s));     // SyncBN: one all-reduce
+            {
+                BnFinalizeArgs f = fin_args(head_bn_[0], part, prow, opix);
+                if (sync_fn_) { f.nsum = part + 2 * 64; f.n_local = N; }
+                else if (prow > kLbcFinalizeRows) {
+                    LBC_TRY(lbc_partial_reduce(W(partial_), prow, 2 * 64, W(partial2_), 64, s));
+                    f.partial = W(partial2_); f.rows = 64;
+                }
+                for (int b = 1; b < 4; ++b) {
+                    f.more_running_mean[b - 1] = P(head_bn_[b].rm); f.more_running_var[b - 1] = P(head_bn_[b].rv);
+                    f.more_num_batches_tracked[b - 1] = static_cast<long long*>(t_[head_bn_[b].nbt].ptr);
+                }
+                LBC_TRY(lbc_bn_finalize(f, s));
+            }
         }
         din = W(D.u);
     }

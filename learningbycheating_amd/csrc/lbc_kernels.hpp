@@ -18,6 +18,9 @@ struct BnFinalizeArgs {
     float* running_mean;         // train: updated (nullable); eval: read
     float* running_var;
     long long* num_batches_tracked;   // nullable
+    // train: further BatchNorms that see the SAME tensor (the waypoint head's four branches, image.py:54-60): their running
+    // statistics and counters get the same update in this launch (nullable entries end the list)
+    float* more_running_mean[3]; float* more_running_var[3]; long long* more_num_batches_tracked[3];
     float momentum, eps;
     int train;
     float* scale;                // out: gamma*invstd
