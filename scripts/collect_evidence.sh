@@ -2,7 +2,7 @@
 # copies what scripts/gpu_evidence.sh left in gpurun_out/ to profiles/${ROUND}_final_* (the tracked, judged copies); missing pieces are skipped
 cd "$(dirname "$0")/.."; R=gpurun_out; P=profiles; ROUND=${ROUND:-r04}; F=$P/${ROUND}_final
 c() { [ -e "$1" ] && cp "$1" "$2"; }
-c $R/summary.txt ${F}_summary.txt; c $R/bench_bf16.log ${F}_bench_bf16.log; c $R/bench_resident_bf16.log ${F}_bench_resident_bf16.log
+c $R/summary.txt ${F}_summary.txt; c $R/bench_bf16.log ${F}_bench_bf16.log; c $R/bench_h2d_bf16.log ${F}_bench_h2d_bf16.log
 for B in 128 64 32; do c $R/bench_b${B}_bf16.log ${F}_bench_b${B}_bf16.log; c $R/breakdown_b${B}_bf16.json ${F}_breakdown_b${B}_bf16.json; done
 for W in phase1_bs64_fp32 birdview_bs128 phase2_bs128; do c $R/bench_$W.log ${F}_bench_$W.log; c $R/breakdown_$W.json ${F}_breakdown_$W.json; done
 c $R/breakdown_bs256_bf16.json ${F}_breakdown_bs256_bf16.json

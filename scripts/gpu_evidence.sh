@@ -13,7 +13,7 @@ if [[ "$PHASES" == *bench* ]]; then
     timeout 300 python bench.py --global-batch $B --steps 50 --warmup 10 --no-cpu-baseline --no-alt --breakdown $R/breakdown_b${B}_bf16.json > $R/bench_b${B}_bf16.log 2>&1
     echo "b$B: $(tail -1 $R/bench_b${B}_bf16.log | cut -c1-200)" >> $S
   done
-  timeout 300 python bench.py --resident --no-cpu-baseline --no-alt > $R/bench_resident_bf16.log 2>&1; echo "resident: $(tail -1 $R/bench_resident_bf16.log | cut -c1-200)" >> $S
+  timeout 300 python bench.py --h2d --no-cpu-baseline --no-alt > $R/bench_h2d_bf16.log 2>&1; echo "h2d (PCIe-inclusive): $(tail -1 $R/bench_h2d_bf16.log | cut -c1-200)" >> $S
   for WLD in phase1_bs64_fp32 birdview_bs128 phase2_bs128; do
     timeout 300 python bench.py --workload $WLD --steps 30 --warmup 5 --no-cpu-baseline --breakdown $R/breakdown_$WLD.json > $R/bench_$WLD.log 2>&1
     echo "$WLD: $(tail -1 $R/bench_$WLD.log | cut -c1-220)" >> $S
