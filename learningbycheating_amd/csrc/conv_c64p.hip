@@ -26,8 +26,8 @@ namespace {
 // the landed halo is transformed IN PLACE once per tile (450 rows x 128 bytes: seven 16-byte chunks per thread, one extra barrier) before the
 // nine taps read it; rows that came from the zero page stay zero.  conv2 of the 64-channel layer reads y1 this way instead of going to
 // conv_halo.hip's register-staged kernel (147 us per launch at 256 images).
-template <int MODE, int EPI, bool PRE = false, bool ASMRD = true>
-__global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw)
+template <int MODE, int EPI, bool PRE = false>
+__global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
 {
     constexpr int BM = 256, BN = 64, WM = 4, WN = 2, MT = 2;
     constexpr int HRMAX = 456;                                  // BM + 2 W + 2 < 456 <=> W <= 98
@@ -108,6 +108,15 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
 #pragma unroll
     for (int j = 0; j < PPW; ++j) issue_piece(first * BM, 0, j);
 
+    // prof (diagnostic, LBC_C64P_PROF): per wave [0] tiles, [1] cycles waiting for the halo + opening barrier, [2] on-load transform,
+    // [3] K loop, [4] epilogue, [5] whole stream
+#ifdef LBC_HIP_EMULATED_FOR_TESTS
+#define LBC_NOW() 0ull
+#else
+#define LBC_NOW() __builtin_amdgcn_s_memtime()
+#endif
+    unsigned long long pf_wait = 0, pf_pre = 0, pf_k = 0, pf_epi = 0, pf_t0 = 0, pf_prev = 0;
+    if (prof) { pf_t0 = LBC_NOW(); pf_prev = pf_t0; }
     bool stores_pending = false;
     for (int it = 0; it < cnt; ++it) {
         const int tile = first + it;
@@ -137,6 +146,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
         // flight); then everybody's are visible -- and nobody reads the other buffer any more
         if (stores_pending) LBC_WAIT_VM(NSTEP); else LBC_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
+        if (prof) { const unsigned long long t = LBC_NOW(); pf_wait += t - pf_prev; pf_prev = t; }
         if constexpr (PRE) {
             // thread -> channel group tid & 7 (its scale / shift: loaded here, through an address the compiler cannot hoist out of the tile
             // loop -- 16 more registers across the K loop would spill), halo rows tid >> 3, + 64, ...; LDS slot of (row, group) = group ^ swizzle(row)
@@ -168,6 +178,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             wg_u1 += u1; wg_u2 += u2;
         }
 
+        if (prof) { const unsigned long long t = LBC_NOW(); pf_pre += t - pf_prev; pf_prev = t; }
         f32x16 acc[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -192,44 +203,18 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
                 aaddr[i] = abuf + (((val ^ zval) & m) ^ zval);
             }
         };
-        // Fragment reads PD depth steps ahead of their MFMAs, as inline asm the compiler does not track, waited for with hand-counted
-        // lgkmcnt (conv_hdmap.hpp's scheme).  Left to hipcc, the reads of step st + 1 sat BEHIND an MFMA of step st and in front of an
-        // `s_waitcnt lgkmcnt(0)` -- with LDS-DMA in flight it waits for everything -- three times per tap (ISA: "w0 MMM rr M w0 MM rr w0 M
-        // rr M rr d" per eight MFMAs): every second MFMA pair paid a full LDS latency that only the SIMD's other wave could cover
-        // (MFMA busy 0.19-0.30 on this kernel).  Here step st issues the reads of step st + PD first and waits until all but the PD * MT
-        // youngest reads have returned: PD = 2 (three register sets) where the registers allow, 1 in the forms that sit at 256 VGPRs.
-        // The K loop has no other LGKM traffic (no scalar loads: checked in the ISA, scripts/isa_mix.py), so the counts are exact.
-        // (ASMRD = false: round 3's compiler-managed reads, one step ahead -- LBC_C64P_NO_ASMRD=1, kept for the A/B)
-        constexpr int PD = (PRE || EPI == 2 || !ASMRD) ? 1 : 2, NS = PD + 1;
-        bf16x8 fa[NS][MT];
-#ifdef LBC_HIP_EMULATED_FOR_TESTS
-#define LBC_C6_RD(DST, ADDR) DST = *reinterpret_cast<const bf16x8*>(smem + (ADDR))
-#define LBC_C6_WAIT(N) do { } while (0)
-#define LBC_C6_USE(SET) do { } while (0)
-#else
-        const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
-#define LBC_C6_RD(DST, ADDR)                                                                                         \
-    do {                                                                                                             \
-        if constexpr (ASMRD) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(lds0 + (unsigned)(ADDR)));         \
-        else DST = *reinterpret_cast<const bf16x8*>(smem + (ADDR));                                                  \
-    } while (0)
-#define LBC_C6_WAIT(N) do { if constexpr (ASMRD) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, (N))); } while (0)
-#define LBC_C6_USE(SET) do { if constexpr (ASMRD) { _Pragma("unroll") for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(fa[SET][i])); } } while (0)
-#endif
+        bf16x8 fa[2][MT];
         tap_addr(0);
 #pragma unroll
-        for (int k = 0; k < PD; ++k) {                          // steps 0 .. PD - 1 (all of tap 0: PD <= 4)
-#pragma unroll
-            for (int i = 0; i < MT; ++i) LBC_C6_RD(fa[k][i], aaddr[i] ^ (32 * k));
-        }
+        for (int i = 0; i < MT; ++i) fa[0][i] = *reinterpret_cast<const bf16x8*>(smem + aaddr[i]);
 #pragma unroll
         for (int st = 0; st < 36; ++st) {                       // (tap, depth step) = (st / 4, st % 4)
             const int t = st >> 2, g = st & 3;
-            if (st + PD < 36) {
-                const int sn = st + PD, gn = sn & 3;
-                if (gn == 0) tap_addr(sn >> 2);                 // (every read of the previous tap has been issued)
+            if (st + 1 < 36) {
+                if (g == 3) tap_addr(t + 1);
+                const int g1 = (g + 1) & 3;
 #pragma unroll
-                for (int i = 0; i < MT; ++i) LBC_C6_RD(fa[sn % NS][i], aaddr[i] ^ (32 * gn));
+                for (int i = 0; i < MT; ++i) fa[(st + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + (aaddr[i] ^ (32 * g1)));
             }
             // the next tile's halo, one piece every fourth step (its last readers passed this tile's opening barrier)
             if (more && (st & 3) == 1 && (st >> 2) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 2);
@@ -241,19 +226,12 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
                 m = m < a.M ? m : a.M - 1;
                 lds_dma16(gsrc + ((unsigned)m * 64u + (unsigned)(32 * wn + (lane & 3) * 8)), smem + GT + wave * 4096 + j * 1024);
             }
-            {   // the reads of this step have returned when at most those of the later steps in flight are outstanding
-                const int ahead = 35 - st < PD ? 35 - st : PD;
-                if (ahead == 2) LBC_C6_WAIT(2 * MT); else if (ahead == 1) LBC_C6_WAIT(MT); else LBC_C6_WAIT(0);
-            }
-            LBC_C6_USE(st % NS);
 #pragma unroll
-            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % NS][i], wreg[t][g], acc[i], 0, 0, 0);
+            for (int i = 0; i < MT; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st & 1][i], wreg[t][g], acc[i], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);                  // keeps the address arithmetic of later taps out of this step (registers)
         }
-#undef LBC_C6_RD
-#undef LBC_C6_WAIT
-#undef LBC_C6_USE
 
+        if (prof) { LBC_WAIT_LGKM0(); const unsigned long long t = LBC_NOW(); pf_k += t - pf_prev; pf_prev = t; }
         // ---- wave-private epilogue
         if (EPI != 0) {     // own pieces of the side tile landed (requested at steps 3 .. 27; only the halo piece of step 29 is younger)
             if (more) LBC_WAIT_VM(1); else LBC_WAIT_VM(0);
@@ -310,6 +288,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             __builtin_amdgcn_wave_barrier();
         }
         stores_pending = true;
+        if (prof) { const unsigned long long t = LBC_NOW(); pf_epi += t - pf_prev; pf_prev = t; }
         if (a.stats && EPI == 2) {
             // lanes with the same segment (lane & 3) hold partial sums of the same 8 channels: combine over lane >> 2, then centre:
             // sum g * xhat = (sum g * y - mean * sum g) * invstd
@@ -346,6 +325,11 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             dst[BN + tid] = wg_u2 + u2;
         }
     }
+    if (prof && lane == 0) {
+        unsigned long long* o = prof + ((size_t)blockIdx.x * 8 + wave) * 8;
+        o[0] = (unsigned long long)cnt; o[1] = pf_wait; o[2] = pf_pre; o[3] = pf_k; o[4] = pf_epi; o[5] = LBC_NOW() - pf_t0;
+    }
+#undef LBC_NOW
     (void)npw;
 }
 
@@ -375,15 +359,10 @@ int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
     const int tpw = lbc_cdiv(ntiles, cap);
     const dim3 grid((unsigned)lbc_cdiv(ntiles, tpw));
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
-    const bool asmrd = !lbc_opt_on(kOptC64pNoAsmrd);
-#define LBC_C6(MODEv, EPIv)                                                                                                    \
-    do {                                                                                                                       \
-        if (asmrd) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, true>), grid, dim3(512), 0, s, a, zero, ntiles, tpw);   \
-        else       hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, false>), grid, dim3(512), 0, s, a, zero, ntiles, tpw);  \
-    } while (0)
+    unsigned long long* prof = lbc_opt(kOptC64pProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptC64pProf)) : nullptr;
+#define LBC_C6(MODEv, EPIv) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof)
     if (mode == 0 && a.pre_scale) {
-        if (asmrd) hipLaunchKernelGGL((conv_c64p_k<0, 0, true, true>), grid, dim3(512), 0, s, a, zero, ntiles, tpw);
-        else       hipLaunchKernelGGL((conv_c64p_k<0, 0, true, false>), grid, dim3(512), 0, s, a, zero, ntiles, tpw);
+        hipLaunchKernelGGL((conv_c64p_k<0, 0, true>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof);
         return lbc_check_launch("conv_c64p");
     }
     if (mode == 0) { if (epi == 1) LBC_C6(0, 1); else LBC_C6(0, 0); }
