@@ -217,7 +217,10 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
                 for (int i = 0; i < MT; ++i) fa[(st + 1) & 1][i] = *reinterpret_cast<const bf16x8*>(smem + (aaddr[i] ^ (32 * g1)));
             }
             // the next tile's halo, one piece every fourth step (its last readers passed this tile's opening barrier)
-            if (more && (st & 3) == 1 && (st >> 2) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 2);
+            // the next tile's halo, one piece every second step (all requested by step 15 of 36: in-kernel stamps, scripts/c64p_prof.py,
+            // show a wave 28 % of its time in the tile's opening wait + barrier -- with the pieces requested as late as step 29 just the
+            // same (profiles/r04_run6_*): that time is barrier skew between the SIMD's older and younger wave, not halo latency)
+            if (more && (st & 1) == 1 && (st >> 1) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 1);
             if (EPI != 0 && (st & 7) == 3 && st < 32) {
                 // this wave's 64 x 32 sub-tile of the residual / pre-BatchNorm activation, 16 rows (one DMA piece: 4 lanes per 64-byte
                 // row) at a time -> wave-private: its own vmcnt in front of the epilogue is all the synchronisation it needs
@@ -234,7 +237,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
         if (prof) { LBC_WAIT_LGKM0(); const unsigned long long t = LBC_NOW(); pf_k += t - pf_prev; pf_prev = t; }
         // ---- wave-private epilogue
         if (EPI != 0) {     // own pieces of the side tile landed (requested at steps 3 .. 27; only the halo piece of step 29 is younger)
-            if (more) LBC_WAIT_VM(1); else LBC_WAIT_VM(0);
+            // (requested at steps 3 .. 27: the youngest requests of the tile, the halo pieces are all older)
+            LBC_WAIT_VM(0);
         }
         const char* gt = smem + GT + wave * 4096 + l31 * 2;
         float s1 = 0.f, s2 = 0.f;
