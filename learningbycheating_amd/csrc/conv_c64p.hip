@@ -26,22 +26,31 @@ namespace {
 // the landed halo is transformed IN PLACE once per tile (450 rows x 128 bytes: seven 16-byte chunks per thread, one extra barrier) before the
 // nine taps read it; rows that came from the zero page stay zero.  conv2 of the 64-channel layer reads y1 this way instead of going to
 // conv_halo.hip's register-staged kernel (147 us per launch at 256 images).
-template <int MODE, int EPI, bool PRE = false>
-__global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
+// BMv (round 4): 256 = the shape above (8 waves, halo double-buffered across tiles, one workgroup per CU); 128 = four waves on a 128-pixel
+// tile with ONE halo buffer (328 rows, 41 KB) and TWO workgroups per CU.  In-kernel stamps of the 256 shape (scripts/c64p_prof.py,
+// profiles/r04_run5_c64p_prof.txt): a wave spends 47 % of a tile in its K loop, 21 % in the epilogue, 29 % in the opening wait + barrier
+// -- the eight waves of the workgroup walk the phases in lock-step (one barrier per tile), so the matrix pipe idles through every epilogue
+// and every barrier skew: MFMA busy 0.3.  With two independent four-wave workgroups per CU a SIMD holds one wave of each, and one runs its
+// K loop while the other stores, waits for its halo or sits in a barrier -- latency hidden by occupancy instead of by a software pipeline
+// that a workgroup-wide barrier per tile keeps breaking.  The single buffer costs a second barrier per tile (everybody has left the K loop
+// before the next halo is requested); its landing is covered by the epilogue and by the other workgroup.
+template <int MODE, int EPI, bool PRE = false, int BMv = 256>
+__global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
 {
-    constexpr int BM = 256, BN = 64, WM = 4, WN = 2, MT = 2;
-    constexpr int HRMAX = 456;                                  // BM + 2 W + 2 < 456 <=> W <= 98
-    constexpr int NP = HRMAX / 8;                               // 1-KiB halo pieces per tile (57)
-    constexpr int PPW = (NP + 7) / 8;                           // ... per wave (the last wave has one)
+    constexpr int BM = BMv, BN = 64, WM = BMv / 64, WN = 2, MT = 2;
+    constexpr int NWAVES = WM * WN, NBUF = BMv == 256 ? 2 : 1;
+    constexpr int HRMAX = BMv == 256 ? 456 : 328;               // BM + 2 W + 2 < HRMAX <=> W <= 98
+    constexpr int NP = HRMAX / 8;                               // 1-KiB halo pieces per tile (57 / 41)
+    constexpr int PPW = (NP + NWAVES - 1) / NWAVES;             // ... per wave (8 / 11; the last wave has fewer)
     constexpr int ABYTES = HRMAX * 128;
     constexpr int ZROW = (HRMAX - 1) * 128;
     constexpr int SROWS = 16, SROW_B = 32 * 2 + 16;             // staged rows per copy-out step, their LDS pitch (32 bf16 + 16 bytes)
-    constexpr int STG = 2 * ABYTES;                             // wave-private staging: 8 x SROWS x SROW_B
-    constexpr int RED = STG + 8 * SROWS * SROW_B;               // [2][WM][2][BN] floats
+    constexpr int STG = NBUF * ABYTES;                          // wave-private staging: NWAVES x SROWS x SROW_B
+    constexpr int RED = STG + NWAVES * SROWS * SROW_B;          // [2][WM][2][BN] floats
     constexpr int GT = RED + 2 * WM * 2 * BN * 4;               // EPI 1 / 2: per wave [64 rows][32 columns] of the residual / pre-BatchNorm activation
-    constexpr int SMEM = GT + (EPI != 0 ? 8 * 64 * 64 : 0);
+    constexpr int SMEM = GT + (EPI != 0 ? NWAVES * 64 * 64 : 0);
     constexpr int NSTEP = 64 / SROWS;                           // copy-out steps per wave and tile = 16-byte stores per lane
-    static_assert(SMEM <= 160 * 1024 && PPW == 8, "conv_c64p: LDS / piece arithmetic");
+    static_assert(SMEM <= (BMv == 256 ? 160 : 80) * 1024 && PPW <= 18 && (BMv == 256 || BMv == 128), "conv_c64p: LDS / piece arithmetic");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -78,14 +87,14 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
     // or past the halo come from the zero page (the last buffer row is the ZERO ROW of the border select)
     const int prow = lane >> 3, pseg = lane & 7;
     const int prel0 = wave * PPW * 8 + prow - (W + 1);
-    const int pswz_even = (pseg ^ (prow >> 1)) * 8, pswz_odd = (pseg ^ (4 + (prow >> 1))) * 8;
+    const int pswz_even = (pseg ^ (prow >> 1)) * 8, pswz_odd = (pseg ^ (4 + (prow >> 1))) * 8;     // swizzle of an even / odd PIECE (8 rows each)
     auto issue_piece = [&](const int m0x, const int buf, const int j) {
         const int piece = wave * PPW + j;
         if (piece < NP) {                                       // wave-uniform
             const int rel = prel0 + 8 * j;
             const int q = m0x + rel;
             const bool ok = q >= 0 && q < a.M && rel + (W + 1) < BM + 2 * W + 2;
-            const __bf16* src = ok ? xin + ((size_t)q * 64 + (size_t)((j & 1) ? pswz_odd : pswz_even)) : zero;
+            const __bf16* src = ok ? xin + ((size_t)q * 64 + (size_t)((piece & 1) ? pswz_odd : pswz_even)) : zero;
             lds_dma16(src, smem + buf * ABYTES + piece * 1024);
         }
     };
@@ -115,13 +124,14 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
 #else
 #define LBC_NOW() __builtin_amdgcn_s_memtime()
 #endif
+    constexpr bool PROFILED = EPI != 2;      // (the fused BatchNorm-backward form sits at 256 VGPRs: the stamps' registers would spill into its epilogue)
     unsigned long long pf_wait = 0, pf_pre = 0, pf_k = 0, pf_epi = 0, pf_t0 = 0, pf_prev = 0;
-    if (prof) { pf_t0 = LBC_NOW(); pf_prev = pf_t0; }
+    if (PROFILED && prof) { pf_t0 = LBC_NOW(); pf_prev = pf_t0; }
     bool stores_pending = false;
     for (int it = 0; it < cnt; ++it) {
         const int tile = first + it;
         const int m0 = tile * BM;
-        const int buf = it & 1;
+        const int buf = NBUF == 2 ? (it & 1) : 0;
         const bool more = it + 1 < cnt;
         // tap validity of this lane's rows in this tile
         int amask[MT];
@@ -146,7 +156,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
         // flight); then everybody's are visible -- and nobody reads the other buffer any more
         if (stores_pending) LBC_WAIT_VM(NSTEP); else LBC_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
-        if (prof) { const unsigned long long t = LBC_NOW(); pf_wait += t - pf_prev; pf_prev = t; }
+        if (PROFILED && prof) { const unsigned long long t = LBC_NOW(); pf_wait += t - pf_prev; pf_prev = t; }
         if constexpr (PRE) {
             // thread -> channel group tid & 7 (its scale / shift: loaded here, through an address the compiler cannot hoist out of the tile
             // loop -- 16 more registers across the K loop would spill), halo rows tid >> 3, + 64, ...; LDS slot of (row, group) = group ^ swizzle(row)
@@ -157,7 +167,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             const f32x8 ps8 = ParamVec<8>::ld(a.pre_scale + cg * 8), pt8 = ParamVec<8>::ld(a.pre_shift + cg * 8);
             const float floor8 = a.pre_relu ? 0.f : -INFINITY;
             const int HR = BM + 2 * W + 2;
-            for (int hr = tid >> 3; hr < HR; hr += 64) {
+            for (int hr = tid >> 3; hr < HR; hr += NWAVES * 8) {
                 const int q = m0 - (W + 1) + hr;
                 if (q >= 0 && q < a.M) {
                     bf16x8* p = reinterpret_cast<bf16x8*>(smem + buf * ABYTES + hr * 128 + ((cg ^ ((hr >> 1) & 7)) << 4));
@@ -178,7 +188,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             wg_u1 += u1; wg_u2 += u2;
         }
 
-        if (prof) { const unsigned long long t = LBC_NOW(); pf_pre += t - pf_prev; pf_prev = t; }
+        if (PROFILED && prof) { const unsigned long long t = LBC_NOW(); pf_pre += t - pf_prev; pf_prev = t; }
         f32x16 acc[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -220,7 +230,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             // the next tile's halo, one piece every second step (all requested by step 15 of 36: in-kernel stamps, scripts/c64p_prof.py,
             // show a wave 28 % of its time in the tile's opening wait + barrier -- with the pieces requested as late as step 29 just the
             // same (profiles/r04_run6_*): that time is barrier skew between the SIMD's older and younger wave, not halo latency)
-            if (more && (st & 1) == 1 && (st >> 1) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 1);
+            // (single halo buffer: requested behind the K loop instead, below)
+            if (NBUF == 2 && more && (st & 1) == 1 && (st >> 1) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 1);
             if (EPI != 0 && (st & 7) == 3 && st < 32) {
                 // this wave's 64 x 32 sub-tile of the residual / pre-BatchNorm activation, 16 rows (one DMA piece: 4 lanes per 64-byte
                 // row) at a time -> wave-private: its own vmcnt in front of the epilogue is all the synchronisation it needs
@@ -234,11 +245,21 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             __builtin_amdgcn_sched_barrier(0);                  // keeps the address arithmetic of later taps out of this step (registers)
         }
 
-        if (prof) { LBC_WAIT_LGKM0(); const unsigned long long t = LBC_NOW(); pf_k += t - pf_prev; pf_prev = t; }
+        if (PROFILED && prof) { LBC_WAIT_LGKM0(); const unsigned long long t = LBC_NOW(); pf_k += t - pf_prev; pf_prev = t; }
         // ---- wave-private epilogue
-        if (EPI != 0) {     // own pieces of the side tile landed (requested at steps 3 .. 27; only the halo piece of step 29 is younger)
+        if (EPI != 0) {     // own pieces of the side tile landed
             // (requested at steps 3 .. 27: the youngest requests of the tile, the halo pieces are all older)
             LBC_WAIT_VM(0);
+        }
+        if constexpr (NBUF == 1) {
+            // one halo buffer: the next tile's halo is requested once EVERY wave has left the K loop; it lands under this tile's
+            // epilogue (and under the CU's other workgroup).  The requests are older than the epilogue's stores, as the opening wait assumes
+            if (more) {
+                LBC_WAIT_LGKM0();
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) issue_piece(m0 + BM, 0, j);
+            }
         }
         const char* gt = smem + GT + wave * 4096 + l31 * 2;
         float s1 = 0.f, s2 = 0.f;
@@ -292,7 +313,7 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             __builtin_amdgcn_wave_barrier();
         }
         stores_pending = true;
-        if (prof) { const unsigned long long t = LBC_NOW(); pf_epi += t - pf_prev; pf_prev = t; }
+        if (PROFILED && prof) { const unsigned long long t = LBC_NOW(); pf_epi += t - pf_prev; pf_prev = t; }
         if (a.stats && EPI == 2) {
             // lanes with the same segment (lane & 3) hold partial sums of the same 8 channels: combine over lane >> 2, then centre:
             // sum g * xhat = (sum g * y - mean * sum g) * invstd
@@ -329,8 +350,8 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
             dst[BN + tid] = wg_u2 + u2;
         }
     }
-    if (prof && lane == 0) {
-        unsigned long long* o = prof + ((size_t)blockIdx.x * 8 + wave) * 8;
+    if (PROFILED && prof && lane == 0) {
+        unsigned long long* o = prof + ((size_t)blockIdx.x * NWAVES + wave) * 8;
         o[0] = (unsigned long long)cnt; o[1] = pf_wait; o[2] = pf_pre; o[3] = pf_k; o[4] = pf_epi; o[5] = LBC_NOW() - pf_t0;
     }
 #undef LBC_NOW
@@ -340,11 +361,15 @@ __global__ __launch_bounds__(512, 2) void conv_c64p_k(IgemmArgs a, const void* z
 }  // namespace
 
 // statistics rows of a launch: one per persistent workgroup
+// tile rows of the launch: LBC_C64P_BM = 256 / 128 pins a shape; default: the four-wave 128-pixel shape (two workgroups per CU)
+static int c64p_bm() { const long long v = lbc_opt(kOptC64pBm); return v == 256 ? 256 : 128; }
+static int c64p_cap(int bm) { return lbc_opt(kOptHaloBlocks) > 0 ? (int)lbc_opt(kOptHaloBlocks) : (bm == 256 ? 256 : 512); }   // persistent workgroups (tests: fewer)
+
 int lbc_conv_c64p_rows(const IgemmArgs& a)
 {
-    const int ntiles = lbc_cdiv(a.M, 256);
-    const int cap = lbc_opt(kOptHaloBlocks) > 0 ? (int)lbc_opt(kOptHaloBlocks) : 256;
-    return lbc_cdiv(ntiles, lbc_cdiv(ntiles, cap));
+    const int bm = c64p_bm();
+    const int ntiles = lbc_cdiv(a.M, bm);
+    return lbc_cdiv(ntiles, lbc_cdiv(ntiles, c64p_cap(bm)));
 }
 
 // C = K = 64, 3x3 / stride 1 on bf16 tensors with bf16 weight copies (lbc_conv_hdma_pick: cfg kLbcCfgHdma + 3); statistics rows
@@ -353,20 +378,25 @@ int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
 {
     LBC_REQUIRE(a.C == 64 && a.K == 64 && !a.post_scale == !a.post_shift && (mode == 0 || mode == 1), "conv_c64p: shape");
     LBC_REQUIRE(!a.pre_scale || (mode == 0 && a.pre_shift && !a.resid && !a.bnb_y), "conv_c64p: BatchNorm-on-load serves plain forward launches");
-    LBC_REQUIRE(256 + 2 * a.W + 2 < 456, "conv_c64p: image too wide for the halo buffer");
+    LBC_REQUIRE(2 * a.W + 2 < 200, "conv_c64p: image too wide for the halo buffer");
     LBC_REQUIRE(!a.bnb_y || (mode == 1 && !a.resid), "conv_c64p: the fused BatchNorm-backward reduce serves input gradients without a residual");
     const void* zero = nullptr;
     int rc = lbc_zero_page(&zero);
     if (rc) return rc;
-    const int ntiles = lbc_cdiv(a.M, 256);
-    const int cap = lbc_opt(kOptHaloBlocks) > 0 ? (int)lbc_opt(kOptHaloBlocks) : 256;     // one persistent workgroup per CU (tests: fewer)
-    const int tpw = lbc_cdiv(ntiles, cap);
+    const int bm = c64p_bm();
+    const int ntiles = lbc_cdiv(a.M, bm);
+    const int tpw = lbc_cdiv(ntiles, c64p_cap(bm));
     const dim3 grid((unsigned)lbc_cdiv(ntiles, tpw));
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
     unsigned long long* prof = lbc_opt(kOptC64pProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptC64pProf)) : nullptr;
-#define LBC_C6(MODEv, EPIv) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof)
+#define LBC_C6(MODEv, EPIv)                                                                                                          \
+    do {                                                                                                                             \
+        if (bm == 256) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, 256>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof); \
+        else           hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, 128>), grid, dim3(256), 0, s, a, zero, ntiles, tpw, prof); \
+    } while (0)
     if (mode == 0 && a.pre_scale) {
-        hipLaunchKernelGGL((conv_c64p_k<0, 0, true>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof);
+        if (bm == 256) hipLaunchKernelGGL((conv_c64p_k<0, 0, true, 256>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof);
+        else           hipLaunchKernelGGL((conv_c64p_k<0, 0, true, 128>), grid, dim3(256), 0, s, a, zero, ntiles, tpw, prof);
         return lbc_check_launch("conv_c64p");
     }
     if (mode == 0) { if (epi == 1) LBC_C6(0, 1); else LBC_C6(0, 0); }

@@ -73,6 +73,7 @@ enum LbcOpt {
     kOptNoC64pPre,         // LBC_NO_C64P_PRE: 1 = forward launches of the 64-channel layer with BatchNorm-on-load stay on conv_halo.hip (A/B)
     kOptHdmaSmallMinTiles, // LBC_HDMA_SMALL_MIN_TILES: fill threshold (tiles) from which a launch with few rows takes the four-wave 128 x 64 persistent shape (default 48; tests set 1)
     kOptNoBnFold,          // LBC_NO_BN_FOLD: 1 = every BatchNorm finalize is its own launch (A/B, tests); default: folded into the consuming elementwise pass where the partial rows are few
+    kOptC64pBm,            // LBC_C64P_BM: tile rows of conv_c64p_k: 256 = eight waves, double-buffered halo, one workgroup per CU (round 3); 128 (default) = four waves, one halo buffer, two workgroups per CU
     kOptC64pProf,          // LBC_C64P_PROF: device address of a u64[grid][8 waves][8] buffer -> conv_c64p_k stamps s_memtime around its phases (diagnostic, scripts/c64p_prof.py)
     kOptHeadNoSplit,       // LBC_HEAD_NO_SPLIT: 1 = the MFMA head multiplies with ONE bf16 copy of its folded weights (round 3's form; A/B) instead of the high + low pair
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)

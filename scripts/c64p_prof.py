@@ -44,14 +44,16 @@ for name, run in CASES.items():
         run()
     e1.record(); torch.cuda.synchronize()
     plain_us = e0.elapsed_time(e1) * 100
-    prof = torch.zeros((256, 8, 8), dtype=torch.int64, device=dev)
+    prof = torch.zeros((1024, 8, 8), dtype=torch.int64, device=dev)
     _lib.config_set("LBC_C64P_PROF", prof.data_ptr())
     run(); torch.cuda.synchronize()
     e0.record(); run(); e1.record(); torch.cuda.synchronize()
     stamped_us = e0.elapsed_time(e1) * 1000
     _lib.config_set("LBC_C64P_PROF", -1)
-    p = prof.cpu().double()
-    q = p[p[:, :, 0] > 0]
+    p = prof.cpu().double().reshape(-1, 8)          # [workgroup * waves per workgroup + wave][8] (8 or 4 waves per workgroup)
+    q = p[p[:, 0] > 0]
+    nw = 8 if int(_lib.config_get("LBC_C64P_BM")) == 256 else 4
+    p = p[: (p.shape[0] // nw) * nw].reshape(-1, nw, 8)
     tiles = q[:, 0]
     tot = q[:, 5]
     sh = lambda i: (q[:, i] / tot).mean().item()
@@ -60,7 +62,7 @@ for name, run in CASES.items():
           "epilogue %.2f | rest %.2f; per tile: K loop %.2f us (MFMA-bound: 72 MFMAs x 32 cycles x 2 waves per SIMD = 4608 cycles = %.2f us at 2.4 GHz), wait %.2f us, epilogue %.2f us"
           % (name, N, plain_us, stamped_us, q.shape[0], tiles.mean().item(), sh(1), sh(2), sh(3), sh(4), 1 - sh(1) - sh(2) - sh(3) - sh(4),
              (q[:, 3] / tiles).mean().item() / ticks_per_us, 4608 / 2400.0, (q[:, 1] / tiles).mean().item() / ticks_per_us, (q[:, 4] / tiles).mean().item() / ticks_per_us), flush=True)
-    for wv in range(8):
+    for wv in range(nw):
         sel = p[:, wv][p[:, wv, 0] > 0]
         if len(sel):
             print("    wave %d: wait %.2f pre %.2f K %.2f epi %.2f" % ((wv,) + tuple((sel[:, i] / sel[:, 5]).mean().item() for i in (1, 2, 3, 4))))
