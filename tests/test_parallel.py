@@ -324,11 +324,6 @@ def test_sync_batchnorm_and_gradient_buckets_gloo_world4():
     assert grad <= 2e-4, (grad, name)
 
 
-def test_data_parallel_gradients_emulated_gloo_world4():
-    (err, scale), = _run_world(_dp_worker, 4, results=1, timeout=900)
-    assert err <= 1e-6 * scale + 1e-12, (err, scale)
-
-
 def _sync_error_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -487,7 +482,7 @@ def _bucket_data(total, seed=60):
 
 
 def _bf16_bucket_worker(rank, world, port, q):
-    """three optimisation steps on two ranks, three times from the same initial weights: (A) f32 executor + f32 buckets, (B) f32
+    """two optimisation steps on two ranks, three times from the same initial weights: (A) f32 executor + f32 buckets, (B) f32
     executor + bf16 buckets, (D) bf16 executor + f32 buckets.  |B - A| is what the compressed wire format costs, |D - A| what the
     bf16 arithmetic of the same mode costs."""
     os.environ["MASTER_ADDR"] = "127.0.0.1"
@@ -497,7 +492,7 @@ def _bf16_bucket_worker(rank, world, port, q):
     emu.activate()
     from learningbycheating_amd.training.native import NativeTrainer
     from learningbycheating_amd.parallel import STAGE_PREFIXES
-    n, steps = 2, 3
+    n, steps = 2, 2
     x, speed, cmd, tgt = _bucket_data(world * n)
     sl = slice(rank * n, (rank + 1) * n)
     dev = torch.device("cpu")
@@ -529,7 +524,7 @@ def _bf16_bucket_worker(rank, world, port, q):
 
 
 def test_bf16_gradient_buckets_cost_less_than_the_bf16_arithmetic_gloo_world2():
-    """BASELINE.json config 3 sends the gradients as bf16.  After three Adam steps on two ranks the parameters of the run with bf16
+    """BASELINE.json config 3 sends the gradients as bf16.  After two Adam steps on two ranks the parameters of the run with bf16
     buckets differ from the f32-bucket run by LESS (per backward stage, mean absolute difference) than the run with the bf16
     executor and f32 buckets does: the wire format is not what limits the mode's accuracy.  (Adam normalises the update: one bf16
     rounding of a gradient, 2^-9 relative, moves m / sqrt(v) by the same relative amount -- a few 1e-3 of lr per step.)"""
@@ -537,7 +532,7 @@ def test_bf16_gradient_buckets_cost_less_than_the_bf16_arithmetic_gloo_world2():
     lr = 1e-4
     for st, (wire, arith) in enumerate(res):
         assert wire <= 0.5 * arith, ("stage %d: bf16 buckets move the parameters more than half of what the bf16 arithmetic does" % st, wire, arith)
-        assert wire <= 0.05 * lr * 3, ("stage %d: mean parameter difference from bf16 buckets after 3 steps, in units of lr" % st, wire / lr)
+        assert wire <= 0.05 * lr * 2, ("stage %d: mean parameter difference from bf16 buckets after 2 steps, in units of lr" % st, wire / lr)
 
 
 def test_bf16_wire_sum_of_eight_shards_emulated():

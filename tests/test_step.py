@@ -68,7 +68,7 @@ def _k_steps(dev, phase, small, k, n, grad_tol, head_tol, side_stream=True, lbc_
         tgt[..., 0] = tgt[..., 0] * 1.2 - 0.6
         tgt[..., 1] = tgt[..., 1] * 0.5 + 0.3
         warm = NativeTrainer(student, None, n, (3, sh, sw), dev, phase="l1_all", lr=1e-3)
-        for _ in range(6 if small else 30):
+        for _ in range(4 if small else 30):
             warm.step(x.to(dev), speed.to(dev), onehot.to(dev), target=tgt.to(dev))
         del warm
     tr = NativeTrainer(student, teacher, n, ((7 if skind == "birdview" else 3), sh, sw), dev, phase=phase, lr=LR, teacher_shape=(7, th, tw))
@@ -196,9 +196,10 @@ def _k_steps(dev, phase, small, k, n, grad_tol, head_tol, side_stream=True, lbc_
              worst["loss"], worst["p_out_of_range"]))
 
 
-@pytest.mark.parametrize("phase", [1, 0, "birdview"])
+@pytest.mark.parametrize("phase", [1, "birdview"])
 def test_native_trainer_k_steps_match_oracle_emulated(env, phase):
-    """the composition on the CPU-emulated kernels at reduced sizes (ResNet-18, 32 x 64 frames / 64 x 64 maps)"""
+    """the composition on the CPU-emulated kernels at reduced sizes (ResNet-18, 32 x 64 frames / 64 x 64 maps); phase 0 runs at full
+    size on the GPU only (same trainer code, another loss kernel -- covered per kernel in tests/test_model.py::test_loss_kernels)"""
     dev, _ = env
     _k_steps(dev, phase, True, 2, 3, 2e-4, 2e-4)
 
