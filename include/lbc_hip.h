@@ -148,6 +148,11 @@ int lbc_net_num_stages(void);
 /* State lbc_net_backward() would differentiate: batch size and mode of the last forward, and a counter that every forward
  * increments -- a caller that holds several forward results (autograd) can detect that the workspace has moved on. */
 int lbc_net_last_forward(const lbc_net* net, int* batch, int* train, long long* generation);
+/* frozen = 1: the caller promises not to change parameters or buffers until it says otherwise (the frozen privileged teacher of
+ * reference training/train_image_phase1.py:244-248, phase2_utils.py:70-77).  Eval-mode forwards then derive what they derive from
+ * the weights alone -- the bf16 weight copies (precision 2) and every BatchNorm's folded affine -- on the first forward only instead of
+ * on every one.  frozen = 0 (default) or any lbc_net_bind: derived again on the next forward. */
+int lbc_net_set_frozen(lbc_net* net, int frozen);
 int lbc_net_backward(lbc_net* net, const float* d_sel, const float* d_all, int stage, lbc_stream_t stream);
 /* Synchronized BatchNorm for data-parallel training (not in the reference, which is single-device; the equivalent of wrapping
  * its modules in torch.nn.SyncBatchNorm): every BatchNorm of a training-mode forward normalises with the statistics of the

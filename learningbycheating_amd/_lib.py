@@ -71,6 +71,7 @@ _SIGNATURES = {
     "lbc_net_num_stages": (c_int, []),
     "lbc_net_last_forward": (c_int, [c_void_p, ctypes.POINTER(c_int), ctypes.POINTER(c_int), ctypes.POINTER(ctypes.c_longlong)]),
     "lbc_net_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "lbc_net_set_frozen": (c_int, [c_void_p, c_int]),
     "lbc_net_set_sync_bn": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int]),
     "lbc_comm_unique_id": (c_int, [c_void_p]),
     "lbc_comm_create": (c_int, [c_void_p, c_int, c_int, ctypes.POINTER(c_void_p)]),

@@ -122,6 +122,12 @@ class PolicyBase(ResnetBase):
                 p.data = p.data.contiguous(memory_format=torch.channels_last)
         return out
 
+    def load_state_dict(self, *args, **kwargs):
+        out = super().load_state_dict(*args, **kwargs)
+        for eng in getattr(self, "_engines", {}).values():     # (values copied in place: a frozen engine must derive its weight copies again)
+            eng.invalidate()
+        return out
+
     def _arch(self):
         return {"resnet18": 18, "resnet34": 34}[self.backbone]
 

@@ -457,8 +457,11 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
     // bf16 modes: the padded image is bf16 too
     if (image_u8) LBC_TRY(lbc_prep_input_u8(static_cast<const unsigned char*>(image), W(xp_), bf16_, N, Cin, H0, W0, nc, s));
     else          LBC_TRY(lbc_prep_input(static_cast<const float*>(image), W(xp_), bf16_, N, Cin, H0, W0, nc, s));
-    if (act_bf16_) LBC_TRY(weight_prep(s));   // the caller's optimizer may have stepped: refresh the bf16 weight copies
-    if (!tr) LBC_TRY(bn_eval_prep(s));        // eval: every BatchNorm's affine from its running statistics, one launch
+    // derived from the weights alone: skipped when the caller declared them frozen and an eval-mode forward has derived them already
+    const bool reuse = frozen_ && derived_valid_ && !tr;
+    if (act_bf16_ && !reuse) LBC_TRY(weight_prep(s));   // the caller's optimizer may have stepped: refresh the bf16 weight copies
+    if (!tr && !reuse) LBC_TRY(bn_eval_prep(s));        // eval: every BatchNorm's affine from its running statistics, one launch
+    derived_valid_ = frozen_ && !tr;                    // (a training forward moves the running statistics: the eval-mode affines are stale after it)
 
     // resnet.py:148-152: conv1 -> bn1 -> relu -> maxpool
     StemArgs st;
@@ -1129,6 +1132,7 @@ int lbc_net_bind(lbc_net* net, void* workspace, void* const* tensor_ptrs, float*
 {
     LBC_REQUIRE(net && workspace && tensor_ptrs, "net_bind: null argument");
     net->impl.set_workspace(workspace);
+    net->impl.invalidate_derived();
     auto& ts = net->impl.tensors();
     for (size_t i = 0; i < ts.size(); ++i) {
         ts[i].ptr = tensor_ptrs[i];
@@ -1155,6 +1159,12 @@ int lbc_net_last_forward(const lbc_net* net, int* batch, int* train, long long* 
     if (batch) *batch = net->impl.last_batch();
     if (train) *train = net->impl.last_train();
     if (generation) *generation = net->impl.generation();
+    return LBC_OK;
+}
+int lbc_net_set_frozen(lbc_net* net, int frozen)
+{
+    LBC_REQUIRE(net, "net_set_frozen: null net");
+    net->impl.set_frozen(frozen != 0);
     return LBC_OK;
 }
 int lbc_net_set_sync_bn(lbc_net* net, lbc_allreduce_fn fn, void* ctx, int world_size, float* buf, int buf_floats)

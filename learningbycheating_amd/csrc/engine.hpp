@@ -81,6 +81,8 @@ public:
     struct ActInfo { std::string name; size_t offset_bytes; int H, W, C, elem; };
     std::vector<ActInfo> activations() const;
     // what backward() would differentiate: batch size and mode of the last forward, and how many forwards ran before it
+    void set_frozen(bool f) { frozen_ = f; derived_valid_ = false; }
+    void invalidate_derived() { derived_valid_ = false; }
     int last_batch() const { return lastN_; }
     int last_train() const { return last_train_; }
     long long generation() const { return generation_; }
@@ -191,6 +193,7 @@ private:
     size_t partial_floats_ = 0;
 
     // state of the last forward
+    bool frozen_ = false, derived_valid_ = false;     // lbc_net_set_frozen: weight copies / eval-mode affines derived once
     int lastN_ = 0;
     int last_train_ = 0;
     float* bwd_D_ = nullptr;   // running "gradient wrt block output" buffer between stages

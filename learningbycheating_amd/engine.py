@@ -163,6 +163,16 @@ class PolicyEngine:
                                % (what, rc, type(err).__name__, err)) from err
         _lib.check(rc, what)
 
+    def set_frozen(self, frozen=True):
+        """the caller promises not to touch parameters / buffers (a frozen teacher): eval-mode forwards then derive the bf16 weight
+        copies and the folded BatchNorm affines once instead of per forward (lbc_net_set_frozen); any re-bind derives them again"""
+        self._frozen = bool(frozen)
+        _lib.check(_lib.get().lbc_net_set_frozen(self.handle, int(self._frozen)), "net_set_frozen")
+
+    def invalidate(self):
+        """the bound tensors were rewritten in place (load_state_dict): whatever a frozen engine derived from them is derived again"""
+        _lib.check(_lib.get().lbc_net_set_frozen(self.handle, int(getattr(self, "_frozen", False))), "net_set_frozen")
+
     # ---- introspection (parity tests) ------------------------------------------------------
     def activations(self):
         """{name: tensor view} of the activations the last training-mode forward left in the workspace (lbc_net_activation_info):

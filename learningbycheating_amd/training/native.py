@@ -36,6 +36,9 @@ class NativeTrainer:
         if teacher is not None:
             teacher.eval()
             self.teng = teacher.engine((batch,) + tuple(teacher_shape), device, max_batch=batch, with_grads=False)
+            # the privileged teacher is frozen (train_image_phase1.py:244-248: loaded, eval(), never stepped): its bf16 weight copies and
+            # folded BatchNorm affines are derived on the first forward only
+            self.teng.set_frozen(True)
         self.cam = camera or camera_struct()
         self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
         self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group, grad_dtype=grad_dtype)   # grad_dtype: see parallel.py

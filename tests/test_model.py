@@ -754,6 +754,41 @@ def test_batchnorm_finalize_folded_into_its_consumer(env, kind, backbone, h, w, 
         assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_frozen_teacher_derives_its_weight_copies_once(env, precision):
+    """lbc_net_set_frozen (NativeTrainer sets it on the privileged teacher, train_image_phase1.py:244-248): the second eval-mode
+    forward launches neither weight_prep nor bn_eval_prep and returns the same bits; load_state_dict derives everything again"""
+    from learningbycheating_amd.bird_view.models import BirdViewPolicyModelSS
+    dev, _ = env
+    small = torch.device(dev).type != "cuda"
+    hw = (64, 64) if small else (192, 192)
+    torch.manual_seed(81)
+    t = BirdViewPolicyModelSS("resnet18", all_branch=True, **({"input_hw": hw} if small else {}))
+    t.precision = precision
+    t = t.to(dev).eval()
+    x, speed, cmd = _inputs("birdview", 3, hw[0], hw[1], 82)
+    eng = t.engine((3, 7) + hw, dev, max_batch=3, with_grads=False)
+    eng.set_frozen(True)
+    outs, counts = [], []
+    for _ in range(2):
+        counts.append(_launch_counts(lambda: outs.append(eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), False)[1].cpu().clone())))
+    assert counts[0].get("bn_eval_prep", 0) == 1 and counts[1].get("bn_eval_prep", 0) == 0, counts
+    assert counts[1].get("weight_prep", 0) == 0 and (precision == "fp32" or counts[0].get("weight_prep", 0) == 1), counts
+    assert torch.equal(outs[0], outs[1])
+    # new weights through the module API: derived again
+    sd = {k: (v * 1.5 if k.endswith("deconv.7.weight") else v.clone()) for k, v in t.state_dict().items()}
+    t.load_state_dict(sd)
+    c3 = _launch_counts(lambda: outs.append(eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), False)[1].cpu().clone()))
+    assert c3.get("bn_eval_prep", 0) == 1 and not torch.equal(outs[2], outs[0])
+    fresh = BirdViewPolicyModelSS("resnet18", all_branch=True, **({"input_hw": hw} if small else {}))
+    fresh.precision = precision
+    fresh.load_state_dict(sd)
+    fresh = fresh.to(dev).eval()
+    with torch.no_grad():
+        want = fresh(x.to(dev), speed.to(dev), cmd.to(dev))[1].cpu()
+    assert torch.equal(outs[2], want)
+
+
 @pytest.mark.parametrize("precision", [0, 2])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 16, marks=gpu)])
 def test_staged_backward_equals_the_single_call(env, kind, backbone, h, w, n, precision, lbc_config):
