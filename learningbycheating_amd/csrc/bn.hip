@@ -272,9 +272,11 @@ __global__ __launch_bounds__(256) void bn_apply_k(BnApplyArgs a)
     if (RES && rscp) { rsc = PV::ld(rscp + c); rsh = PV::ld(rshp + c); }
     const bool relu = a.relu != 0;
     for (long long i = i0; i < total; i += stride) {
-        vec v = Act<T>::ldv(x + i * V);
+        // (x and the residual are not read again before the backward pass: nontemporal, they need not displace what the next
+        //  convolution is about to read -- measured 15.19 -> 15.12 ms per step, profiles/r04_run9_*)
+        vec v = Act<T>::cvt(__builtin_nontemporal_load(reinterpret_cast<const typename Act<T>::raw*>(x + i * V)));
         vec r = v;
-        if (RES) r = Act<T>::ldv(resid + i * V);
+        if (RES) r = Act<T>::cvt(__builtin_nontemporal_load(reinterpret_cast<const typename Act<T>::raw*>(resid + i * V)));
         v = v * sc + sh;
         if (RES) v += r * rsc + rsh;
         if (relu) {
@@ -433,7 +435,7 @@ __global__ __launch_bounds__(256, (MASK || ACCUM || FOLD) ? 1 : 8) void bn_bwd_a
     const long long dj = (stride / ovn) * cvn * V;
     for (long long i = i0; i < total; i += stride, j += dj) {
         vec g = Act<T>::ldv(gp + j);
-        const vec v = Act<T>::ldv(xx + j);
+        const vec v = Act<T>::cvt(__builtin_nontemporal_load(reinterpret_cast<const typename Act<T>::raw*>(xx + j)));     // (the pre-BatchNorm activation: dead after this pass)
         vec m = g, old = g;
         if (MASK) m = Act<T>::ldv(mask + j);
         if (ACCUM) old = Act<T>::ldv(dx + i * V);

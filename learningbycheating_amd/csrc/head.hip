@@ -774,9 +774,15 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
     if (a.act_bf16 && !no_mfma) {
         HeadArgs b = a;
         b.nslice = 1; b.wsplit = wsplit;
-        if (a.scratch && a.N < 128) {                    // fill the chip at small batch: 2..16 slices per image
-            b.nslice = (256 + a.N - 1) / a.N;
+        if (a.scratch) {
+            // about 1024 workgroups whatever the batch: with one workgroup (four waves) per image a 256-image launch left every CU
+            // with four waves streaming 0.5 MB each -- latency bound at 1.0 TB/s (122 us for 126 MB, profiles/r04_final_*); the
+            // image's 32-pixel groups are split over 2 .. 16 slices, merged in slice order by head_merge_k
+            b.nslice = (1024 + a.N - 1) / a.N;
             if (b.nslice > 16) b.nslice = 16;
+            const int cap = ((a.OH * a.OW + 31) / 32 + 3) / 4;     // at least one group per wave and slice
+            if (b.nslice > cap) b.nslice = cap;
+            if (b.nslice < 1) b.nslice = 1;
         }
         hipLaunchKernelGGL(head_fwd_mfma_k, dim3((unsigned)a.N, (unsigned)b.nslice), dim3(256), 0, s, b);
         if (b.nslice > 1) hipLaunchKernelGGL(head_merge_k, dim3((unsigned)lbc_cdiv(a.N * 20, 256)), dim3(256), 0, s, b);
