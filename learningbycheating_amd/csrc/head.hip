@@ -206,12 +206,25 @@ __global__ __launch_bounds__(256) void head_fwd_mfma_k(HeadArgs a)
 #pragma unroll
             for (int g = 0; g < 4; ++g) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[g], wl[g], acc, 0, 0, 0);
         }
+        // the group's 16 logits of this lane merged in ONE step of the online soft-argmax: maximum first, one rescale of the running
+        // sums, 16 exponentials (element by element it took two exponentials and a rescale per logit: the kernel was VALU-bound)
+        float mx = -INFINITY;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
             const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            if (p < HW && colok) {
-                SoftAcc o; o.m = acc[e] + bias; o.l = 1.f; o.sx = posx[p]; o.sy = posy[p];
-                soft_merge(st, o);
+            acc[e] = (p < HW && colok) ? acc[e] + bias : -INFINITY;
+            mx = fmaxf(mx, acc[e]);
+        }
+        if (mx != -INFINITY) {
+            const float M = fmaxf(st.m, mx);
+            const float f = __expf(st.m - M);              // (0 while nothing has been merged yet: st.m = -inf)
+            st.l *= f; st.sx *= f; st.sy *= f; st.m = M;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int p = pbase + (e & 3) + 8 * (e >> 2) + 4 * kh;
+                const int pc = p < HW ? p : HW - 1;
+                const float w = __expf(acc[e] - M);        // (exp(-inf) = 0: padding rows and columns contribute nothing)
+                st.l += w; st.sx += w * posx[pc]; st.sy += w * posy[pc];
             }
         }
     }
