@@ -333,7 +333,7 @@ int Net::weight_prep(hipStream_t s)
         if (n >= WeightPrepArgs::kMax) return false;
         WeightPrepItem& it = a.item[n++];
         it.w = w; it.wn = W(wn); it.wt = W(wt); it.A = A; it.T = T; it.B = B; it.tile_begin = tiles;
-        tiles += lbc_cdiv(A, 32) * lbc_cdiv(B, 32) * T;
+        tiles += lbc_weight_prep_tiles(A, T, B);
         return true;
     };
     bool ok = true;

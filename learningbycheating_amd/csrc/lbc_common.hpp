@@ -154,8 +154,10 @@ struct WeightPrepItem {
     void* wn;             // bf16 [A][T][B]
     void* wt;             // bf16 [B][T][A]
     int A, T, B;
-    int tile_begin;       // first 32x32 tile of this tensor in the launch
+    int tile_begin;       // first tile of this tensor in the launch (lbc_weight_prep_tiles() tiles per tensor)
 };
+// tiles (workgroups) a tensor of [A][T][B] weights takes in lbc_weight_prep: 64 x 64 (a, b) tiles per tap, zero-padded at the edges
+static inline int lbc_weight_prep_tiles(int A, int T, int B) { return lbc_cdiv(A, 64) * lbc_cdiv(B, 64) * T; }
 struct WeightPrepArgs {
     static const int kMax = 48;
     WeightPrepItem item[kMax];
