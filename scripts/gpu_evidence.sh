@@ -19,6 +19,18 @@ if [[ "$PHASES" == *bench* ]]; then
     echo "$WLD: $(tail -1 $R/bench_$WLD.log | cut -c1-220)" >> $S
   done
 fi
+if [[ "$PHASES" == *bench* && -d scratch_r03 ]]; then
+  # boxes of the pool differ by up to 10 %: the previous round's tree (git archive of its last commit, built in scratch_r03/, not tracked)
+  # on THIS box next to the shipped code, one device-resident batch re-fed every step (the one input mode both trees have)
+  pj() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['value'], 'img/s')" 2>&1 | tail -1; }
+  for B in 256 32; do
+    for rep in 1 2; do
+      (cd scratch_r03 && timeout 300 python bench.py --resident --global-batch $B --steps 40 --warmup 10 --no-cpu-baseline --no-alt 2>/dev/null | tail -1 | pj) > $R/ab_prev_b${B}_$rep.txt 2>&1
+      (timeout 300 python bench.py --resident --global-batch $B --steps 40 --warmup 10 --no-cpu-baseline --no-alt 2>/dev/null | tail -1 | pj) > $R/ab_head_b${B}_$rep.txt 2>&1
+      echo "same box, $B images, run $rep: previous round's tree $(cat $R/ab_prev_b${B}_$rep.txt) | shipped code $(cat $R/ab_head_b${B}_$rep.txt)" >> $S
+    done
+  done
+fi
 if [[ "$PHASES" == *prof* ]]; then
   rm -rf $R/prof
   (cd /tmp && LBC_NO_SIDE_STREAM=1 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$R/prof" -o lbc -- python "$OLDPWD/bench.py" --serial --steps 3 --warmup 1 --init-steps 2 --no-cpu-baseline --no-alt) > $R/prof.log 2>&1
