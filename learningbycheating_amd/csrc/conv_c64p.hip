@@ -34,23 +34,34 @@ namespace {
 // K loop while the other stores, waits for its halo or sits in a barrier -- latency hidden by occupancy instead of by a software pipeline
 // that a workgroup-wide barrier per tile keeps breaking.  The single buffer costs a second barrier per tile (everybody has left the K loop
 // before the next halo is requested); its landing is covered by the epilogue and by the other workgroup.
+// ... and then the halo of the 128 shape became a RING (this version): consecutive tiles of a workgroup overlap in 2W + 2 of their
+// BM + 2W + 2 halo rows (194 of 322 at W = 96), and the single buffer re-requested them from L2 for every tile -- 2.5x the input in
+// L2 -> LDS traffic, part of it from HBM in the launches that also stream a side tensor (PMC: 445 MB fetched per fused-BatchNorm
+// input-gradient launch against 285 MB for the 256 shape).  The halo now lives in a ring of R = 456 rows addressed by the running row
+// number g = 128 * tile + halo row (ring row = g mod R): a tile requests only its BM NEW rows, during the PREVIOUS tile's K loop (they
+// land in ring rows whose last reader was the tile before that: R >= BM + halo rows, no second barrier), lanes of a piece whose row is
+// not new are masked off, and the on-load BatchNorm transform (PRE) touches each row once instead of 2.5 times.
 template <int MODE, int EPI, bool PRE = false, int BMv = 256>
 __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
 {
     constexpr int BM = BMv, BN = 64, WM = BMv / 64, WN = 2, MT = 2;
-    constexpr int NWAVES = WM * WN, NBUF = BMv == 256 ? 2 : 1;
-    constexpr int HRMAX = BMv == 256 ? 456 : 328;               // BM + 2 W + 2 < HRMAX <=> W <= 98
-    constexpr int NP = HRMAX / 8;                               // 1-KiB halo pieces per tile (57 / 41)
+    constexpr bool RING = BMv == 128;
+    constexpr int NWAVES = WM * WN, NBUF = RING ? 1 : 2;
+    constexpr int R = 456;                                      // ring rows (RING): >= BM + halo rows = 128 + 322, a multiple of 8
+    constexpr int HRMAX = RING ? R + 1 : 456;                   // rows per buffer; RING: the ring + the zero row.  BM + 2 W + 2 < 456 - 128 resp. 456 <=> W <= 98
+    constexpr int NP = (RING ? 328 : HRMAX) / 8;                // 1-KiB halo pieces of a WHOLE halo (57 / 41: RING requests them for its first tile only)
     constexpr int PPW = (NP + NWAVES - 1) / NWAVES;             // ... per wave (8 / 11; the last wave has fewer)
+    constexpr int NPN = BM / 8 + 1, PPN = (NPN + NWAVES - 1) / NWAVES;   // RING: pieces that hold a tile's BM new rows (17: the range is not piece-aligned), per wave (5)
     constexpr int ABYTES = HRMAX * 128;
-    constexpr int ZROW = (HRMAX - 1) * 128;
-    constexpr int SROWS = 16, SROW_B = 32 * 2 + 16;             // staged rows per copy-out step, their LDS pitch (32 bf16 + 16 bytes)
+    constexpr int ZROW = RING ? R * 128 : (HRMAX - 1) * 128;
+    constexpr int SROWS = (RING && EPI != 0) ? 8 : 16, SROW_B = 32 * 2 + 16;   // staged rows per copy-out step (8 where the side tile leaves no room for 16), their LDS pitch (32 bf16 + 16 bytes)
     constexpr int STG = NBUF * ABYTES;                          // wave-private staging: NWAVES x SROWS x SROW_B
     constexpr int RED = STG + NWAVES * SROWS * SROW_B;          // [2][WM][2][BN] floats
     constexpr int GT = RED + 2 * WM * 2 * BN * 4;               // EPI 1 / 2: per wave [64 rows][32 columns] of the residual / pre-BatchNorm activation
     constexpr int SMEM = GT + (EPI != 0 ? NWAVES * 64 * 64 : 0);
     constexpr int NSTEP = 64 / SROWS;                           // copy-out steps per wave and tile = 16-byte stores per lane
-    static_assert(SMEM <= (BMv == 256 ? 160 : 80) * 1024 && PPW <= 18 && (BMv == 256 || BMv == 128), "conv_c64p: LDS / piece arithmetic");
+    static_assert(SMEM <= (BMv == 256 ? 160 : 80) * 1024 && PPW <= 18 && PPN <= 18 && (BMv == 256 || BMv == 128) && R % 8 == 0 && R >= 128 + 322,
+                  "conv_c64p: LDS / piece arithmetic");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -98,6 +109,19 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             lds_dma16(src, smem + buf * ABYTES + piece * 1024);
         }
     };
+    // RING: piece pg = rows g = 8 pg .. 8 pg + 7 of the workgroup's running row numbering (row g <-> input pixel pix0 + g), into ring
+    // slot pg mod (R / 8); only lanes whose row lies in [g_lo, g_hi) -- the rows that are NEW -- take part (LDS-DMA honours EXEC)
+    const int pix0 = first * BM - (W + 1);
+    auto issue_ring = [&](const int pg, const int g_lo, const int g_hi) {
+        const int g = 8 * pg + prow;
+        if (g >= g_lo && g < g_hi) {
+            const int q = pix0 + g;
+            const int rr = g % R;
+            const bool ok = q >= 0 && q < a.M;
+            const __bf16* src = ok ? xin + ((size_t)q * 64 + (size_t)((pseg ^ ((rr >> 1) & 7)) * 8)) : zero;
+            lds_dma16(src, smem + (pg % (R / 8)) * 1024);
+        }
+    };
     const int npw = wave * PPW + PPW <= NP ? PPW : (NP - wave * PPW > 0 ? NP - wave * PPW : 0);   // pieces this wave requests per tile
     int rowc[MT];
 #pragma unroll
@@ -114,8 +138,15 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
     const __bf16* gsrc = EPI == 1 ? static_cast<const __bf16*>(a.resid) : (EPI == 2 ? static_cast<const __bf16*>(a.bnb_y) : nullptr);
 
     // the first tile's halo
+    if constexpr (RING) {
+        if (tid < 8) *reinterpret_cast<f32x4*>(smem + ZROW + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};     // the zero row of the border select (visible behind the first barrier)
 #pragma unroll
-    for (int j = 0; j < PPW; ++j) issue_piece(first * BM, 0, j);
+        for (int j = 0; j < PPW; ++j)
+            if (wave * PPW + j < NP) issue_ring(wave * PPW + j, 0, BM + 2 * W + 2);
+    } else {
+#pragma unroll
+        for (int j = 0; j < PPW; ++j) issue_piece(first * BM, 0, j);
+    }
 
     // prof (diagnostic, LBC_C64P_PROF): per wave [0] tiles, [1] cycles waiting for the halo + opening barrier, [2] on-load transform,
     // [3] K loop, [4] epilogue, [5] whole stream
@@ -167,10 +198,13 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             const f32x8 ps8 = ParamVec<8>::ld(a.pre_scale + cg * 8), pt8 = ParamVec<8>::ld(a.pre_shift + cg * 8);
             const float floor8 = a.pre_relu ? 0.f : -INFINITY;
             const int HR = BM + 2 * W + 2;
-            for (int hr = tid >> 3; hr < HR; hr += NWAVES * 8) {
+            // (RING: only the rows this tile brought in -- the others were transformed when they arrived)
+            const int hr0 = (RING && it > 0) ? 2 * W + 2 : 0;
+            for (int hr = hr0 + (tid >> 3); hr < HR; hr += NWAVES * 8) {
                 const int q = m0 - (W + 1) + hr;
                 if (q >= 0 && q < a.M) {
-                    bf16x8* p = reinterpret_cast<bf16x8*>(smem + buf * ABYTES + hr * 128 + ((cg ^ ((hr >> 1) & 7)) << 4));
+                    const int rr = RING ? (it * BM + hr) % R : hr;
+                    bf16x8* p = reinterpret_cast<bf16x8*>(smem + buf * ABYTES + rr * 128 + ((cg ^ ((rr >> 1) & 7)) << 4));
                     f32x8 v = __builtin_convertvector(*p, f32x8) * ps8 + pt8;
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], floor8);
@@ -202,12 +236,14 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
 #pragma unroll
         for (int i = 0; i < MT; ++i) asm volatile("" : "+v"(rowc[i]));
 #endif
+        const int rbase = RING ? (it * BM) % R : 0;          // ring row of this tile's halo row 0
         auto tap_addr = [&](const int tap) {
             const int r = tap / 3, s = tap - 3 * r;
             const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
 #pragma unroll
             for (int i = 0; i < MT; ++i) {
-                const int hr = rowc[i] + off;
+                int hr = rowc[i] + off;
+                if constexpr (RING) { hr += rbase; hr = hr >= R ? hr - R : hr; }
                 const int val = (hr << 7) | ((kh ^ ((hr >> 1) & 7)) << 4), zval = ZROW | (kh << 4);
                 const int m = -((amask[i] >> tap) & 1);
                 aaddr[i] = abuf + (((val ^ zval) & m) ^ zval);
@@ -230,8 +266,16 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             // the next tile's halo, one piece every second step (all requested by step 15 of 36: in-kernel stamps, scripts/c64p_prof.py,
             // show a wave 28 % of its time in the tile's opening wait + barrier -- with the pieces requested as late as step 29 just the
             // same (profiles/r04_run6_*): that time is barrier skew between the SIMD's older and younger wave, not halo latency)
-            // (single halo buffer: requested behind the K loop instead, below)
-            if (NBUF == 2 && more && (st & 1) == 1 && (st >> 1) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 1);
+            if constexpr (RING) {
+                // the BM new rows of the next tile: g in [it BM + HR, it BM + HR + BM), the pieces that hold them
+                if (more && (st & 1) == 1 && (st >> 1) < PPN) {
+                    const int g_lo = it * BM + BM + 2 * W + 2;
+                    const int pg = (g_lo >> 3) + wave * PPN + (st >> 1);
+                    if (pg <= ((g_lo + BM - 1) >> 3)) issue_ring(pg, g_lo, g_lo + BM);
+                }
+            } else {
+                if (more && (st & 1) == 1 && (st >> 1) < PPW) issue_piece(m0 + BM, buf ^ 1, st >> 1);
+            }
             if (EPI != 0 && (st & 7) == 3 && st < 32) {
                 // this wave's 64 x 32 sub-tile of the residual / pre-BatchNorm activation, 16 rows (one DMA piece: 4 lanes per 64-byte
                 // row) at a time -> wave-private: its own vmcnt in front of the epilogue is all the synchronisation it needs
@@ -251,16 +295,6 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             // (requested at steps 3 .. 27: the youngest requests of the tile, the halo pieces are all older)
             LBC_WAIT_VM(0);
         }
-        if constexpr (NBUF == 1) {
-            // one halo buffer: the next tile's halo is requested once EVERY wave has left the K loop; it lands under this tile's
-            // epilogue (and under the CU's other workgroup).  The requests are older than the epilogue's stores, as the opening wait assumes
-            if (more) {
-                LBC_WAIT_LGKM0();
-                __builtin_amdgcn_s_barrier();
-#pragma unroll
-                for (int j = 0; j < PPW; ++j) issue_piece(m0 + BM, 0, j);
-            }
-        }
         const char* gt = smem + GT + wave * 4096 + l31 * 2;
         float s1 = 0.f, s2 = 0.f;
         // EPI 2 (fused BatchNorm-backward reduce): mask and sums in the CHUNK phase -- the staged gradient and the pre-BatchNorm activation
@@ -277,11 +311,12 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
         }
 #pragma unroll
         for (int s = 0; s < NSTEP; ++s) {
-            const int mi = s >> 1;
+            constexpr int SPB = 32 / SROWS, RPS = SROWS / 2;                         // copy-out steps per 32-row block, accumulator registers per step
+            const int mi = s / SPB;
 #pragma unroll
-            for (int r8 = 0; r8 < 8; ++r8) {
-                const int e = (s & 1) * 8 + r8;
-                const int lr = (e & 3) + 4 * kh + 8 * ((e >> 2) & 1);                 // row inside the 16-row step
+            for (int r8 = 0; r8 < RPS; ++r8) {
+                const int e = (s % SPB) * RPS + r8;
+                const int lr = (e & 3) + 4 * kh + 8 * ((e >> 2) % (SROWS / 8));      // row inside the step
                 const bool live = m0 + wm * 64 + mi * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh < a.M;
                 float v = acc[mi][e];
                 if (a.post_scale) v = v * psc + psh;
@@ -297,11 +332,14 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
                 }
             }
             __builtin_amdgcn_wave_barrier();                    // (one wave's LDS operations execute in order; this pins the compiler -- and the emulator's fibers)
-            const int m = m0 + wm * 64 + s * SROWS + crow;
-            bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + crow * SROW_B + cseg * 16);
+            // (8-row steps: the upper half of the lanes has no chunk; their row index is kept inside the staging rows)
+            const bool cact = crow < SROWS;
+            const int crw = cact ? crow : 0;
+            const int m = cact ? m0 + wm * 64 + s * SROWS + crow : a.M;
+            bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + crw * SROW_B + cseg * 16);
             if (EPI == 2) {
                 // sums of the STORED (bf16) gradient, as the separate reduce pass sees it; second sum as sum g * y, centred per tile below
-                const f32x8 yf = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(smem + GT + wave * 4096 + (s * SROWS + crow) * 64 + cseg * 16), f32x8);
+                const f32x8 yf = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(smem + GT + wave * 4096 + (s * SROWS + crw) * 64 + cseg * 16), f32x8);
                 f32x8 g = __builtin_convertvector(ch, f32x8);
                 const f32x8 z = yf * bsc8 + bsh8;
 #pragma unroll
