@@ -399,13 +399,21 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
 }  // namespace
 
 // statistics rows of a launch: one per persistent workgroup
-// tile rows of the launch: LBC_C64P_BM = 256 / 128 pins a shape; default: the four-wave 128-pixel shape (two workgroups per CU)
-static int c64p_bm() { const long long v = lbc_opt(kOptC64pBm); return v == 256 ? 256 : 128; }
+// tile rows of the launch: LBC_C64P_BM = 256 / 128 pins a shape; default: the four-wave 128-pixel ring shape (two workgroups per CU),
+// except for the fused BatchNorm-backward form: next to its side tile the ring leaves LDS for 8-row copy-out steps only, and its chunk
+// phase -- mask, sums, eight channels per lane -- then runs with half the lanes: 195 us per launch against 148 us on the 256 shape
+// (profiles/r04_final_* of the run before this policy)
+static int c64p_bm(const IgemmArgs& a)
+{
+    const long long v = lbc_opt(kOptC64pBm);
+    if (v == 256 || v == 128) return (int)v;
+    return a.bnb_y ? 256 : 128;
+}
 static int c64p_cap(int bm) { return lbc_opt(kOptHaloBlocks) > 0 ? (int)lbc_opt(kOptHaloBlocks) : (bm == 256 ? 256 : 512); }   // persistent workgroups (tests: fewer)
 
 int lbc_conv_c64p_rows(const IgemmArgs& a)
 {
-    const int bm = c64p_bm();
+    const int bm = c64p_bm(a);
     const int ntiles = lbc_cdiv(a.M, bm);
     return lbc_cdiv(ntiles, lbc_cdiv(ntiles, c64p_cap(bm)));
 }
@@ -421,7 +429,7 @@ int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
     const void* zero = nullptr;
     int rc = lbc_zero_page(&zero);
     if (rc) return rc;
-    const int bm = c64p_bm();
+    const int bm = c64p_bm(a);
     const int ntiles = lbc_cdiv(a.M, bm);
     const int tpw = lbc_cdiv(ntiles, c64p_cap(bm));
     const dim3 grid((unsigned)lbc_cdiv(ntiles, tpw));
