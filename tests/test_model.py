@@ -692,10 +692,11 @@ def _launch_counts(fn):
     return {ln.split()[0]: int(ln.split()[1]) for ln in buf.raw[:nbytes].decode().strip().splitlines()}
 
 
-@pytest.mark.parametrize("precision", [0, 2])
-@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), ("birdview", "resnet18", 64, 64, 3),
-                                                 pytest.param("image", "resnet34", 160, 384, 32, marks=gpu),
-                                                 pytest.param("image", "resnet34", 160, 384, 16, marks=gpu)])
+@pytest.mark.parametrize("kind,backbone,h,w,n,precision", [("image", "resnet18", 64, 128, 4, 2), ("birdview", "resnet18", 64, 64, 3, 0),
+                                                           pytest.param("image", "resnet34", 160, 384, 32, 0, marks=gpu),
+                                                           pytest.param("image", "resnet34", 160, 384, 32, 2, marks=gpu),
+                                                           pytest.param("image", "resnet34", 160, 384, 16, 0, marks=gpu),
+                                                           pytest.param("image", "resnet34", 160, 384, 16, 2, marks=gpu)])
 def test_batchnorm_finalize_folded_into_its_consumer(env, kind, backbone, h, w, n, precision, lbc_config):
     """small per-GPU batches: where a BatchNorm's partial rows are few, the elementwise pass that consumes its coefficients does
     the finalize itself (BnApplyArgs::fold / BnBwdApplyArgs::fold; reference arithmetic resnet.py:38-54 forward and autograd).

@@ -537,12 +537,10 @@ def test_bf16_gradient_buckets_cost_less_than_the_bf16_arithmetic_gloo_world2():
 
 def test_bf16_wire_sum_of_eight_shards_emulated():
     """the 8-GPU line of the scaling run, emulated in one process: eight shard gradients (2 images each, loss scaled by 1 / 16) summed
-    (a) in f32, (b) as a bf16 ring would -- every shard rounded to bf16 and the running sum rounded to bf16 after every addition
-    (the worst ordering of a ring reduce-scatter) -- and (c) in f32 from the bf16 executor.  Per tensor the wire error stays within
-    8 roundings of 2^-9 of the largest entry and, in the median, below a quarter of the arithmetic's own error (at these test
-    sizes -- 1 x 2 maps in layer 4, untrained weights -- the bf16 executor's gradients are far off, see tests/test_model.py; the
-    full-size figure is the k-step bf16 line in profiles/); one Adam step from either sum moves the parameters identically except
-    where an entry is at the rounding level of its tensor."""
+    (a) in f32 and (b) as a bf16 ring would -- every shard rounded to bf16 and the running sum rounded to bf16 after every addition
+    (the worst ordering of a ring reduce-scatter).  Per tensor the wire error stays within 8 roundings of 2^-9 of the largest entry
+    (median < 1e-2: an order of magnitude below what the bf16 arithmetic of the mode costs at the reference's size); one Adam step
+    from either sum moves the parameters identically except where an entry is at the rounding level of its tensor."""
     import ctypes
     from tests import emu
     emu.activate()
@@ -556,7 +554,7 @@ def test_bf16_wire_sum_of_eight_shards_emulated():
         sd = O.make_state_dict("image", "resnet18", 46, 32, 64)
         cam, lib = camera_struct(), _lib.get()
         sums = {}
-        for prec in (0, 2):
+        for prec in (0,):
             eng, _ = engine_from_state_dict(sd, "image", "resnet18", 32, 64, n, torch.device("cpu"), precision=prec)
             f32 = torch.zeros_like(eng.grad_flat)
             wire = torch.zeros_like(eng.grad_flat).bfloat16()
@@ -570,20 +568,19 @@ def test_bf16_wire_sum_of_eight_shards_emulated():
                 wire = (wire.float() + eng.grad_flat.bfloat16().float()).bfloat16()
             sums[prec] = (f32, wire.float(), dict(eng.grad_offsets))
         exact, wire, offs = sums[0]
-        arith = sums[2][0]
-        e_wire, e_arith = [], []
+        e_wire = []
         for name, (off, cnt) in offs.items():
             if name.startswith("location_pred") and name.endswith("bias"):
                 continue                     # analytically zero gradients (softmax shift invariance): round-off only
             ref = exact[off:off + cnt]
             scale = float(ref.abs().max()) + 1e-30
             e_wire.append(float((wire[off:off + cnt] - ref).abs().max()) / scale)
-            e_arith.append(float((arith[off:off + cnt] - ref).abs().max()) / scale)
             assert e_wire[-1] <= 8 * 2.0 ** -9 + 2.0 ** -9, (name, e_wire[-1])
         med = lambda z: sorted(z)[len(z) // 2]
-        print("bf16 wire sum of 8 shards: per-tensor error rel-to-max median %.2e max %.2e; bf16 executor's own: median %.2e max %.2e"
-              % (med(e_wire), max(e_wire), med(e_arith), max(e_arith)))
-        assert med(e_wire) <= 0.25 * med(e_arith), (med(e_wire), med(e_arith))
+        print("bf16 wire sum of 8 shards: per-tensor error rel-to-max median %.2e max %.2e" % (med(e_wire), max(e_wire)))
+        # (the bf16 ARITHMETIC of the same mode is 2-6e-2 off per tensor at the reference's size, tests/test_model.py
+        #  test_bf16_gradients_with_frozen_decisions_full_size: an order of magnitude above this)
+        assert med(e_wire) <= 1e-2, med(e_wire)
         # one Adam step from zero moments: p -= lr g / (|g| + eps'): identical unless |g| is at the rounding level of the sum
         lr, eps = 1e-4, 1e-8
         upd = lambda g: lr * g / (g.abs() + eps)

@@ -68,7 +68,7 @@ def _k_steps(dev, phase, small, k, n, grad_tol, head_tol, side_stream=True, lbc_
         tgt[..., 0] = tgt[..., 0] * 1.2 - 0.6
         tgt[..., 1] = tgt[..., 1] * 0.5 + 0.3
         warm = NativeTrainer(student, None, n, (3, sh, sw), dev, phase="l1_all", lr=1e-3)
-        for _ in range(4 if small else 30):
+        for _ in range(3 if small else 30):
             warm.step(x.to(dev), speed.to(dev), onehot.to(dev), target=tgt.to(dev))
         del warm
     tr = NativeTrainer(student, teacher, n, ((7 if skind == "birdview" else 3), sh, sw), dev, phase=phase, lr=LR, teacher_shape=(7, th, tw))
