@@ -755,7 +755,7 @@ def test_batchnorm_finalize_folded_into_its_consumer(env, kind, backbone, h, w, 
         assert rel[-1] < 5e-2 and rel[len(rel) // 2] < 1.5e-2, (rel[-1], rel[len(rel) // 2])
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["bf16"])
 def test_frozen_teacher_derives_its_weight_copies_once(env, precision):
     """lbc_net_set_frozen (NativeTrainer sets it on the privileged teacher, train_image_phase1.py:244-248): the second eval-mode
     forward launches neither weight_prep nor bn_eval_prep and returns the same bits; load_state_dict derives everything again"""
