@@ -39,6 +39,11 @@ typedef struct lbc_conv_desc {
                            the same (depth-contiguous) layout; weight gradients are still produced in f32 */
     int w_transposed;   /* lbc_conv2d_dgrad / lbc_deconv3x3s2_fwd only: `w` is the lbc_weight_transpose()d copy (depth-
                            contiguous for these GEMMs).  Required when bf16 = 1. */
+    void* split_workspace;          /* optional (NULL = none): device scratch that lets lbc_conv2d_fwd / lbc_conv2d_dgrad launches with */
+    size_t split_workspace_bytes;   /* few output tiles (3x3 / stride 1, bf16 = 3, small N*H*W) cut the channel contraction into ranges:
+                                       f32 partial tiles here, summed in a fixed order by a second launch that does the epilogue.  A
+                                       launch uses at most 8 * N*OH*OW*K * 4 bytes and ignores a scratch that is too small.  Results
+                                       differ from the unsplit launch by f32 summation order only. */
 } lbc_conv_desc;
 
 /* nn.Conv2d forward (reference bird_view/models/resnet.py:15-22,102; image.py:57).

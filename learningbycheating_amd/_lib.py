@@ -15,7 +15,8 @@ c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ct
 
 
 class ConvDesc(ctypes.Structure):
-    _fields_ = [(n, c_int) for n in ("N", "H", "W", "C", "K", "KH", "KW", "S", "P", "relu", "bf16", "w_transposed")]
+    _fields_ = ([(n, c_int) for n in ("N", "H", "W", "C", "K", "KH", "KW", "S", "P", "relu", "bf16", "w_transposed")] +
+                [("split_workspace", c_void_p), ("split_workspace_bytes", c_size_t)])
 
 
 class NetDesc(ctypes.Structure):

@@ -23,6 +23,7 @@ static IgemmArgs conv_args(const lbc_conv_desc* d)
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;
     a.relu = d->relu;
     a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 >= 2; a.w_bf16 = d->bf16 == 3;
+    a.split_ws = static_cast<float*>(d->split_workspace); a.split_ws_floats = (long long)(d->split_workspace_bytes / 4);
     return a;
 }
 
@@ -56,6 +57,7 @@ static int conv_dgrad_impl(const lbc_conv_desc* d, const void* dy, const void* w
     memset(&a, 0, sizeof(a));
     a.x = dy; a.w = w; a.y = dx; a.resid = resid; a.bias = bias; a.relu = relu; a.bf16 = d->bf16 != 0; a.act_bf16 = d->bf16 >= 2; a.w_bf16 = d->bf16 == 3;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
+    a.split_ws = static_cast<float*>(d->split_workspace); a.split_ws_floats = (long long)(d->split_workspace_bytes / 4);
     a.N = d->N; a.H = OH; a.W = OW; a.C = d->K;
     a.OH = d->H; a.OW = d->W; a.K = d->C;
     a.KH = d->KH; a.KW = d->KW; a.S = d->S; a.P = d->P;

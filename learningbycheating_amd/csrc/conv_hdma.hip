@@ -397,6 +397,7 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
         return kLbcCfgHdma + 3;
     }
     int best = -1;
+    long long best_tiles = 0;
     double best_score = 0.0;
     for (int i = 0; i < 3; ++i) {
         const HdmaCfg& c = kHdmaCfg[i];
@@ -407,9 +408,12 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
         const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn);
         if (tiles < fill) continue;
         const double score = (double)tiles / (double)(((tiles + 255) / 256) * 256) * (c.bm * c.bn >= 256 * 256 ? 1.0 : 0.9);
-        if (score > best_score) { best_score = score; best = i; }
+        if (score > best_score) { best_score = score; best = i; best_tiles = tiles; }
     }
-    if (best >= 0) return kLbcCfgHdma + best;
+    // (A/B: an eight-wave launch that leaves most CUs idle -- layer 2 at 32 images is 120 tiles -- as four-wave tiles, two workgroups per CU)
+    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < lbc_opt(kOptHdmaSmallBelow) && a.K % 64 == 0 &&
+                              lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4);
+    if (best >= 0 && !prefer_small) return kLbcCfgHdma + best;
     // Few rows (the per-GPU load of the 8-GPU run: layer 3 / 4 at 32 images have 7680 / 1920 output pixels): 128 x 64 tiles, four waves,
     // two workgroups per CU (conv_hdmap.hpp) instead of the 64 x 64 register-staged tiles of conv_igemm.hip (31 us per 9-GFLOP launch)
     if ((forced < 0 || forced == 4) && !a.pre_scale && a.K % 64 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4)) {

@@ -1,11 +1,113 @@
 // Launch policy of the persistent halo-staged convolution (kernel: conv_hdmap.hpp; one translation unit per tile shape so that
 // the 15 instantiations compile in parallel).
 #include "lbc_common.hpp"
+#include "lbc_act.hpp"
 
 int lbc_conv_hdmap_launch_256x128_320(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_256x128_384(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_128x256_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
-int lbc_conv_hdmap_launch_128x64_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
+int lbc_conv_hdmap_launch_128x64_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s, int nsplit);
+
+namespace {
+
+// Second launch of a split-K convolution (conv_hdmap_k<.., EPI 3> left f32 partial tiles [range][M][K] in IgemmArgs::split_ws): sums
+// the ranges in the order 0 .. nsplit - 1 and does what the unsplit kernel's epilogue does with its accumulators -- affine, bias, residual add, ReLU,
+// the bf16 store, and per 128-row block (the unsplit launch's tile rows: the same number of partial rows) either the (sum, sum of
+// squares) of the f32 value or, FUSED, the BatchNorm-backward sums of the stored (rounded, masked) gradient (IgemmArgs::bnb_*).
+// One workgroup per (128 rows, 64 columns): thread = (row group of 32, 8-column segment), four rows each.
+template <bool FUSED>
+__global__ __launch_bounds__(256) void conv_split_epilogue_k(IgemmArgs a, const int nsplit)
+{
+    __shared__ float red[2][32][64];
+    const int tid = threadIdx.x, rg = tid >> 3, seg = tid & 7;
+    const int mt = blockIdx.x, n0 = blockIdx.y * 64, col = n0 + seg * 8;
+    const size_t plane = (size_t)a.M * (size_t)a.K;
+    __bf16* y = static_cast<__bf16*>(a.y);
+    const __bf16* resid = static_cast<const __bf16*>(a.resid);
+    const __bf16* by = static_cast<const __bf16*>(a.bnb_y);
+    size_t o[4];
+    bool live[4];
+    f32x8 v[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int m = mt * 128 + rg + 32 * q;
+        live[q] = m < a.M;
+        o[q] = (size_t)(live[q] ? m : 0) * (size_t)a.K + (size_t)col;
+        v[q] = ParamVec<8>::ld(a.split_ws + o[q]);
+    }
+    for (int r = 1; r < nsplit; ++r)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += ParamVec<8>::ld(a.split_ws + (size_t)r * plane + o[q]);
+    f32x8 u1 = ParamVec<8>::splat(0.f), u2 = u1;
+    f32x8 bsc = u1, bsh = u1, bmu = u1, biv = u1;
+    if constexpr (FUSED) {
+        bsc = ParamVec<8>::ld(a.bnb_scale + col); bsh = ParamVec<8>::ld(a.bnb_shift + col);
+        bmu = ParamVec<8>::ld(a.bnb_mean + col); biv = ParamVec<8>::ld(a.bnb_invstd + col);
+    }
+    const f32x8 psc = a.post_scale ? ParamVec<8>::ld(a.post_scale + col) : ParamVec<8>::splat(1.f);
+    const f32x8 psh = a.post_scale ? ParamVec<8>::ld(a.post_shift + col) : ParamVec<8>::splat(0.f);
+    const f32x8 bia = a.bias ? ParamVec<8>::ld(a.bias + col) : ParamVec<8>::splat(0.f);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        f32x8 t = v[q];
+        if (a.post_scale) t = t * psc + psh;
+        if (a.bias) t += bia;
+        if (resid) t += __builtin_convertvector(*reinterpret_cast<const bf16x8*>(resid + o[q]), f32x8);
+        if (a.relu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] = fmaxf(t[e], 0.f);
+        }
+        bf16x8 ch = __builtin_convertvector(t, bf16x8);
+        if constexpr (FUSED) {
+            const f32x8 yf = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(by + o[q]), f32x8);
+            f32x8 g = __builtin_convertvector(ch, f32x8);
+            const f32x8 z = yf * bsc + bsh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
+            ch = __builtin_convertvector(g, bf16x8);
+            if (live[q]) { u1 += g; u2 += g * (yf - bmu) * biv; }
+        } else if (live[q]) {
+            u1 += t; u2 += t * t;
+        }
+        if (live[q]) *reinterpret_cast<bf16x8*>(y + o[q]) = ch;
+    }
+    if (a.stats) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { red[0][rg][seg * 8 + e] = u1[e]; red[1][rg][seg * 8 + e] = u2[e]; }
+        __syncthreads();
+        if (tid < 128) {
+            const int which = tid >> 6, c = tid & 63;
+            float sum = 0.f;
+#pragma unroll
+            for (int r = 0; r < 32; ++r) sum += red[which][r][c];
+            a.stats[(size_t)(a.stat_row0 + mt) * 2 * (size_t)a.K + (size_t)which * (size_t)a.K + (size_t)(n0 + c)] = sum;
+        }
+    }
+}
+
+}  // namespace
+
+// Split-K ranges of a launch of the four-wave 128 x 64 shape (1 = none).  Launches with few tiles leave CUs idle AND run one wave per
+// SIMD where they run (nothing hides a wave's LDS / DMA latencies): layer 4 at 32 images is 120 tiles of 72 K-tiles each.  With the
+// gathered channels cut into ranges the launch has tiles x ranges workgroups of 1 / ranges the K-tiles, and a second, elementwise
+// launch (conv_split_epilogue_k).  Needs the caller's scratch (IgemmArgs::split_ws).
+int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
+{
+    (void)mode;
+    if (cfg != kLbcCfgHdma + 4 || !a.split_ws || a.pre_scale) return 1;
+    const long long opt = lbc_opt(kOptHdmapSplit);
+    if (opt == 0) return 1;
+    const int nslab = a.C / 64;
+    const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64), elems = (long long)a.M * a.K;
+    auto fits = [&](long long n) { return n > 1 && nslab % n == 0 && elems * n <= a.split_ws_floats && elems * n < (1ll << 31); };
+    if (opt > 1) return fits(opt) ? (int)opt : 1;
+    const long long max_tiles = lbc_opt(kOptHdmapSplitMaxTiles) > 0 ? lbc_opt(kOptHdmapSplitMaxTiles) : 256;
+    if (tiles > max_tiles) return 1;
+    // as many ranges as two workgroups per CU take in one round, two slabs (18 K-tiles) or more each
+    for (long long n = 8; n > 1; n >>= 1)
+        if (fits(n) && tiles * n <= 512 && nslab / n >= 2) return (int)n;
+    return 1;
+}
 
 // Persistent form of conv_hdma.hip's cfg 1 (256 x 128) and cfg 2 (128 x 256); false = the launch keeps conv_hdma_k
 // (BatchNorm-on-load, the 256 x 256 test shape, LBC_NO_HDMA_PERSIST=1).
@@ -31,12 +133,21 @@ int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const int ntiles = lbc_cdiv(a.M, bm) * (a.K / bn);
     // one workgroup per CU (LDS; two for the four-wave shape); tiles per workgroup so that a grid of <= `cap` workgroups covers the launch
     const int cap = lbc_opt(kOptHdmaPersistWgs) > 0 ? (int)lbc_opt(kOptHdmaPersistWgs) : (cfg == kLbcCfgHdma + 4 ? 512 : 256);
+    const int nsplit = lbc_conv_hdmap_nsplit(a, mode, cfg);
+    if (nsplit > 1) {
+        rc = lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, 1, (unsigned)(ntiles * nsplit), s, nsplit);
+        if (rc) return rc;
+        const dim3 eg((unsigned)lbc_cdiv(a.M, 128), (unsigned)(a.K / 64));
+        if (a.bnb_y) hipLaunchKernelGGL(conv_split_epilogue_k<true>, eg, dim3(256), 0, s, a, nsplit);
+        else hipLaunchKernelGGL(conv_split_epilogue_k<false>, eg, dim3(256), 0, s, a, nsplit);
+        return lbc_check_launch("conv_split_epilogue");
+    }
     const int tpw = lbc_cdiv(ntiles, cap);
     const unsigned grid = (unsigned)lbc_cdiv(ntiles, tpw);
     if (cfg == kLbcCfgHdma + 1) {
         if (256 + 2 * a.W + 2 <= 320 - 8) return lbc_conv_hdmap_launch_256x128_320(a, mode, zero, ntiles, tpw, grid, s);   // W <= 30: layers 3 / 4
         return lbc_conv_hdmap_launch_256x128_384(a, mode, zero, ntiles, tpw, grid, s);
     }
-    if (cfg == kLbcCfgHdma + 4) return lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, tpw, grid, s);
+    if (cfg == kLbcCfgHdma + 4) return lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, tpw, grid, s, 1);
     return lbc_conv_hdmap_launch_128x256_192(a, mode, zero, ntiles, tpw, grid, s);
 }

@@ -38,11 +38,15 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p)
 
 // EPI: 0 = plain epilogue (affine / bias / ReLU / statistics), 1 = + residual, 2 = fused BatchNorm-backward reduce (IgemmArgs::bnb_*).
 // One instantiation per form: the residual prefetch (64 registers) and the BatchNorm-backward operands (64) never coexist.
+// EPI 3 = split-K (round 4; launches with few tiles, i.e. the deep layers at the per-GPU batches of the 8-GPU run): workgroup p serves
+// (tile p / nsplit, slab range p % nsplit), contracts C / nsplit of the gathered channels and leaves its accumulators as an f32 partial
+// tile in IgemmArgs::split_ws [range][M][K]; conv_split_epilogue_k (conv_hdmap.hip) sums the ranges in a fixed order and does the
+// epilogue of form 0 / 1 / 2.  One tile per workgroup (the launcher guarantees ntiles * nsplit workgroups).
 // PROF (diagnostic builds, LBC_HDMAP_PROF = device address of 8 x u64 per wave): s_memtime stamps around the waits of every K-tile;
 // per wave: [0] K-tiles, [1] cycles in the three leading depth steps, [2] in the vmcnt wait, [3] in lgkmcnt(0) + barrier, [4] in the
 // tail (step-0 reads of the next K-tile, last depth step, DMA issue), [5] in epilogues, [6] whole stream, [7] tiles
 template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, bool PROF = false, int VAR = 0>
-__global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
+__global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof, const int nsplit)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -83,21 +87,28 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
     const int l31 = lane & 31, kh = lane >> 5;
     const int W = a.W, H = a.H, C = a.C;
     const int ntn = a.K / BN;
-    const int nslab = C / 64;
+    const int nslab = EPI == 3 ? C / 64 / nsplit : C / 64;     // slabs (64 gathered channels) this workgroup contracts
 
     // this workgroup's tiles: [first, first + cnt), consecutive ids share the M-tile
-    int first, cnt;
+    int first, cnt, split = 0;
     {
         const int nwg = gridDim.x, b = blockIdx.x;
         const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
         const int p = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
-        first = p * tpw;
-        cnt = ntiles - first < tpw ? ntiles - first : tpw;
+        if constexpr (EPI == 3) {
+            first = p / nsplit;
+            split = p - first * nsplit;
+            cnt = first < ntiles ? 1 : 0;
+        } else {
+            first = p * tpw;
+            cnt = ntiles - first < tpw ? ntiles - first : tpw;
+        }
     }
     if (cnt <= 0) return;
 
-    const __bf16* xin = static_cast<const __bf16*>(a.x);
-    const __bf16* win = static_cast<const __bf16*>(a.w);
+    // (split-K: the range's first slab is folded into the operand bases -- 128 bytes per slab in a pixel's row and in a weight row)
+    const __bf16* xin = static_cast<const __bf16*>(a.x) + (EPI == 3 ? split * nslab * 64 : 0);
+    const __bf16* win = static_cast<const __bf16*>(a.w) + (EPI == 3 ? split * nslab * 64 : 0);
     const int prow = lane >> 3, pseg = lane & 7;
 
     // ---- DMA roles: per-thread constants + a wave-uniform origin per piece (the issue slots sit next to MFMAs that leave room
@@ -382,7 +393,21 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
 
         // ---- wave-private epilogue: affine / bias / residual / ReLU on the accumulators, 16 rows at a time through this wave's own
         //      staging rows, 16-byte stores; statistics (or the fused BatchNorm-backward sums) per tile
-        {
+        if constexpr (EPI == 3) {
+            // split-K: the accumulators as they are, f32, into this range's partial tile (a 32-lane half-wave writes 128 contiguous bytes)
+            float* part = a.split_ws + (size_t)split * (size_t)a.M * (size_t)a.K;
+            const int colw = n0 + wn * WTN;
+#pragma unroll
+            for (int mi = 0; mi < MT; ++mi)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                    if (m < a.M) {
+#pragma unroll
+                        for (int nj = 0; nj < NT; ++nj) part[(unsigned)m * (unsigned)a.K + (unsigned)(colw + nj * 32 + l31)] = acc[mi][nj][r];
+                    }
+                }
+        } else {
             char* stg = smem + STG + wave * (SROWS * SROW_B);
             float* red = reinterpret_cast<float*>(smem + RED);
             __bf16* yout = static_cast<__bf16*>(a.y);
@@ -537,20 +562,31 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
 
 // launches the instantiation for (mode, epilogue form) of one tile shape
 template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
-int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, dim3 grid, hipStream_t s)
+int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, dim3 grid, hipStream_t s, int nsplit = 1)
 {
+    if (nsplit > 1) {
+        // split-K (EPI 3): one tile per workgroup, grid = ntiles * nsplit; the epilogue is the caller's second launch
+        if constexpr (BM == 128 && BN == 64) {
+            LBC_REQUIRE(a.split_ws && tpw == 1 && grid.x == (unsigned)(ntiles * nsplit) && (a.C / 64) % nsplit == 0, "conv_hdmap: bad split-K launch");
+            if (mode == 0) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 3, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, nsplit);
+            else hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 1, 3, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, nsplit);
+            return lbc_check_launch("conv_hdmap(split)");
+        } else {
+            LBC_REQUIRE(false, "conv_hdmap: split-K exists for the 128 x 64 shape only");
+        }
+    }
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
     // A/B variants (plain forward only); 16 = the shipped schedule with compiler-managed fragment reads instead of the asm ones
     const long long var = lbc_opt(kOptHdmapVar) > 0 ? lbc_opt(kOptHdmapVar) : 0;
     unsigned long long* prof = lbc_opt(kOptHdmapProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptHdmapProf)) : nullptr;
     if ((prof || var) && mode == 0 && epi == 0) {
-#define LBC_HV(PROFv, VARv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, PROFv, VARv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, prof)
+#define LBC_HV(PROFv, VARv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, PROFv, VARv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, prof, 1)
         if (prof) { if (var == 16) LBC_HV(true, 0); else if (var == 2) LBC_HV(true, 2); else if (var == 4) LBC_HV(true, 4); else LBC_HV(true, 8); }
         else      { if (var == 16) LBC_HV(false, 0); else if (var == 1) LBC_HV(false, 1); else if (var == 2) LBC_HV(false, 2); else if (var == 4) LBC_HV(false, 4); else LBC_HV(false, 8); }
 #undef LBC_HV
         return lbc_check_launch("conv_hdmap");
     }
-#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr)
+#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, 1)
     if (mode == 0) {
         LBC_REQUIRE(epi != 2, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
         if (epi == 1) LBC_HP(0, 1); else LBC_HP(0, 0);

@@ -566,7 +566,9 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
     const double in_elems = (double)a.N * a.H * a.W * a.C * ((mode == 1 && a.S == 2) ? nph / 4.0 : 1.0);
     // profile class = kernel family + GEMM orientation
     const bool halo = cfg < kLbcCfgGlds && wmajor && lbc_conv3x3_halo_eligible(a, mode);
-    const char* pname = cfg >= kLbcCfgHdma ? (mode == 0 ? "conv_hdma_gather" : "conv_hdma_transposed")
+    const bool ksplit = cfg >= kLbcCfgHdma && lbc_conv_hdmap_nsplit(a, mode, cfg) > 1;     // two launches (partial tiles, epilogue) in one bracket
+    const char* pname = ksplit ? (mode == 0 ? "conv_hdma_gather_split" : "conv_hdma_transposed_split")
+                        : cfg >= kLbcCfgHdma ? (mode == 0 ? "conv_hdma_gather" : "conv_hdma_transposed")
                         : cfg >= kLbcCfgGlds ? (mode == 0 ? "conv_glds_gather" : "conv_glds_transposed")
                         : halo ? (mode == 0 ? "conv_halo_gather" : "conv_halo_transposed")
                                : (mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed");

@@ -305,10 +305,21 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     a.M = N * c.OH * c.OW; a.LH = c.OH; a.LW = c.OW; a.ostep = 1;
     a.bf16 = bf16_; a.act_bf16 = act_bf16_;
     if (act_bf16_) { a.w = W(c.wn); a.w_bf16 = 1; }
+    split_scratch(a);
     const int cfg = lbc_igemm_pick_for(a, 0);
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? (stats_buf ? stats_buf : W(partial_)) : nullptr;
     return lbc_igemm_launch(a, 1, 0, cfg, s);
+}
+
+// Split-K scratch of a convolution launch (IgemmArgs::split_ws): the weight gradients' slab arena.  Its other users are the weight-gradient
+// launches; with the deferred grouped weight gradients (the bf16 mode's default) they sit on the same stream as every forward / input-gradient
+// launch, so the arena is free whenever one of those runs.  With a side stream for the weight gradients it is not: no split there.
+void Net::split_scratch(IgemmArgs& a) const
+{
+    if (!defer_wgrad_ || side_on_ || !wg_floats_) return;
+    a.split_ws = W(wg_partial_);
+    a.split_ws_floats = (long long)wg_floats_;
 }
 
 // would a training forward of this convolution at batch N take conv_glds.hip when its input needs no transform on load?
@@ -805,6 +816,7 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
     if (c.s == 1) {
         a.LH = c.H; a.LW = c.W; a.ostep = 1;
         a.M = N * c.H * c.W;
+        split_scratch(a);
         const int cfg = wmajor ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K);
         if (bnb && bnb_y && fused_rows && lbc_igemm_fuses_bn_bwd(a, wmajor, 1, cfg)) {
             a.bnb_y = bnb_y; a.bnb_scale = W(bnb->scale); a.bnb_shift = W(bnb->shift);

@@ -148,6 +148,7 @@ private:
     int fork(hipStream_t s);
     int join(hipStream_t s);
     hipStream_t wstream(hipStream_t s) const { return side_on_ ? side_ : s; }
+    void split_scratch(IgemmArgs& a) const;
     hipStream_t side_ = nullptr;
     hipEvent_t ev_fork_ = nullptr, ev_join_ = nullptr;
     bool side_allowed_ = true, side_on_ = false, side_dirty_ = false;

@@ -77,6 +77,9 @@ enum LbcOpt {
     kOptC64pProf,          // LBC_C64P_PROF: device address of a u64[grid][8 waves][8] buffer -> conv_c64p_k stamps s_memtime around its phases (diagnostic, scripts/c64p_prof.py)
     kOptHeadNoSplit,       // LBC_HEAD_NO_SPLIT: 1 = the MFMA head multiplies with ONE bf16 copy of its folded weights (round 3's form; A/B) instead of the high + low pair
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
+    kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs, unset = policy (lbc_conv_hdmap_nsplit)
+    kOptHdmapSplitMaxTiles, // LBC_HDMAP_SPLIT_MAX_TILES: the policy splits launches of at most this many tiles (default 256)
+    kOptHdmaSmallBelow,    // LBC_HDMA_SMALL_BELOW: launches whose best eight-wave shape has fewer tiles than this take the four-wave 128 x 64 shape instead (default 0: never; A/B)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
@@ -143,6 +146,10 @@ struct IgemmArgs {
     const float* bnb_shift;
     const float* bnb_mean;
     const float* bnb_invstd;
+    // Split-K scratch (nullable): launches with few output tiles may cut the gathered channels into ranges, one workgroup per (tile,
+    // range), f32 partial tiles [range][M][K] here and a second launch that sums them and does the epilogue (conv_hdmap.hip).
+    float* split_ws;
+    long long split_ws_floats;
 };
 // true when the kernel a (cfg, wmajor, mode) launch takes implements IgemmArgs::bnb_*
 bool lbc_igemm_fuses_bn_bwd(const IgemmArgs& a, int wmajor, int mode, int cfg);
@@ -181,6 +188,7 @@ int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s);     // co
 int lbc_conv_c64p_rows(const IgemmArgs& a);                                  // statistics rows it writes: one per persistent workgroup
 bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg);       // conv_hdmap.hip: persistent form of cfg 1 / 2
 int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
+int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg);          // split-K ranges of that launch (1 = none)
 int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64} or -1
 int lbc_conv_glds_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);

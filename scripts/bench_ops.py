@@ -25,7 +25,7 @@ LAYERS = [  # name, H, W, C, K, k, s, p     (input geometry; 160x384 RGB network
 DECONVS = [("dec0", 5, 12, 640, 256), ("dec1", 10, 24, 256, 128), ("dec2", 20, 48, 128, 64)]
 
 
-def timeit(fn, iters=10):
+def timeit(fn, iters=int(os.environ.get("BENCH_OPS_ITERS", "10"))):
     fn(); fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -64,6 +64,10 @@ def main():
             ps, pt = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev)
             d = _lib.ConvDesc(N, H, W, C, K, k, k, s, p, 0, mode, 0)
             dT = _lib.ConvDesc(N, H, W, C, K, k, k, s, p, 0, mode, 1)
+            if os.environ.get("BENCH_OPS_SPLIT_WS"):     # split-K scratch (lbc_conv_desc.split_workspace): what the executor hands its launches
+                sws = torch.empty(8 * N * H * W * max(C, K), device=dev)
+                for dd in (d, dT):
+                    dd.split_workspace, dd.split_workspace_bytes = P(sws), sws.numel() * 4
             st = _lib.stream_for(x)
             _lib.check(lib.lbc_weight_transpose_f32(P(w), P(wt), K, k * k, C, st))
             ws = torch.empty(lib.lbc_conv2d_wgrad_workspace(ctypes.byref(d)) // 4 + 1, device=dev)

@@ -35,12 +35,17 @@ def check_guard(buf, n):
 
 
 class Conv:
-    def __init__(self, device):
+    def __init__(self, device, split_floats=0):
+        """split_floats > 0: every descriptor carries a split-K scratch of that many floats (lbc_conv_desc.split_workspace)"""
         self.dev = device
         self.lib = _lib.get()
+        self.split_ws = torch.full((split_floats,), float("nan"), device=device) if split_floats else None
 
     def desc(self, N, H, W, C, K, k, s, p, relu=0, bf16=0, wt=0):
-        return _lib.ConvDesc(N, H, W, C, K, k, k, s, p, relu, bf16, wt)
+        d = _lib.ConvDesc(N, H, W, C, K, k, k, s, p, relu, bf16, wt)
+        if self.split_ws is not None:
+            d.split_workspace, d.split_workspace_bytes = _lib.ptr(self.split_ws), self.split_ws.numel() * 4
+        return d
 
     def transpose(self, w3, A, T, B):
         """w3: device tensor [A][T][B] -> [B][T][A] through the library"""

@@ -492,10 +492,12 @@ def early_reads_checked(dev):
 HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256, 4: 128}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves)
 HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
               (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2), (3, 10, 24, 128, 128, 4), (2, 5, 12, 192, 256, 4), (1, 9, 27, 64, 192, 4),
+              (2, 6, 12, 512, 128, 4),
               (2, 9, 17, 64, 64, 3), (5, 12, 40, 64, 64, 3), (1, 7, 96, 64, 64, 3)]       # the last three: several tiles per persistent workgroup needs LBC_HALO_BLOCKS-like forcing on the GPU only
 HDMA_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, -1), (64, 10, 24, 256, 256, -1), (256, 5, 12, 512, 512, -1),
                                                    (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 0),
-                                                   (32, 40, 96, 64, 64, -1), (40, 48, 48, 64, 64, -1)]]
+                                                   (32, 40, 96, 64, 64, -1), (40, 48, 48, 64, 64, -1),
+                                                   (32, 5, 12, 512, 512, 4), (32, 10, 24, 256, 256, 4)]]      # (the last two: layer 4 / 3 at 32 images, split-K)
 
 
 @pytest.mark.parametrize("case", HDMA_SMALL + HDMA_REAL)
@@ -599,6 +601,27 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
                 assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True), dx), (opt, val)
             lbc_config(opt, -1)
             lbc_config("LBC_HDMA_PERSIST_WGS", -1)
+    # Split-K of the four-wave shape (lbc_conv_desc.split_workspace; the deep layers at the per-GPU batches of the 8-GPU run): every range
+    # count that divides the channel slabs, against the reference and against the unsplit launch -- same products, the f32 sums
+    # regrouped (per range, then over the ranges): outputs within one bf16 rounding, statistics rows (same row count) within f32 noise
+    if cfgid == 4:
+        for ns in [n for n in (2, 3, 4, 8) if (C // 64) % n == 0]:
+            lbc_config("LBC_HDMAP_SPLIT", ns)
+            cs = Conv(dev, split_floats=ns * M * max(C, K))
+            ys, sts = cs.fwd(x, w, 1, 1, stats=True, bf16=3)
+            assert torch.isfinite(cs.split_ws[:ns * M * K]).all() and torch.isnan(cs.split_ws[ns * M * K:]).all(), "the split launch did not run (or wrote outside its partial tiles)"
+            assert relerr(ys, ref) < 1e-4 + OUT_TOL[2] and relerr(ys, y) < 2.0 ** -7
+            assert sts.shape == st.shape and torch.allclose(sts, st, rtol=1e-4, atol=1e-3), (sts - st).abs().max()
+            ys2, _ = cs.fwd(x, w, 1, 1, resid=r, relu=1, bf16=3)
+            assert relerr(ys2, F.relu(ref + r)) < 1e-4 + OUT_TOL[2] and relerr(ys2, y2) < 2.0 ** -7
+            if K % 64 == 0 and C % 64 == 0 and (K // 64) % ns == 0:
+                dxs = cs.dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
+                assert relerr(dxs, xg.grad + rr) < 1e-4 + OUT_TOL[2] and relerr(dxs, dx) < 2.0 ** -7
+            # a scratch too small for the partial tiles: the launch stays unsplit (bit-identical to it)
+            small = Conv(dev, split_floats=ns * M * K - 1)
+            yb, stb = small.fwd(x, w, 1, 1, stats=True, bf16=3)
+            assert torch.equal(yb, y) and torch.equal(stb, st) and torch.isnan(small.split_ws).all()
+            lbc_config("LBC_HDMAP_SPLIT", -1)
     # A/B: the per-tap LDS-DMA kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_HDMA", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, 1, bf16=3)
