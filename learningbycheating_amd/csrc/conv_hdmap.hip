@@ -91,6 +91,10 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_k(IgemmArgs a, const 
 // SIMD where they run (nothing hides a wave's LDS / DMA latencies): layer 4 at 32 images is 120 tiles of 72 K-tiles each.  With the
 // gathered channels cut into ranges the launch has tiles x ranges workgroups of 1 / ranges the K-tiles, and a second, elementwise
 // launch (conv_split_epilogue_k).  Needs the caller's scratch (IgemmArgs::split_ws).
+// Measured (profiles/r04_run14_split_k.log; per launch, forward = input gradient): the second launch and the partial tiles cost about
+// what half the K loop saves.  512 channels (72 K-tiles per tile), 32 images: 22 -> 19 us in 2 or 4 ranges, 28 in 8; 16 images: 21 -> 15;
+// 64 images (240 tiles): 24 -> 27.  256 channels (36 K-tiles): 15 -> 21 us at 32 images, 13 -> 16 at 16.  Hence the policy: four ranges
+// for launches of at most 128 tiles that contract 512 channels or more -- layer 4 at up to 32 images per GPU; nothing else.
 int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
 {
     (void)mode;
@@ -101,12 +105,9 @@ int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
     const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64), elems = (long long)a.M * a.K;
     auto fits = [&](long long n) { return n > 1 && nslab % n == 0 && elems * n <= a.split_ws_floats && elems * n < (1ll << 31); };
     if (opt > 1) return fits(opt) ? (int)opt : 1;
-    const long long max_tiles = lbc_opt(kOptHdmapSplitMaxTiles) > 0 ? lbc_opt(kOptHdmapSplitMaxTiles) : 256;
-    if (tiles > max_tiles) return 1;
-    // as many ranges as two workgroups per CU take in one round, two slabs (18 K-tiles) or more each
-    for (long long n = 8; n > 1; n >>= 1)
-        if (fits(n) && tiles * n <= 512 && nslab / n >= 2) return (int)n;
-    return 1;
+    const long long max_tiles = lbc_opt(kOptHdmapSplitMaxTiles) > 0 ? lbc_opt(kOptHdmapSplitMaxTiles) : 128;
+    if (tiles > max_tiles || nslab < 8) return 1;
+    return fits(4) ? 4 : 1;
 }
 
 // Persistent form of conv_hdma.hip's cfg 1 (256 x 128) and cfg 2 (128 x 256); false = the launch keeps conv_hdma_k

