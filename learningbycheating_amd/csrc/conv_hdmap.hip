@@ -93,8 +93,10 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_k(IgemmArgs a, const 
 // launch (conv_split_epilogue_k).  Needs the caller's scratch (IgemmArgs::split_ws).
 // Measured (profiles/r04_run14_split_k.log; per launch, forward = input gradient): the second launch and the partial tiles cost about
 // what half the K loop saves.  512 channels (72 K-tiles per tile), 32 images: 22 -> 19 us in 2 or 4 ranges, 28 in 8; 16 images: 21 -> 15;
-// 64 images (240 tiles): 24 -> 27.  256 channels (36 K-tiles): 15 -> 21 us at 32 images, 13 -> 16 at 16.  Hence the policy: four ranges
-// for launches of at most 128 tiles that contract 512 channels or more -- layer 4 at up to 32 images per GPU; nothing else.
+// 64 images (240 tiles): 24 -> 27.  256 channels (36 K-tiles): 15 -> 21 us at 32 images, 13 -> 16 at 16.  Inside the training step
+// (r04_run15_split_k_policy.log) the 3 us per launch at 32 images do not show (4.22 vs 4.23 / 4.26 ms: the timing loop of a lone
+// launch hides less of a launch's fixed cost than the stream does); at 16 images the step gains 3.7 % (3.52 -> 3.39 ms).  Hence the
+// policy: four ranges for launches of at most 64 tiles that contract 512 channels or more -- layer 4 at up to 16 images per GPU.
 int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
 {
     (void)mode;
@@ -105,7 +107,7 @@ int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
     const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64), elems = (long long)a.M * a.K;
     auto fits = [&](long long n) { return n > 1 && nslab % n == 0 && elems * n <= a.split_ws_floats && elems * n < (1ll << 31); };
     if (opt > 1) return fits(opt) ? (int)opt : 1;
-    const long long max_tiles = lbc_opt(kOptHdmapSplitMaxTiles) > 0 ? lbc_opt(kOptHdmapSplitMaxTiles) : 128;
+    const long long max_tiles = lbc_opt(kOptHdmapSplitMaxTiles) > 0 ? lbc_opt(kOptHdmapSplitMaxTiles) : 64;
     if (tiles > max_tiles || nslab < 8) return 1;
     return fits(4) ? 4 : 1;
 }

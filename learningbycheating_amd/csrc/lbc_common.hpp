@@ -77,8 +77,8 @@ enum LbcOpt {
     kOptC64pProf,          // LBC_C64P_PROF: device address of a u64[grid][8 waves][8] buffer -> conv_c64p_k stamps s_memtime around its phases (diagnostic, scripts/c64p_prof.py)
     kOptHeadNoSplit,       // LBC_HEAD_NO_SPLIT: 1 = the MFMA head multiplies with ONE bf16 copy of its folded weights (round 3's form; A/B) instead of the high + low pair
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
-    kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs (tests, A/B), unset / 1 = policy (lbc_conv_hdmap_nsplit: layer 4 at up to 32 images)
-    kOptHdmapSplitMaxTiles, // LBC_HDMAP_SPLIT_MAX_TILES: the policy splits launches of at most this many tiles (default 128)
+    kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs (tests, A/B), unset / 1 = policy (lbc_conv_hdmap_nsplit: layer 4 at up to 16 images)
+    kOptHdmapSplitMaxTiles, // LBC_HDMAP_SPLIT_MAX_TILES: the policy splits launches of at most this many tiles (default 64)
     kOptHdmaSmallBelow,    // LBC_HDMA_SMALL_BELOW: launches whose best eight-wave shape has fewer tiles than this take the four-wave 128 x 64 shape instead (default 0: never; A/B)
     kOptCount
 };

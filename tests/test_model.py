@@ -240,8 +240,8 @@ def test_gradients_with_frozen_decisions_full_size(env, kind, backbone, h, w, n)
 @gpu
 @pytest.mark.parametrize("split", [-1, 2])
 def test_bf16_gradients_with_frozen_decisions_full_size(env, split, lbc_config):
-    """(split: LBC_HDMAP_SPLIT -- -1 = the shipped policy, layer 4's convolutions in four channel ranges at this batch; 2 = every launch
-    of the four-wave shape, layers 3 and 4, in two: the split-K path with all three epilogue forms under the same bound.)
+    """(split: LBC_HDMAP_SPLIT -- -1 = the shipped policy, no split-K launch at this batch; 2 = every launch of the four-wave shape,
+    layers 3 and 4, in two channel ranges: the split-K path with all three epilogue forms under the same bound.)
     The shipped bf16 mode (BASELINE.json config 3) at the reference's size, N = 32 = the per-GPU batch of the 8-GPU run, on a
     trained-like (warm-started) ResNet-34: every parameter gradient against the float64 oracle that takes the executor's own
     ReLU / max-pool decisions AND rounds where the executor rounds (MFMA operands, stored activations and activation gradients to
