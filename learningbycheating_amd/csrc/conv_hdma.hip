@@ -410,8 +410,13 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
         const double score = (double)tiles / (double)(((tiles + 255) / 256) * 256) * (c.bm * c.bn >= 256 * 256 ? 1.0 : 0.9);
         if (score > best_score) { best_score = score; best = i; best_tiles = tiles; }
     }
-    // (A/B: an eight-wave launch that leaves most CUs idle -- layer 2 at 32 images is 120 tiles -- as four-wave tiles, two workgroups per CU)
-    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < lbc_opt(kOptHdmaSmallBelow) && a.K % 64 == 0 &&
+    // An eight-wave launch that leaves half the CUs idle runs faster as four-wave 128 x 64 tiles, two workgroups per CU and four times the
+    // workgroups, where that shape's 184-row halo holds the image rows (layers 3 / 4): 120 tiles = layer 3 at 64 images 29 -> 22 us per
+    // launch (the step 7.20 -> 6.89 ms on that box), layer 4 at 128 images 50 -> 38 us (10.34 -> 10.14 ms); at 240 tiles (layer 3 at 128
+    // images) it loses, 35 -> 41 us (profiles/r04_run16_small_tiles_at_120.log).  Nothing in between was measured: the threshold sits at
+    // 160 tiles (62 % of the CUs).  LBC_HDMA_SMALL_BELOW=0: never.
+    const long long below = lbc_opt(kOptHdmaSmallBelow) >= 0 ? lbc_opt(kOptHdmaSmallBelow) : 160;
+    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < below && a.K % 64 == 0 && !a.pre_scale &&
                               lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4);
     if (best >= 0 && !prefer_small) return kLbcCfgHdma + best;
     // Few rows (the per-GPU load of the 8-GPU run: layer 3 / 4 at 32 images have 7680 / 1920 output pixels): 128 x 64 tiles, four waves,

@@ -79,7 +79,7 @@ enum LbcOpt {
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs (tests, A/B), unset / 1 = policy (lbc_conv_hdmap_nsplit: layer 4 at up to 16 images)
     kOptHdmapSplitMaxTiles, // LBC_HDMAP_SPLIT_MAX_TILES: the policy splits launches of at most this many tiles (default 64)
-    kOptHdmaSmallBelow,    // LBC_HDMA_SMALL_BELOW: launches whose best eight-wave shape has fewer tiles than this take the four-wave 128 x 64 shape instead (default 0: never; A/B)
+    kOptHdmaSmallBelow,    // LBC_HDMA_SMALL_BELOW: launches whose best eight-wave shape has fewer tiles than this take the four-wave 128 x 64 shape instead where it fits (default 160; 0 = never)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);
