@@ -488,6 +488,33 @@ def early_reads_checked(dev):
     return dev.type == "cpu" or os.environ.get("LBC_TEST_EXPERIMENTAL", "1") != "0"
 
 
+def test_conv_launch_policy_at_the_per_gpu_batches(env, lbc_config):
+    """which tile shape a 3x3 / stride-1 launch of the ResNet-34 layers (resnet.py:164) gets at the per-GPU batches of the 1 / 2 / 4 / 8
+    GPU runs -- host logic only, read off the statistics-row count of a query call (rows = M / tile rows).  Eight-wave 256 x 128 tiles
+    where they fill the CUs; launches that would be fewer than 160 of them take the four-wave 128 x 64 shape where its 184-row halo holds
+    the image rows (layers 3 / 4; measured in profiles/r04_run16_small_tiles_at_120.log); LBC_HDMA_SMALL_BELOW=0 switches that off."""
+    from learningbycheating_amd import _lib
+    lib = _lib.get()
+
+    def rows(N, H, W, C, K):
+        r = ctypes.c_int(0)
+        d = _lib.ConvDesc(N, H, W, C, K, 3, 3, 1, 1, 0, 3, 0)
+        _lib.check(lib.lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(r), None))
+        return r.value, N * H * W
+
+    L2, L3, L4 = (20, 48, 128, 128), (10, 24, 256, 256), (5, 12, 512, 512)
+    expect = {(256, L2): 256, (256, L3): 256, (256, L4): 256,      # 960 / 480 / 240 eight-wave tiles
+              (128, L2): 256, (128, L3): 256, (128, L4): 128,      # layer 4: 120 eight-wave tiles -> 480 four-wave tiles
+              (64, L2): 256, (64, L3): 128, (64, L4): 128,         # layer 3: 120 -> 480; layer 4: 60 eight-wave tiles are below the fill threshold anyway
+              (32, L2): 256, (32, L3): 128, (32, L4): 128}         # layer 2 (120 tiles): its 48-pixel rows need a 226-row halo, the four-wave shape holds 184
+    for (N, shape), bm in expect.items():
+        r, M = rows(N, *shape)
+        assert r == -(-M // bm), (N, shape, r, M, bm)
+    lbc_config("LBC_HDMA_SMALL_BELOW", 0)
+    assert rows(128, *L4)[0] == -(-128 * 60 // 256) and rows(64, *L3)[0] == -(-64 * 240 // 256)
+    assert rows(64, *L4)[0] == -(-64 * 60 // 128)                  # (below the eight-wave fill threshold: unchanged)
+
+
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
 HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256, 4: 128}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves)
 HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
