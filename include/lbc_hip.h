@@ -50,7 +50,8 @@ typedef struct lbc_conv_desc {
  * y[N,OH,OW,K] = conv(x', w) (+bias) (+resid) (relu), x' = relu?(x*pre_scale+pre_shift) when
  * pre_scale != NULL (the producing BatchNorm applied on load; zero padding stays zero).
  * stats (nullable): per-workgroup partial (sum, sum^2) of y per channel, [rows][2][K];
- * *stats_rows receives the number of rows written (query with stats == NULL allowed). */
+ * *stats_rows receives the number of rows written.  Query: call with y == NULL (nothing is launched) and the SAME descriptor, resid
+ * and pre_scale (NULL or not) as the real call -- they select the kernel, and the kernel sets the row count. */
 int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const void* w, const float* bias,
                    const void* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
                    void* y, float* stats, int* stats_rows, lbc_stream_t stream);

@@ -38,7 +38,8 @@ int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const void* w, const f
     a.LH = a.OH; a.LW = a.OW; a.ostep = 1;
     a.M = d->N * a.OH * a.OW;
     a.pre_scale = pre_scale; a.pre_shift = pre_shift; a.pre_relu = pre_relu;
-    // NB a row-count query must describe the launch it is for: pass the same pre_scale (NULL or not) as the real call
+    a.resid = resid;
+    // NB a row-count query must describe the launch it is for: pass the same pre_scale and resid (NULL or not) as the real call
     const int cfg = lbc_igemm_pick_for(a, 0);
     if (stats_rows) *stats_rows = lbc_igemm_rows(a, cfg);
     if (!y) return LBC_OK;   // query only

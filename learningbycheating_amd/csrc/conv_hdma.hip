@@ -381,7 +381,8 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     // BatchNorm-on-load as an in-LDS transform of the halo: forward only, behind LBC_HDMA_PROLOGUE=1 until it is measured
     // (the 64-channel layer's persistent kernel has it always: conv_c64p_k<0, 0, true>; LBC_NO_C64P_PRE=1 sends those launches back to conv_halo.hip)
     const bool c64 = a.C == 64 && a.K == 64;
-    if (a.pre_scale && (mode != 0 || (c64 ? (lbc_opt_on(kOptNoC64pPre) || a.resid != nullptr) : !lbc_opt_on(kOptHdmaPrologue)))) return -1;
+    const bool hdmap_pre = lbc_opt_on(kOptHdmapPre) && !a.resid;      // conv_hdmap_k<.., PRE> where the launch is eligible for it, conv_igemm.hip otherwise
+    if (a.pre_scale && (mode != 0 || (c64 ? (lbc_opt_on(kOptNoC64pPre) || a.resid != nullptr) : !(lbc_opt_on(kOptHdmaPrologue) || hdmap_pre)))) return -1;
     if (a.KH != 3 || a.KW != 3 || a.P != 1 || a.S != 1 || a.C % 64 || (mode != 0 && mode != 1)) return -1;
     if (a.H != a.OH || a.W != a.OW || a.M != a.N * a.H * a.W || (long long)a.N * a.H * a.W * a.C >= (1ll << 31)) return -1;
     if ((long long)a.K * 9 * a.C >= (1ll << 31)) return -1;
@@ -408,6 +409,7 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
         const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn);
         if (tiles < fill) continue;
         const double score = (double)tiles / (double)(((tiles + 255) / 256) * 256) * (c.bm * c.bn >= 256 * 256 ? 1.0 : 0.9);
+        if (a.pre_scale && !lbc_opt_on(kOptHdmaPrologue) && !lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + i)) continue;      // (LBC_HDMAP_PRE alone: only shapes whose persistent form has the transform)
         if (score > best_score) { best_score = score; best = i; best_tiles = tiles; }
     }
     // An eight-wave launch that leaves half the CUs idle runs faster as four-wave 128 x 64 tiles, two workgroups per CU and four times the
@@ -416,12 +418,12 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     // images) it loses, 35 -> 41 us (profiles/r04_run16_small_tiles_at_120.log).  Nothing in between was measured: the threshold sits at
     // 160 tiles (62 % of the CUs).  LBC_HDMA_SMALL_BELOW=0: never.
     const long long below = lbc_opt(kOptHdmaSmallBelow) >= 0 ? lbc_opt(kOptHdmaSmallBelow) : 160;
-    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < below && a.K % 64 == 0 && !a.pre_scale &&
+    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < below && a.K % 64 == 0 &&
                               lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4);
     if (best >= 0 && !prefer_small) return kLbcCfgHdma + best;
     // Few rows (the per-GPU load of the 8-GPU run: layer 3 / 4 at 32 images have 7680 / 1920 output pixels): 128 x 64 tiles, four waves,
     // two workgroups per CU (conv_hdmap.hpp) instead of the 64 x 64 register-staged tiles of conv_igemm.hip (31 us per 9-GFLOP launch)
-    if ((forced < 0 || forced == 4) && !a.pre_scale && a.K % 64 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4)) {
+    if ((forced < 0 || forced == 4) && a.K % 64 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4)) {
         const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64);
         // (its own knob; LBC_GEMM256_MIN_TILES -- the per-tap kernel's threshold, which tests set to 1 -- still applies when this one is unset)
         const long long small_fill = lbc_opt(kOptHdmaSmallMinTiles) > 0 ? lbc_opt(kOptHdmaSmallMinTiles)

@@ -2,6 +2,7 @@
 // the 15 instantiations compile in parallel).
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
+#include "conv_hdmap.hpp"      // (hdmap_pre_channels<>: nothing is instantiated here)
 
 int lbc_conv_hdmap_launch_256x128_320(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_256x128_384(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
@@ -116,8 +117,16 @@ int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
 // (BatchNorm-on-load, the 256 x 256 test shape, LBC_NO_HDMA_PERSIST=1).
 bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg)
 {
-    if (lbc_opt_on(kOptNoHdmaPersist) || a.pre_scale || (mode != 0 && mode != 1)) return false;
+    if (lbc_opt_on(kOptNoHdmaPersist) || (mode != 0 && mode != 1)) return false;
     if (a.bnb_y && (mode != 1 || a.resid)) return false;
+    if (a.pre_scale) {
+        // BatchNorm-on-load (conv_hdmap_k<.., PRE>; LBC_HDMAP_PRE=1): plain forward, and the coefficient table must fit next to the shape's LDS
+        if (!lbc_opt_on(kOptHdmapPre) || mode != 0 || a.resid || a.bnb_y) return false;
+        const int pc = cfg == kLbcCfgHdma + 1 ? (256 + 2 * a.W + 2 <= 320 - 8 ? hdmap_pre_channels<256, 128, 4, 2, 320, 16>() : hdmap_pre_channels<256, 128, 4, 2, 384, 8>())
+                       : cfg == kLbcCfgHdma + 2 ? hdmap_pre_channels<128, 256, 2, 4, 192, 8>()
+                       : cfg == kLbcCfgHdma + 4 ? hdmap_pre_channels<128, 64, 2, 2, 192, 16>() : 0;
+        if (a.C > pc) return false;
+    }
     // the halo (BM + 2W + 2 rows) must end at least 8 rows before its LDS buffer does: the last 8-row DMA piece then comes from the
     // zero page as a whole and holds the zero row of the border select
     if (cfg == kLbcCfgHdma + 1) return 256 + 2 * a.W + 2 <= 384 - 8;

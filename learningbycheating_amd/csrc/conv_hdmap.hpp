@@ -19,6 +19,7 @@
 // right after the barrier stalled every wave's issue: profiles/r03_run6_hdmap_prof.log); every K-tile waits with a counted vmcnt for its
 // successor's weight tile: what this wave requested after that tile stays in flight, the previous tile's stores included.
 #pragma once
+#include <type_traits>
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include "conv_lds_dma.hpp"
@@ -42,11 +43,30 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p)
 // (tile p / nsplit, slab range p % nsplit), contracts C / nsplit of the gathered channels and leaves its accumulators as an f32 partial
 // tile in IgemmArgs::split_ws [range][M][K]; conv_split_epilogue_k (conv_hdmap.hip) sums the ranges in a fixed order and does the
 // epilogue of form 0 / 1 / 2.  One tile per workgroup (the launcher guarantees ntiles * nsplit workgroups).
+// PRE (forward, plain epilogue; behind LBC_HDMAP_PRE=1 until it is measured): the producer's BatchNorm + ReLU applied to the input
+// (IgemmArgs::pre_*; a block's conv2 reads the raw conv1 output, resnet.py:38-54) as an in-place transform of the staged halo.  The
+// lane that requested a 16-byte piece of the NEXT slab's halo (8 channels of one row) transforms exactly those 16 bytes once they have
+// landed -- no other lane is involved, so the slab's closing barrier is the only synchronization it needs: the piece requested in
+// K-tile s is read back in the tail of K-tile s + 2 (the counted vmcnt wait in front of that K-tile's barrier covers it), transformed
+// and written under the MFMAs of K-tile s + 3.  The halo pieces are therefore requested in the first three K-tiles of a slab (ATAPS 4),
+// and the per-channel scale / shift sit in an LDS table (filled once; 2 x 8 floats per lane and slab re-read into registers).  The
+// extra LDS operations sit between the hand-counted fragment reads: a counted lgkmcnt wait can only become stricter by them.
 // PROF (diagnostic builds, LBC_HDMAP_PROF = device address of 8 x u64 per wave): s_memtime stamps around the waits of every K-tile;
 // per wave: [0] K-tiles, [1] cycles in the three leading depth steps, [2] in the vmcnt wait, [3] in lgkmcnt(0) + barrier, [4] in the
 // tail (step-0 reads of the next K-tile, last depth step, DMA issue), [5] in epilogues, [6] whole stream, [7] tiles
-template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, bool PROF = false, int VAR = 0>
-__global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof, const int nsplit)
+template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
+constexpr int hdmap_lds_bytes() { return 2 * HRMAX * 128 + 3 * BN * 128 + WM * WN * SROWS * ((BN / WN) * 2 + 16) + WM * 2 * BN * 4; }
+// gathered channels the PRE form's LDS table has room for (the 384-row halo of layer 2 leaves 2 KB: 256 channels; so does the four-wave shape)
+template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
+constexpr int hdmap_pre_channels()
+{
+    constexpr int used = hdmap_lds_bytes<BM, BN, WM, WN, HRMAX, SROWS>();
+    constexpr int room = WM * WN == 4 ? 80 * 1024 : 160 * 1024;          // (the four-wave shape must stay at two workgroups per CU)
+    return used + 4096 <= room ? 512 : (used + 2048 <= room ? 256 : (used + 1024 <= room ? 128 : 0));
+}
+
+template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, bool PROF = false, int VAR = 0, bool PRE = false>
+__global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || (PRE && WM * WN == 8)) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof, const int nsplit)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
@@ -65,13 +85,17 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
     constexpr int SROW_B = WTN * 2 + 16;                        // LDS pitch of a staged row (64 bf16 + 16 bytes); SROWS rows per copy-out step
     constexpr int STG = BRING + NB * TILE_B;                    // wave-private staging: NW x SROWS x SROW_B
     constexpr int RED = STG + NW * SROWS * SROW_B;              // [WM][2][BN] floats
-    constexpr int SMEM = RED + WM * 2 * BN * 4;
+    constexpr int PTAB = RED + WM * 2 * BN * 4;                 // PRE: [2][PRE_C] floats, scale then shift of the gathered channels
+    constexpr int PRE_C = PRE ? hdmap_pre_channels<BM, BN, WM, WN, HRMAX, SROWS>() : 0;
+    static_assert(!PRE || (MODE == 0 && EPI == 0 && PRE_C > 0 && (VAR & 8) != 0), "conv_hdmap: BatchNorm-on-load is a form of the plain forward");
+    static_assert(PTAB == hdmap_lds_bytes<BM, BN, WM, WN, HRMAX, SROWS>(), "conv_hdmap: LDS layout");
+    constexpr int SMEM = PTAB + 2 * PRE_C * 4;
     constexpr int ZROW = (HRMAX - 1) * 128;                     // last row of either halo buffer: beyond the halo, filled from the zero page
     static_assert(SMEM <= 160 * 1024, "conv_hdmap: LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
     constexpr int HPW = HRMAX / (8 * NW);                       // 1-KiB halo pieces (8 rows) per wave per slab
     constexpr int NBW = BN / (8 * NW);                          // 1-KiB weight pieces per wave per K-tile
-    constexpr int ATAPS = 7;                                    // taps of a slab whose issue slot may carry halo pieces of the next slab
+    constexpr int ATAPS = PRE ? 4 : 7;                          // taps of a slab whose issue slot may carry halo pieces of the next slab (PRE: early enough to be transformed in place before the slab ends)
     constexpr int PPT = (HPW + ATAPS - 1) / ATAPS;              // halo pieces of the next slab requested per tap (taps 0 .. ATAPS - 1)
     static_assert(PPT >= 1 && PPT <= 2, "conv_hdmap: halo pieces per tap");
     constexpr int NSTEP = WTM / SROWS;                          // copy-out steps per wave and tile
@@ -239,6 +263,49 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);                 \
     } while (0)
 
+    // ---- PRE: in-place BatchNorm (+ ReLU) of the halo pieces this lane requested.  16-byte LDS accesses of the same kind as the fragment
+    //      reads (inline asm with ASMRD: ordered among themselves and with the fragment reads, not tracked by the compiler)
+#ifdef LBC_HIP_EMULATED_FOR_TESTS
+#define LBC_LDS_RD16(DST, ADDR) DST = *reinterpret_cast<const std::remove_reference_t<decltype(DST)>*>(smem + (ADDR))
+#define LBC_LDS_WR16(ADDR, SRC) *reinterpret_cast<std::remove_cv_t<std::remove_reference_t<decltype(SRC)>>*>(smem + (ADDR)) = (SRC)
+#define LBC_FENCE(V) do { } while (0)
+#else
+#define LBC_LDS_RD16(DST, ADDR)                                                                                                  \
+    do {                                                                                                                         \
+        if constexpr (ASMRD) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(lds0 + (unsigned)(ADDR)));                     \
+        else DST = *reinterpret_cast<const std::remove_reference_t<decltype(DST)>*>(smem + (ADDR));                                                       \
+    } while (0)
+#define LBC_LDS_WR16(ADDR, SRC)                                                                                                  \
+    do {                                                                                                                         \
+        if constexpr (ASMRD) asm volatile("ds_write_b128 %0, %1" : : "v"(lds0 + (unsigned)(ADDR)), "v"(SRC) : "memory");         \
+        else *reinterpret_cast<std::remove_cv_t<std::remove_reference_t<decltype(SRC)>>*>(smem + (ADDR)) = (SRC);                                                           \
+    } while (0)
+#define LBC_FENCE(V) do { if constexpr (ASMRD) asm volatile("" : "+v"(V)); } while (0)
+#endif
+    // channel chunk (8 channels) of the lane's 16 bytes in pieces with even / odd index (the swizzle of the DMA source, aswz above)
+    const int pcs[2] = {pseg ^ ((arow0 >> 1) & 7), pseg ^ (((arow0 >> 1) + 4) & 7)};
+    f32x4 pco[PRE ? 2 : 1][4];              // [piece parity][scale lo, scale hi, shift lo, shift hi] of the slab being transformed
+    const float pfloor = a.pre_relu ? 0.f : -INFINITY;
+    auto pre_coef = [&](const int slab) {   // (consumed two K-tiles later at the earliest: behind at least one lgkmcnt(0) + barrier)
+#pragma unroll
+        for (int par = 0; par < 2; ++par) {
+            const int o = PTAB + (slab * 64 + pcs[par] * 8) * 4;
+            LBC_LDS_RD16(pco[par][0], o); LBC_LDS_RD16(pco[par][1], o + 16);
+            LBC_LDS_RD16(pco[par][2], o + PRE_C * 4); LBC_LDS_RD16(pco[par][3], o + PRE_C * 4 + 16);
+        }
+    };
+    auto pre_piece_addr = [&](const int buf, const int j) { return buf * ABYTES + (wave * HPW + j) * 1024 + lane * 16; };
+    auto pre_pad = [&](const int j) { return (wave * HPW + j) * 8 >= HR; };            // wave-uniform: the piece came from the zero page
+    auto pre_xform = [&](const bf16x8 raw, const int par) {
+        const f32x8 v = __builtin_convertvector(raw, f32x8);
+        f32x4 lo = __builtin_shufflevector(v, v, 0, 1, 2, 3) * pco[par][0] + pco[par][2];
+        f32x4 hi = __builtin_shufflevector(v, v, 4, 5, 6, 7) * pco[par][1] + pco[par][3];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], pfloor); hi[e] = fmaxf(hi[e], pfloor); }
+        return __builtin_convertvector(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
+    };
+    bf16x8 pxr[PRE ? PPT : 1];              // pieces read back in a K-tile's tail, transformed in the next K-tile
+
     // s_waitcnt vmcnt(n) for the handful of counts the stream produces (the immediate must be a constant)
     auto wait_vm = [&](const int n) {
         switch (n) {
@@ -257,12 +324,34 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
     int sg = 0;                             // slabs consumed so far: halo buffer sg & 1
     tap_mask(m0, amask);
 
+    if constexpr (PRE) {                    // the coefficient table, visible to every wave before the first piece is transformed
+        float* tab = reinterpret_cast<float*>(smem + PTAB);
+        for (int i = tid; i < C; i += NW * 64) { tab[i] = a.pre_scale[i]; tab[PRE_C + i] = a.pre_shift[i]; }
+        LBC_WAIT_LGKM0();
+        __builtin_amdgcn_s_barrier();
+    }
     // prologue: the halo of slab 0 and the first two weight tiles in flight; everything of K-tile 0 landed and visible
 #pragma unroll
     for (int j = 0; j < HPW; ++j) issue_a(m0, 0, 0, j);
     issue_b(n0, 0, 0, 0, 0, NBW);
     issue_b(n0, 0, 1, 1, 0, NBW);
     LBC_WAIT_VM(NBW);
+    if constexpr (PRE) {                    // the first halo: all of this wave's pieces at once
+        bf16x8 x0[HPW];
+        pre_coef(0);
+#pragma unroll
+        for (int j = 0; j < HPW; ++j)
+            if (!pre_pad(j)) LBC_LDS_RD16(x0[j], pre_piece_addr(0, j));
+        LBC_WAIT_LGKM0();
+#pragma unroll
+        for (int par = 0; par < 2; ++par)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) LBC_FENCE(pco[par][q]);
+#pragma unroll
+        for (int j = 0; j < HPW; ++j)
+            if (!pre_pad(j)) { LBC_FENCE(x0[j]); const bf16x8 t = pre_xform(x0[j], j & 1); LBC_LDS_WR16(pre_piece_addr(0, j), t); }
+        LBC_WAIT_LGKM0();
+    }
     __builtin_amdgcn_s_barrier();
     tap_addr(0, 0, amask);
     LBC_RD(0, 0, 0);
@@ -334,6 +423,19 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
                     }
                     LBC_WAIT_OLDER_READS();                              // set g & 1 is in (its reads were issued a full step ago)
                     LBC_USE(g & 1);
+                    if constexpr (PRE) {
+                        // the pieces requested in K-tile t - 3, read back in the tail of K-tile t - 1 (older than this step's fragment reads:
+                        // the wait above covers them): transform, write back -- complete by this K-tile's lgkmcnt(0) + barrier
+                        if (g == 0 && t >= 3 && follows) {
+#pragma unroll
+                            for (int q = 0; q < PPT; ++q)
+                                if ((t - 3) * PPT + q < HPW && !pre_pad((t - 3) * PPT + q)) {
+                                    LBC_FENCE(pxr[q]);
+                                    const bf16x8 tq = pre_xform(pxr[q], ((t - 3) * PPT + q) & 1);
+                                    LBC_LDS_WR16(pre_piece_addr(buf ^ 1, (t - 3) * PPT + q), tq);
+                                }
+                        }
+                    }
                     LBC_MM(g & 1);
                     if (VAR & 4) {
 #pragma unroll
@@ -371,6 +473,18 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
                     if (((KS - 1) & 1) == upper) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
                 }
                 if (has_next) LBC_RD(nslot, 0, 0);
+                if constexpr (PRE) {
+                    if (follows) {
+                        if (t == 0) pre_coef(LAST ? 0 : c + 1);          // (the previous slab's last piece was transformed in its K-tile 5)
+                        if (t >= 2) {
+                            // the pieces requested in K-tile t - 2 have landed (the vmcnt wait in front of this K-tile's barrier left only
+                            // the requests of K-tiles t - 1 and t in flight): read them back, behind the next K-tile's step-0 fragments
+#pragma unroll
+                            for (int q = 0; q < PPT; ++q)
+                                if ((t - 2) * PPT + q < HPW && !pre_pad((t - 2) * PPT + q)) LBC_LDS_RD16(pxr[q], pre_piece_addr(buf ^ 1, (t - 2) * PPT + q));
+                        }
+                    }
+                }
                 LBC_USE((KS - 1) & 1);                                   // in since the lgkmcnt(0) in front of the barrier
                 LBC_MM((KS - 1) & 1);
                 if (VAR & 2) {          // everything in one burst behind the barrier: K-tile k + 1's successor is K-tile k + 2 -> slot (t + 2) % 3
@@ -552,6 +666,9 @@ __global__ __launch_bounds__(WM * WN * 64, (BM / WM == 128 && WM * WN == 4) ? 1 
         o[0] = pf_kt; o[1] = pf_steps; o[2] = pf_vm; o[3] = pf_bar; o[4] = pf_tail; o[5] = pf_epi; o[6] = LBC_NOW() - pf_t0; o[7] = (unsigned long long)cnt;
     }
 #undef LBC_NOW
+#undef LBC_LDS_RD16
+#undef LBC_LDS_WR16
+#undef LBC_FENCE
 #undef LBC_RD
 #undef LBC_RD1
 #undef LBC_USE
@@ -576,6 +693,16 @@ int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int 
         }
     }
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
+    if (a.pre_scale) {
+        constexpr int PC = hdmap_pre_channels<BM, BN, WM, WN, HRMAX, SROWS>();
+        if constexpr (PC > 0) {
+            LBC_REQUIRE(mode == 0 && epi == 0 && a.C <= PC, "conv_hdmap: BatchNorm-on-load is a form of the plain forward with at most %d gathered channels", PC);
+            hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, false, 8, true>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, 1);
+            return lbc_check_launch("conv_hdmap(pre)");
+        } else {
+            LBC_REQUIRE(false, "conv_hdmap: this tile shape has no LDS left for the BatchNorm-on-load table");
+        }
+    }
     // A/B variants (plain forward only); 16 = the shipped schedule with compiler-managed fragment reads instead of the asm ones
     const long long var = lbc_opt(kOptHdmapVar) > 0 ? lbc_opt(kOptHdmapVar) : 0;
     unsigned long long* prof = lbc_opt(kOptHdmapProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptHdmapProf)) : nullptr;

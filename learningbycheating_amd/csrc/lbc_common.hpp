@@ -79,6 +79,7 @@ enum LbcOpt {
     kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
     kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs (tests, A/B), unset / 1 = policy (lbc_conv_hdmap_nsplit: layer 4 at up to 16 images)
     kOptHdmapSplitMaxTiles, // LBC_HDMAP_SPLIT_MAX_TILES: the policy splits launches of at most this many tiles (default 64)
+    kOptHdmapPre,          // LBC_HDMAP_PRE: 1 = the persistent halo-staged convolution takes forward launches with BatchNorm-on-load (in-place transform of the staged halo, conv_hdmap_k<.., PRE>; read when a network is planned: blocks then keep bn1 fused into conv2).  Built in round 4 without a GPU left to measure it.
     kOptHdmaSmallBelow,    // LBC_HDMA_SMALL_BELOW: launches whose best eight-wave shape has fewer tiles than this take the four-wave 128 x 64 shape instead where it fits (default 160; 0 = never)
     kOptCount
 };

@@ -64,10 +64,12 @@ class Conv:
             wh = wh.to(torch.bfloat16)       # bf16 weight copy, same [K][kh][kw][C] layout
         buf, y = guarded((N, OH, OW, K), self.dev, dtype=at)
         rows = ctypes.c_int(0)
-        _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
-        st = torch.zeros((rows.value, 2, K), device=self.dev) if stats else None
         keep = [t.to(self.dev) if t is not None else None for t in (bias, nhwc(resid).to(at) if resid is not None else None,
                                                                       pre[0] if pre else None, pre[1] if pre else None)]
+        # (the row-count query describes the launch it is for: the same on-load transform and residual, NULL or not -- they select the kernel)
+        _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), None, None, None, _lib.ptr(keep[1]), _lib.ptr(keep[2]), _lib.ptr(keep[3]),
+                                           1 if (pre and pre[2]) else 0, None, None, ctypes.byref(rows), None))
+        st = torch.zeros((rows.value, 2, K), device=self.dev) if stats else None
         _lib.check(self.lib.lbc_conv2d_fwd(ctypes.byref(d), _lib.ptr(xh), _lib.ptr(wh), _lib.ptr(keep[0]), _lib.ptr(keep[1]),
                                            _lib.ptr(keep[2]), _lib.ptr(keep[3]), 1 if (pre and pre[2]) else 0, _lib.ptr(y),
                                            _lib.ptr(st), ctypes.byref(rows), _lib.stream_for(xh)))

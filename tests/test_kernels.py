@@ -515,6 +515,13 @@ def test_conv_launch_policy_at_the_per_gpu_batches(env, lbc_config):
     assert rows(64, *L4)[0] == -(-64 * 60 // 128)                  # (below the eight-wave fill threshold: unchanged)
 
 
+def hdmap_pre_checked(dev):
+    """BatchNorm-on-load inside the persistent convolution (LBC_HDMAP_PRE=1, off by default) was built after the round's GPU time was
+    spent: its addressing and schedule are checked on the emulator; what only the GPU can check -- that the counted vmcnt wait really
+    covers the piece a lane reads back -- runs there with LBC_TEST_HDMAP_PRE=1 (first thing to do before measuring it)."""
+    return dev.type == "cpu" or os.environ.get("LBC_TEST_HDMAP_PRE", "0") == "1"
+
+
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
 HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256, 4: 128}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves)
 HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
@@ -581,6 +588,33 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         assert relerr(yp, refp) < 5e-4 + OUT_TOL[2]      # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
         assert torch.allclose(stp[:, 0].sum(0), refp.sum((0, 2, 3)), rtol=2e-3, atol=2e-2)
         lbc_config("LBC_HDMA_PROLOGUE", 0)
+        yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
+        assert relerr(yp, yq) < 2.0 ** -7
+    # The same transform inside the PERSISTENT kernel (conv_hdmap_k<.., PRE>, LBC_HDMAP_PRE=1): every lane transforms the 16-byte halo
+    # pieces it requested itself, two K-tiles after the request, under the MFMAs of the third.  Against the reference and the
+    # register-staged kernel; with one / two workgroups for the whole launch (several tiles per workgroup: the next tile's first halo
+    # is transformed during the current tile's last slab) bit-identical to the default grid.
+    pre_fits = {1: W <= 59 and C <= (256 if W > 30 else 512), 2: W <= 27 and C <= 256, 4: W <= 27 and C <= 256, -1: True}      # the persistent shape's halo rows, its LDS left for the coefficient table
+    if not (C == 64 and K == 64) and pre_fits.get(cfgid, False) and hdmap_pre_checked(dev):
+        ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
+        xin = rbf(F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)))
+        refp = F.conv2d(xin, rbf(w), None, 1, 1)
+        lbc_config("LBC_HDMAP_PRE", 1)
+        yp, stp = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
+        if cfgid >= 0:
+            assert stp.shape[0] == -(-M // HDMA_BM[cfgid])       # (the kernel under test, not the generic kernel's 64-row tiles)
+        assert relerr(yp, refp) < 5e-4 + OUT_TOL[2]
+        assert torch.allclose(stp[:, 0].sum(0), refp.sum((0, 2, 3)), rtol=2e-3, atol=2e-2)
+        assert torch.allclose(stp[:, 1].sum(0), (refp * refp).sum((0, 2, 3)), rtol=2e-3)
+        ynr, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, False), bf16=3)           # no ReLU on load
+        assert relerr(ynr, F.conv2d(rbf(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)), rbf(w), None, 1, 1)) < 5e-4 + OUT_TOL[2]
+        if cfgid >= 0:
+            for wgs in (1, 2):
+                lbc_config("LBC_HDMA_PERSIST_WGS", wgs)
+                yb, stb = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
+                assert torch.equal(yb, yp) and torch.equal(stb, stp), wgs
+            lbc_config("LBC_HDMA_PERSIST_WGS", -1)
+        lbc_config("LBC_HDMAP_PRE", 0)
         yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
         assert relerr(yp, yq) < 2.0 ** -7
     if C == 64 and K == 64 and cfgid in (3, -1):
