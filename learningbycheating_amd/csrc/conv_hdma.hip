@@ -418,7 +418,8 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     // images) it loses, 35 -> 41 us (profiles/r04_run16_small_tiles_at_120.log).  Nothing in between was measured: the threshold sits at
     // 160 tiles (62 % of the CUs).  LBC_HDMA_SMALL_BELOW=0: never.
     const long long below = lbc_opt(kOptHdmaSmallBelow) >= 0 ? lbc_opt(kOptHdmaSmallBelow) : 160;
-    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < below && a.K % 64 == 0 &&
+    // (not under LBC_GEMM256_MIN_TILES: the tests' switch that sends small launches to the eight-wave shapes keeps its meaning)
+    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < below && a.K % 64 == 0 && lbc_opt(kOptGemm256MinTiles) <= 0 &&
                               lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4);
     if (best >= 0 && !prefer_small) return kLbcCfgHdma + best;
     // Few rows (the per-GPU load of the 8-GPU run: layer 3 / 4 at 32 images have 7680 / 1920 output pixels): 128 x 64 tiles, four waves,
