@@ -77,6 +77,8 @@ class DevicePool:
         pass
 
     def get(self, k):
+        if self.pos + self.batch > self.n:
+            self.pos = 0
         s = slice(self.pos, self.pos + self.batch)
         self.pos = (self.pos + self.batch) % self.n
         return {key: v[s] for key, v in self.t.items()}
@@ -236,10 +238,10 @@ def self_spawn(args):
 
 
 def read_traffic():
-    """HBM bytes per launch of the convolution family from the committed PMC passes of THIS round's code: profiles/r04_pmc_traffic.json,
+    """HBM bytes per launch of the convolution family from the committed PMC passes of THIS round's code: profiles/r05_pmc_traffic.json,
     written by scripts/pmc_traffic.py from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_evidence.sh (counters need
     their own runs: they cannot be collected inside this process); an older round's file is a fallback and says so in its `source`"""
-    for name in ("r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -274,7 +276,8 @@ def main():
     ap.add_argument("--resident", action="store_true", help="re-feed ONE device-resident batch every step")
     ap.add_argument("--init-steps", type=int, default=40, help="below-horizon warm start (stands in for the phase-0 checkpoint)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the short exact-f32 run reported under 'also'")
+    ap.add_argument("--no-alt", action="store_true", help="skip the short extra runs of the default line: exact f32 ('also'), PCIe-inclusive "
+                                                          "('h2d_inclusive') and the 32-image per-GPU load of the 8-GPU run ('per_gpu_32')")
     ap.add_argument("--breakdown", default=None, help="write the per-kernel-class profile of the instrumented step here (json)")
     ap.add_argument("--serial", action="store_true",
                     help="profiling runs: the teacher forward stays on the main stream (with LBC_NO_SIDE_STREAM=1 every kernel then runs alone, "
@@ -310,9 +313,11 @@ def main():
 
     per_gpu = global_batch // world
     assert per_gpu * world == global_batch, "global batch must divide by the number of GPUs"
-    pool = FramePool(per_gpu if args.resident else args.pool_frames, per_gpu, device, 1000 + rank, need_rgb=kind != "birdview", slots=args.h2d or args.resident)
-    if not args.h2d and not args.resident:
-        pool = DevicePool(pool)          # (the pinned host copy is dropped: everything the timed region reads lives in HBM)
+    host_pool = FramePool(per_gpu if args.resident else args.pool_frames, per_gpu, device, 1000 + rank, need_rgb=kind != "birdview", slots=True)
+    # the default feed: everything the timed region reads lives in HBM (the pinned host copy only serves --h2d and the short
+    # PCIe-inclusive run the default line reports next to the headline number)
+    dev_pool = None if (args.h2d or args.resident) else DevicePool(host_pool)
+    cur = {"pool": host_pool if dev_pool is None else dev_pool, "pg": per_gpu}
     # Warm start below the horizon: the phase-1 unprojection has a 1/y pole at the horizon and the reference always
     # starts phase 1 from a phase-0 checkpoint (train_image_phase1.py:244); a few L1 steps towards below-horizon targets
     # stand in for it.  Not timed.
@@ -325,6 +330,7 @@ def main():
     def run_steps(tr, n, mode, weights=None):
         """n steps through the double-buffered H2D pipeline (or on one resident batch); returns the last loss tensor"""
         loss = None
+        pool = cur["pool"]
         if args.resident:
             b = pool.get(0)
         for i in range(n):
@@ -332,7 +338,7 @@ def main():
             if not args.resident:
                 b = pool.get(k)
             if mode == "warm":
-                loss = tr.step(b["rgb"], b["speed"], b["onehot"], target=tgt)
+                loss = tr.step(b["rgb"], b["speed"], b["onehot"], target=tgt[:cur["pg"]])
             elif kind == "birdview":
                 loss = tr.step(b["bv"], b["speed"], b["onehot"], target=b["loc"])
             else:
@@ -346,7 +352,14 @@ def main():
                 pool.prefetch(k)
         return loss
 
-    def timed_run(dt_name, steps, warmup):
+    def timed_run(dt_name, steps, warmup, pool=None, pg=None):
+        """pool / pg: another feed (the pinned host dataset) or another per-GPU batch for this run; default = the run's own"""
+        if pool is not None:
+            cur["pool"] = pool
+        pool = cur["pool"]
+        cur["pg"] = pg or per_gpu
+        pool.batch = cur["pg"]
+        pg = cur["pg"]
         student, teacher = build_models(device, kind)
         prec = {"f32": "fp32", "bf16_mfma": "bf16_mfma", "bf16": "bf16"}[dt_name]
         for m in (student, teacher):
@@ -357,12 +370,12 @@ def main():
         pool.prefetch(0); pool.prefetch(1)
         gdt = torch.bfloat16 if (args.grad_allreduce == "bf16" or (args.grad_allreduce == "auto" and dt_name == "bf16")) else None
         if kind == "birdview":
-            tr = NativeTrainer(teacher, None, per_gpu, (7, 192, 192), device, phase="birdview", lr=1e-4, world_size=world, grad_dtype=gdt, sync_bn=args.sync_bn)
+            tr = NativeTrainer(teacher, None, pg, (7, 192, 192), device, phase="birdview", lr=1e-4, world_size=world, grad_dtype=gdt, sync_bn=args.sync_bn)
         else:
-            warm = NativeTrainer(student, None, per_gpu, (3, 160, 384), device, phase="l1_all", lr=1e-3, world_size=world, grad_dtype=gdt)
+            warm = NativeTrainer(student, None, pg, (3, 160, 384), device, phase="l1_all", lr=1e-3, world_size=world, grad_dtype=gdt)
             run_steps(warm, args.init_steps, "warm")
             del warm
-            tr = NativeTrainer(student, teacher, per_gpu, (3, 160, 384), device, phase=1, lr=1e-4, world_size=world, grad_dtype=gdt,
+            tr = NativeTrainer(student, teacher, pg, (3, 160, 384), device, phase=1, lr=1e-4, world_size=world, grad_dtype=gdt,
                                sync_bn=args.sync_bn)
         if args.serial:
             tr.overlap_teacher = False
@@ -436,6 +449,8 @@ def main():
         return roof, hbm, br
 
     tr, dt, loss_mean = timed_run(dtype, args.steps, args.warmup)
+    # the ranks the gradient buckets really travel between: a one from every rank summed on the buckets' own communicator and stream
+    rccl_ranks = tr.reducer.participants() if world > 1 else None
     roof, hbm, breakdown = instrumented_step(tr, dtype)
     if rank == 0 and args.breakdown:
         os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
@@ -446,12 +461,13 @@ def main():
     if rank == 0:
         value = global_batch * args.steps / dt
         feed = ("ONE device-resident batch re-fed every step" if args.resident else
-                ("%d-frame pinned host dataset per rank, uint8 H2D of every batch (%.1f MB) double-buffered inside the timed region" % (pool.n, pool.bytes_per_step / 1e6)
-                 if args.h2d else "%d-frame dataset per rank resident in HBM, a different batch every step" % pool.n))
+                ("%d-frame pinned host dataset per rank, uint8 H2D of every batch (%.1f MB) double-buffered inside the timed region" % (host_pool.n, host_pool.bytes_per_step / 1e6)
+                 if args.h2d else "%d-frame dataset per rank resident in HBM, a different batch every step" % host_pool.n))
         out = {"metric": wl["metric"], "value": round(value, 2), "unit": "images/sec",
                "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
-               # ranks of the communicator the gradient buckets actually travelled on (None: one process, nothing travels)
-               "rccl_ranks": (dist.get_world_size() if (world > 1 and args.dist_backend == "nccl") else None),
+               # ranks of the communicator the gradient buckets actually travelled on, read back from it (StageAllReducer.participants;
+               # None: one process, nothing travels); `comm_backend` says whether that communicator is RCCL
+               "rccl_ranks": rccl_ranks, "comm_backend": (("rccl" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None),
                "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",
@@ -474,8 +490,33 @@ def main():
         aroof, ahbm, _ = instrumented_step(atr, "f32")
         also = {"dtype": "f32", "value": round(global_batch * asteps / adt, 2), "ms_per_step": round(1e3 * adt / asteps, 3),
                 "steps": asteps, "note": "exact-f32 MFMA path (the one held to the 1e-3 waypoint parity bar)", "roofline": aroof, "roofline_hbm": ahbm}
+    h2d_incl = small = None
+    if world == 1 and not args.no_alt and not args.h2d and not args.resident and dtype != "f32":
+        # (a) SURVEY 8(d) writes the metric with the uint8 H2D of every batch inside the timed region: the same step fed from the pinned host
+        #     dataset (113 MB per 256-image batch, double-buffered on a copy stream) -- never `value`, reported next to it
+        torch.cuda.empty_cache()
+        hsteps = max(5, min(20, args.steps // 2))
+        host_pool.pos = 0
+        htr, hdt, _ = timed_run(dtype, hsteps, 5, pool=host_pool)
+        h2d_incl = {"ms_per_step": round(1e3 * hdt / hsteps, 3), "value": round(global_batch * hsteps / hdt, 2), "steps": hsteps,
+                    "h2d_mb_per_step": round(host_pool.bytes_per_step / 1e6, 1),
+                    "note": "the same step with the uint8 frames uploaded from pinned host memory inside the timed region (double-buffered): the PCIe-inclusive rate"}
+        del htr
+        # (b) the metric's 8-GPU operating point is 32 images per GPU: that load on this one GPU (no communication), with its own roofline
+        if kind == "phase1" and global_batch == 256:
+            torch.cuda.empty_cache()
+            str_, sdt, _ = timed_run(dtype, 30, 10, pool=dev_pool, pg=32)
+            sroof, shbm, _ = instrumented_step(str_, dtype)
+            small = {"per_gpu_batch": 32, "ms_per_step": round(1e3 * sdt / 30, 3), "value_one_gpu": round(32 * 30 / sdt, 2), "steps": 30,
+                     "no_comm_projection_8gpu": round(8 * 32 * 30 / sdt, 1),
+                     "note": "the per-GPU load of the 8-GPU run (256 / 8 images) on ONE GPU, no communication: what the 8-GPU value can at most be is 8 x value_one_gpu",
+                     "roofline": {k: sroof[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "avg_launch_ms")},
+                     "roofline_hbm": {k: shbm[k] for k in ("bound", "achieved", "peak", "unit", "frac", "launches_per_step", "ms_per_step")}}
+            del str_
     if rank == 0:
         out["also"] = also
+        out["h2d_inclusive"] = h2d_incl
+        out["per_gpu_32"] = small
         if not args.no_cpu_baseline and world == 1:      # reported at N = 1 only (rank 0 must not keep the other ranks waiting)
             out["cpu_baseline"] = cpu_baseline(kind)
         print(json.dumps(out), flush=True)

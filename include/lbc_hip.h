@@ -25,9 +25,16 @@ typedef void* lbc_stream_t;
 
 const char* lbc_last_error(void);
 const char* lbc_backend(void);   /* "hip-gfx950" for the product library */
+/* ABI version of THIS header; lbc_version() returns the one the library was built with -- a host compares the two at load time.
+ * 100: rounds 1-3.  101: lbc_conv_desc grew split_workspace / split_workspace_bytes (round 4; the library still answered 100).
+ * 200: lbc_conv_desc starts with struct_size, which every entry point checks (a descriptor from an older header, or one that was not
+ *      initialised, is refused with LBC_EINVAL instead of being read past); lbc_adam_profile_elems. */
+#define LBC_HIP_ABI_VERSION 200
 int lbc_version(void);
 
 typedef struct lbc_conv_desc {
+    unsigned struct_size;   /* = sizeof(lbc_conv_desc): start every descriptor as `lbc_conv_desc d = LBC_CONV_DESC_INIT;` -- all other
+                               fields zero (no scratch, no fused ReLU, exact f32), then fill in the geometry */
     int N, H, W, C;     /* input tensor (NHWC) */
     int K;              /* output channels */
     int KH, KW, S, P;   /* filter size, stride, padding */
@@ -45,6 +52,7 @@ typedef struct lbc_conv_desc {
                                        launch uses at most 8 * N*OH*OW*K * 4 bytes and ignores a scratch that is too small.  Results
                                        differ from the unsplit launch by f32 summation order only. */
 } lbc_conv_desc;
+#define LBC_CONV_DESC_INIT { (unsigned)sizeof(lbc_conv_desc) }
 
 /* nn.Conv2d forward (reference bird_view/models/resnet.py:15-22,102; image.py:57).
  * y[N,OH,OW,K] = conv(x', w) (+bias) (+resid) (relu), x' = relu?(x*pre_scale+pre_shift) when
@@ -321,6 +329,8 @@ long long lbc_config_get(const char* name);
  * line per class "name count total_ms total_flops total_bytes" and resets the log. */
 int lbc_profile_enable(int on);
 int lbc_profile_report(char* buf, int cap);
+/* parameter elements behind the optimizer's chunk table: only books the profiler's bytes of an lbc_adam_step launch (28 B per element) */
+void lbc_adam_profile_elems(long long n);
 
 #ifdef __cplusplus
 }

@@ -14,9 +14,17 @@ _lib = None
 c_void_p, c_int, c_float, c_size_t, c_char_p = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t, ctypes.c_char_p
 
 
+ABI_VERSION = 200     # include/lbc_hip.h LBC_HIP_ABI_VERSION: load() refuses a library that answers anything else
+
+
 class ConvDesc(ctypes.Structure):
-    _fields_ = ([(n, c_int) for n in ("N", "H", "W", "C", "K", "KH", "KW", "S", "P", "relu", "bf16", "w_transposed")] +
+    """lbc_conv_desc; struct_size (its first member, checked by every entry point) is filled in here: ConvDesc(N, H, W, C, K, ...)"""
+    _fields_ = ([("struct_size", ctypes.c_uint)] +
+                [(n, c_int) for n in ("N", "H", "W", "C", "K", "KH", "KW", "S", "P", "relu", "bf16", "w_transposed")] +
                 [("split_workspace", c_void_p), ("split_workspace_bytes", c_size_t)])
+
+    def __init__(self, *args, **kw):
+        super().__init__(ctypes.sizeof(ConvDesc), *args, **kw)
 
 
 class NetDesc(ctypes.Structure):
@@ -104,6 +112,7 @@ _SIGNATURES = {
     "lbc_config_get": (ctypes.c_longlong, [c_char_p]),
     "lbc_profile_enable": (c_int, [c_int]),
     "lbc_profile_report": (c_int, [c_char_p, c_int]),
+    "lbc_adam_profile_elems": (None, [ctypes.c_longlong]),
 }
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 
@@ -113,6 +122,10 @@ def _declare(lib):
         fn = getattr(lib, name)   # AttributeError here = the library does not export what include/lbc_hip.h declares
         fn.restype = res
         fn.argtypes = args
+    v = lib.lbc_version()
+    if v != ABI_VERSION:
+        raise RuntimeError("learningbycheating_amd: the library answers ABI version %d, this binding was written for %d "
+                           "(include/lbc_hip.h LBC_HIP_ABI_VERSION): rebuild liblbc_hip.so" % (v, ABI_VERSION))
     return lib
 
 

@@ -139,6 +139,10 @@ class PolicyBase(ResnetBase):
         if eng is None or eng.max_batch < n:
             eng = PolicyEngine(self._arch(), self.input_channel, h, w, self._normalize, max(n, 1), image.device, prec)
             self._engines[key] = eng
+        # "frozen" is a promise of whoever holds the engine (NativeTrainer for its teacher), not a property of the cached engine: anyone who
+        # comes through the module API gets an engine that derives its weight copies and folded BatchNorm affines from the tensors as they are
+        if getattr(eng, "_frozen", False):
+            eng.set_frozen(False)
         tensors = dict(self.named_parameters())
         tensors.update(dict(self.named_buffers()))
         eng.bind({k: v.data for k, v in tensors.items() if k in set(eng.names)}, with_grads or eng.grad_flat is not None,

@@ -44,7 +44,10 @@ __global__ __launch_bounds__(256) void adam_k(const AdamChunk* __restrict__ chun
     }
 }
 
+static long long g_adam_prof_elems = 0;      // lbc_adam_profile_elems: what the launch profiler books for an optimizer launch
 }  // namespace
+
+extern "C" void lbc_adam_profile_elems(long long n) { g_adam_prof_elems = n > 0 ? n : 0; }
 
 int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, double lr, double beta1, double beta2, double eps,
                     double weight_decay, int step, hipStream_t s)
@@ -55,7 +58,7 @@ int lbc_adam_launch(const AdamChunk* chunks_dev, int nchunks, double lr, double 
     const float lr_over_bc1 = (float)(lr / bc1);
     const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
     // algorithmic bytes: read p, g, m, v and write p, m, v = 7 x 4 bytes per element (648 MB for the 23.13 M parameters of the student)
-    LbcProfScope prof("adam", 0.0, 28.0 * (double)(lbc_opt(kOptAdamElems) > 0 ? lbc_opt(kOptAdamElems) : 0), s);
+    LbcProfScope prof("adam", 0.0, 28.0 * (double)g_adam_prof_elems, s);
     hipLaunchKernelGGL(adam_k, dim3((unsigned)nchunks), dim3(256), 0, s, chunks_dev, lr_over_bc1, inv_bc2_sqrt, (float)beta1,
                        (float)beta2, (float)(1.0 - beta1), (float)(1.0 - beta2), (float)eps, (float)weight_decay);
     return lbc_check_launch("adam");

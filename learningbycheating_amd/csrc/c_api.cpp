@@ -13,7 +13,21 @@ const char* lbc_backend(void)
     return "hip-gfx950";
 #endif
 }
-int lbc_version(void) { return 100; }
+int lbc_version(void) { return LBC_HIP_ABI_VERSION; }
+
+// Every entry point that takes a descriptor checks it came from THIS header: a host built against an older lbc_hip.h (the struct grew
+// in ABI 101: split_workspace) or one that forgot LBC_CONV_DESC_INIT passes a struct the library would read past / read garbage from
+static bool desc_ok(const lbc_conv_desc* d, const char* who)
+{
+    if (!d) { lbc_set_error("%s: null descriptor", who); return false; }
+    if (d->struct_size != sizeof(lbc_conv_desc)) {
+        lbc_set_error("%s: lbc_conv_desc.struct_size is %u, this library (ABI %d) expects %zu -- initialise the descriptor with LBC_CONV_DESC_INIT "
+                      "and rebuild the host against this library's lbc_hip.h", who, d->struct_size, LBC_HIP_ABI_VERSION, sizeof(lbc_conv_desc));
+        return false;
+    }
+    return true;
+}
+#define LBC_DESC(d, who) do { if (!desc_ok((d), (who))) return LBC_EINVAL; } while (0)
 
 static IgemmArgs conv_args(const lbc_conv_desc* d)
 {
@@ -31,7 +45,7 @@ int lbc_conv2d_fwd(const lbc_conv_desc* d, const void* x, const void* w, const f
                    const void* resid, const float* pre_scale, const float* pre_shift, int pre_relu,
                    void* y, float* stats, int* stats_rows, lbc_stream_t stream)
 {
-    LBC_REQUIRE(d, "conv2d_fwd: null desc");
+    LBC_DESC(d, "conv2d_fwd");
     IgemmArgs a = conv_args(d);
     a.OH = (d->H + 2 * d->P - d->KH) / d->S + 1;
     a.OW = (d->W + 2 * d->P - d->KW) / d->S + 1;
@@ -94,7 +108,7 @@ int lbc_weight_transpose_f32(const float* w, float* wt, int A, int T, int B, lbc
 int lbc_conv2d_dgrad(const lbc_conv_desc* d, const void* dy, const void* w, const void* resid,
                      void* dx, lbc_stream_t stream)
 {
-    LBC_REQUIRE(d, "conv2d_dgrad: null desc");
+    LBC_DESC(d, "conv2d_dgrad");
     LBC_REQUIRE(!d->bf16 || d->w_transposed, "conv2d_dgrad: bf16 needs w_transposed = 1 (see lbc_weight_transpose_f32)");
     // weights [K][T][C]: depth index (gathered channel) = k is the slow axis -> wmajor 0 with row length C;
     // the transposed copy [C][T][K] is depth-contiguous -> wmajor 1
@@ -116,7 +130,8 @@ int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const void* w, co
                         const float* pre_scale, const float* pre_shift, int pre_relu,
                         void* y, float* stats, int* stats_rows, lbc_stream_t stream)
 {
-    LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_fwd: geometry must be k3 s2 p1 op1");
+    LBC_DESC(d, "deconv3x3s2_fwd");
+    LBC_REQUIRE(d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_fwd: geometry must be k3 s2 p1 op1");
     LBC_REQUIRE(!d->bf16 || d->w_transposed, "deconv3x3s2_fwd: bf16 needs w_transposed = 1 (see lbc_weight_transpose_f32)");
     lbc_conv_desc c = deconv_as_conv(d);
     return conv_dgrad_impl(&c, x, w, /*wmajor=*/d->w_transposed ? 1 : 0, nullptr, bias, pre_scale, pre_shift, pre_relu, d->relu, y, stats,
@@ -125,7 +140,8 @@ int lbc_deconv3x3s2_fwd(const lbc_conv_desc* d, const void* x, const void* w, co
 
 int lbc_deconv3x3s2_dgrad(const lbc_conv_desc* d, const void* dy, const void* w, void* dx, lbc_stream_t stream)
 {
-    LBC_REQUIRE(d && d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_dgrad: geometry must be k3 s2 p1 op1");
+    LBC_DESC(d, "deconv3x3s2_dgrad");
+    LBC_REQUIRE(d->KH == 3 && d->KW == 3 && d->S == 2 && d->P == 1, "deconv3x3s2_dgrad: geometry must be k3 s2 p1 op1");
     lbc_conv_desc c = deconv_as_conv(d);
     c.relu = 0;
     // forward gather conv over dy with the deconv weight read as [O=C_T][kh][kw][I=K_T]
@@ -150,7 +166,7 @@ static WgradArgs conv_wgrad_args(const lbc_conv_desc* d)
 
 size_t lbc_conv2d_wgrad_workspace(const lbc_conv_desc* d)
 {
-    if (!d) return 0;
+    if (!desc_ok(d, "conv2d_wgrad_workspace")) return 0;
     WgradArgs a = conv_wgrad_args(d);
     return (size_t)a.nsplit * (size_t)a.CP * (size_t)(a.KH * a.KW) * (size_t)a.CQ * sizeof(float);
 }
@@ -159,7 +175,8 @@ int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                      const float* pre_scale, const float* pre_shift, int pre_relu,
                      float* dw, float beta, void* workspace, lbc_stream_t stream)
 {
-    LBC_REQUIRE(d && workspace, "conv2d_wgrad: null desc/workspace");
+    LBC_DESC(d, "conv2d_wgrad");
+    LBC_REQUIRE(workspace, "conv2d_wgrad: null workspace");
     WgradArgs a = conv_wgrad_args(d);
     a.p = dy; a.q = x; a.partial = (float*)workspace;
     a.q_scale = pre_scale; a.q_shift = pre_shift; a.q_relu = pre_relu;
@@ -172,7 +189,7 @@ int lbc_conv2d_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
 // n same-shaped 3x3 / stride-1 convolutions on bf16 tensors in one launch (+ one reduce launch)
 int lbc_conv2d_wgrad_group_supported(const lbc_conv_desc* d)
 {
-    if (!d) return 0;
+    if (!desc_ok(d, "conv2d_wgrad_group_supported")) return 0;
     WgradArgs a = conv_wgrad_args(d);
     a.p = d; a.q = d;     // (eligibility looks at geometry and flags only)
     return lbc_wgrad_tr_eligible(a) ? 1 : 0;
@@ -189,7 +206,8 @@ int lbc_conv2d_wgrad_group(const lbc_conv_desc* d, int n, const void* const* x, 
                            const float* const* pre_scale, const float* const* pre_shift, int pre_relu,
                            float* const* dw, void* workspace, lbc_stream_t stream)
 {
-    LBC_REQUIRE(d && x && dy && dw && workspace && n >= 1 && n <= kLbcWgradGroupMax, "conv2d_wgrad_group: null argument or group size %d outside [1,%d]", n, kLbcWgradGroupMax);
+    LBC_DESC(d, "conv2d_wgrad_group");
+    LBC_REQUIRE(x && dy && dw && workspace && n >= 1 && n <= kLbcWgradGroupMax, "conv2d_wgrad_group: null argument or group size %d outside [1,%d]", n, kLbcWgradGroupMax);
     LBC_REQUIRE(lbc_conv2d_wgrad_group_supported(d), "conv2d_wgrad_group: 3x3 / stride 1 / pad 1 on bf16 tensors (bf16 mode >= 2), channels multiples of 64");
     WgradArgs a = conv_wgrad_args(d);
     a.nsplit = lbc_wgrad_tr_group_split(a, n);
@@ -225,7 +243,7 @@ static WgradArgs deconv_wgrad_args(const lbc_conv_desc* d)
 
 size_t lbc_deconv3x3s2_wgrad_workspace(const lbc_conv_desc* d)
 {
-    if (!d) return 0;
+    if (!desc_ok(d, "deconv3x3s2_wgrad_workspace")) return 0;
     WgradArgs a = deconv_wgrad_args(d);
     return (size_t)a.nsplit * (size_t)a.CP * 9 * (size_t)a.CQ * sizeof(float);
 }
@@ -234,7 +252,8 @@ int lbc_deconv3x3s2_wgrad(const lbc_conv_desc* d, const void* x, const void* dy,
                           const float* pre_scale, const float* pre_shift, int pre_relu,
                           float* dw, float beta, void* workspace, lbc_stream_t stream)
 {
-    LBC_REQUIRE(d && workspace, "deconv_wgrad: null desc/workspace");
+    LBC_DESC(d, "deconv3x3s2_wgrad");
+    LBC_REQUIRE(workspace, "deconv_wgrad: null workspace");
     LBC_REQUIRE(!pre_relu, "deconv_wgrad: ReLU-on-load of the dense operand is not supported");
     WgradArgs a = deconv_wgrad_args(d);
     a.p = x; a.q = dy; a.partial = (float*)workspace;

@@ -42,7 +42,7 @@ namespace {
 // land in ring rows whose last reader was the tile before that: R >= BM + halo rows, no second barrier), lanes of a piece whose row is
 // not new are masked off, and the on-load BatchNorm transform (PRE) touches each row once instead of 2.5 times.
 template <int MODE, int EPI, bool PRE = false, int BMv = 256>
-__global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof)
+__global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw)
 {
     constexpr int BM = BMv, BN = 64, WM = BMv / 64, WN = 2, MT = 2;
     constexpr bool RING = BMv == 128;
@@ -148,16 +148,6 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
         for (int j = 0; j < PPW; ++j) issue_piece(first * BM, 0, j);
     }
 
-    // prof (diagnostic, LBC_C64P_PROF): per wave [0] tiles, [1] cycles waiting for the halo + opening barrier, [2] on-load transform,
-    // [3] K loop, [4] epilogue, [5] whole stream
-#ifdef LBC_HIP_EMULATED_FOR_TESTS
-#define LBC_NOW() 0ull
-#else
-#define LBC_NOW() __builtin_amdgcn_s_memtime()
-#endif
-    constexpr bool PROFILED = EPI != 2;      // (the fused BatchNorm-backward form sits at 256 VGPRs: the stamps' registers would spill into its epilogue)
-    unsigned long long pf_wait = 0, pf_pre = 0, pf_k = 0, pf_epi = 0, pf_t0 = 0, pf_prev = 0;
-    if (PROFILED && prof) { pf_t0 = LBC_NOW(); pf_prev = pf_t0; }
     bool stores_pending = false;
     for (int it = 0; it < cnt; ++it) {
         const int tile = first + it;
@@ -187,7 +177,6 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
         // flight); then everybody's are visible -- and nobody reads the other buffer any more
         if (stores_pending) LBC_WAIT_VM(NSTEP); else LBC_WAIT_VM(0);
         __builtin_amdgcn_s_barrier();
-        if (PROFILED && prof) { const unsigned long long t = LBC_NOW(); pf_wait += t - pf_prev; pf_prev = t; }
         if constexpr (PRE) {
             // thread -> channel group tid & 7 (its scale / shift: loaded here, through an address the compiler cannot hoist out of the tile
             // loop -- 16 more registers across the K loop would spill), halo rows tid >> 3, + 64, ...; LDS slot of (row, group) = group ^ swizzle(row)
@@ -222,7 +211,6 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             wg_u1 += u1; wg_u2 += u2;
         }
 
-        if (PROFILED && prof) { const unsigned long long t = LBC_NOW(); pf_pre += t - pf_prev; pf_prev = t; }
         f32x16 acc[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i)
@@ -289,7 +277,6 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             __builtin_amdgcn_sched_barrier(0);                  // keeps the address arithmetic of later taps out of this step (registers)
         }
 
-        if (PROFILED && prof) { LBC_WAIT_LGKM0(); const unsigned long long t = LBC_NOW(); pf_k += t - pf_prev; pf_prev = t; }
         // ---- wave-private epilogue
         if (EPI != 0) {     // own pieces of the side tile landed
             // (requested at steps 3 .. 27: the youngest requests of the tile, the halo pieces are all older)
@@ -351,7 +338,6 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             __builtin_amdgcn_wave_barrier();
         }
         stores_pending = true;
-        if (PROFILED && prof) { const unsigned long long t = LBC_NOW(); pf_epi += t - pf_prev; pf_prev = t; }
         if (a.stats && EPI == 2) {
             // lanes with the same segment (lane & 3) hold partial sums of the same 8 channels: combine over lane >> 2, then centre:
             // sum g * xhat = (sum g * y - mean * sum g) * invstd
@@ -388,11 +374,6 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             dst[BN + tid] = wg_u2 + u2;
         }
     }
-    if (PROFILED && prof && lane == 0) {
-        unsigned long long* o = prof + ((size_t)blockIdx.x * NWAVES + wave) * 8;
-        o[0] = (unsigned long long)cnt; o[1] = pf_wait; o[2] = pf_pre; o[3] = pf_k; o[4] = pf_epi; o[5] = LBC_NOW() - pf_t0;
-    }
-#undef LBC_NOW
     (void)npw;
 }
 
@@ -434,15 +415,14 @@ int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s)
     const int tpw = lbc_cdiv(ntiles, c64p_cap(bm));
     const dim3 grid((unsigned)lbc_cdiv(ntiles, tpw));
     const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
-    unsigned long long* prof = lbc_opt(kOptC64pProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptC64pProf)) : nullptr;
 #define LBC_C6(MODEv, EPIv)                                                                                                          \
     do {                                                                                                                             \
-        if (bm == 256) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, 256>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof); \
-        else           hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, 128>), grid, dim3(256), 0, s, a, zero, ntiles, tpw, prof); \
+        if (bm == 256) hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, 256>), grid, dim3(512), 0, s, a, zero, ntiles, tpw); \
+        else           hipLaunchKernelGGL((conv_c64p_k<MODEv, EPIv, false, 128>), grid, dim3(256), 0, s, a, zero, ntiles, tpw); \
     } while (0)
     if (mode == 0 && a.pre_scale) {
-        if (bm == 256) hipLaunchKernelGGL((conv_c64p_k<0, 0, true, 256>), grid, dim3(512), 0, s, a, zero, ntiles, tpw, prof);
-        else           hipLaunchKernelGGL((conv_c64p_k<0, 0, true, 128>), grid, dim3(256), 0, s, a, zero, ntiles, tpw, prof);
+        if (bm == 256) hipLaunchKernelGGL((conv_c64p_k<0, 0, true, 256>), grid, dim3(512), 0, s, a, zero, ntiles, tpw);
+        else           hipLaunchKernelGGL((conv_c64p_k<0, 0, true, 128>), grid, dim3(256), 0, s, a, zero, ntiles, tpw);
         return lbc_check_launch("conv_c64p");
     }
     if (mode == 0) { if (epi == 1) LBC_C6(0, 1); else LBC_C6(0, 0); }

@@ -19,260 +19,16 @@
 // A depth step (K-tile) = one filter tap x 64 channels, channel slab outer / taps inner so that the nine shifted reads of
 // a slab hit in L2.  No BatchNorm-on-load prologue (a DMA cannot transform): launches that need one keep conv_igemm.hip.
 //
-// Synchronisation of one K-tile (P phases of 8 MFMAs; group g = wave >> 2; buffers ring of NBUF K-tiles):
-//   phase p:  [load segment]  fragment ds_reads of tile t from its buffer; (p <= 1) DMA pieces of tile t + NBUF - 1;
-//                             (p == P-1) s_waitcnt vmcnt(n): this wave's pieces of tile t + 1 have landed;
-//                             s_waitcnt lgkmcnt(0): this wave's reads are retired;   s_barrier
-//             [MFMA segment]  8 MFMAs;   s_barrier
-//   RAW: group 0 reads tile t+1 right after the barrier that ends its phase P-1 MFMAs, which is the barrier group 1
-//        crosses between its phase P-1 load and MFMA segments -- every wave has waited for its tile t+1 pieces before it.
-//   WAR: a buffer is refilled from phase 0 of the tile after its last reader; those reads were retired (lgkmcnt(0))
-//        before the barrier the refilling wave has just crossed.
+// (The first-generation kernel of this file -- two barriers per 8 MFMAs, conv_glds_k -- lost to the one below in round 2 and was
+// removed in round 5 with its LBC_GLDS_V1 switch, like the timing-experiment builds LBC_GLDS_DIAG and the early-read variant.)
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
 #include "conv_lds_dma.hpp"
 
 namespace {
 
-template <int BM, int BN, int WM, int WN, int NBUF, int MODE>
-__global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* zero_page, const int diag)
-{
-    constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
-    constexpr int MT = WTM / 32, NT = WTN / 32;
-    static_assert(WM * WN == 8 && NT == 2 && (MT == 2 || MT == 4), "conv_glds: wave tiling");
-    constexpr int P = MT;                                       // phases per K-tile, (MT/2 * 2) x 1 x 4 = 8 MFMAs each
-    constexpr int TILE_A = BM * 128, TILE_B = BN * 128, BUF = TILE_A + TILE_B;   // bytes per K-tile: rows of 64 bf16
-    constexpr int NA = BM / 64, NB = BN / 64, NL = NA + NB;     // 1-KiB DMA pieces (8 rows) per wave per K-tile
-    static_assert(NBUF == 2 || NBUF == 3, "conv_glds: ring depth");
-    static_assert(NBUF * BUF <= 160 * 1024, "conv_glds: LDS");
-    __shared__ __attribute__((aligned(16))) char smem[NBUF * BUF];   // the ONLY LDS object (a second one costs vmcnt(0) per read)
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
-    const int grp = wave >> 2;                                  // waves w and w + 4 share a SIMD: opposite groups
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int W = a.W, H = a.H, C = a.C, T = a.KH * a.KW, KW = a.KW, PAD = a.P;
-
-    // XCD-aware tile order (see conv_igemm.hip): contiguous tile ranges per XCD, column tiles of the same rows adjacent
-    const int ntn = a.K / BN;
-    int tile_id;
-    {
-        const int nwg = gridDim.x, b = blockIdx.x;
-        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
-        tile_id = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
-    }
-    const int mtile = tile_id / ntn;
-    const int m0 = mtile * BM;
-    const int n0 = (tile_id - mtile * ntn) * BN;
-
-    const __bf16* xin = static_cast<const __bf16*>(a.x);
-    const __bf16* win = static_cast<const __bf16*>(a.w);
-    const __bf16* zero = static_cast<const __bf16*>(zero_page);
-
-    // ---- DMA roles: piece (wave * NA + j) of the A tile = rows 8 * piece .. + 7, lane -> (row = lane >> 3, segment = lane & 7)
-    int aoff[NA], amask[NA], aseg[NA];
-#pragma unroll
-    for (int j = 0; j < NA; ++j) {
-        const int row = (wave * NA + j) * 8 + (lane >> 3);
-        const int m = m0 + row;
-        int bits = 0;
-        if (m < a.M) {
-            const int x = m % W;
-            const int y = (m / W) % H;
-            for (int t = 0; t < T; ++t) {
-                const int r = t / KW, s = t - r * KW;
-                const int dy = MODE == 0 ? r - PAD : PAD - r;
-                const int dx = MODE == 0 ? s - PAD : PAD - s;
-                if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
-            }
-        }
-        amask[j] = bits;
-        aoff[j] = (m < a.M ? m : 0) * C;
-        aseg[j] = (((lane & 7) ^ ((row >> 1) & 7))) * 8;        // swizzle on the SOURCE: LDS slot (row, s) holds segment s ^ f(row)
-    }
-    int boff[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        const int row = (wave * NB + j) * 8 + (lane >> 3);
-        boff[j] = (n0 + row) * (T * C) + (((lane & 7) ^ ((row >> 1) & 7))) * 8;
-    }
-    // ---- fragment roles: row l31 of a 32-row block, depth half kh; 16-byte segment (2g + kh) ^ f(row), f(row) = (l31 >> 1) & 7
-    const int swz = (l31 >> 1) & 7;
-    int koff[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) koff[g] = ((g * 2 + kh) ^ swz) << 4;
-    const int aBase = (wm * WTM + l31) * 128;
-    const int bBase = TILE_A + (wn * WTN + l31) * 128;
-
-    const int cpt = C / 64;
-    const int nit = T * cpt;
-
-    f32x16 acc[MT][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int j = 0; j < NT; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // the DMA stream walks K-tiles in order: (channel slab ci, tap ti), taps inner
-    int is_ci = 0, is_ti = 0, is_buf = 0;
-    // pieces 0 .. NB-1 = the weight tile, NB .. NL-1 = the activation tile; a K-tile's pieces are issued in two halves (the load
-    // segments of phases 0 and 1)
-    constexpr int NH = (NL + 1) / 2;
-    auto issue = [&](const int q0, const int q1) {
-        const int r = is_ti / KW, s = is_ti - r * KW;
-        const int shift = (MODE == 0 ? (r - PAD) * W + (s - PAD) : (PAD - r) * W + (PAD - s)) * C + is_ci * 64;
-        const int koffs = is_ti * C + is_ci * 64;
-        char* base = smem + is_buf * BUF;
-#pragma unroll
-        for (int q = 0; q < NL; ++q) {
-            if (q < q0 || q >= q1) continue;
-            if (q < NB) {
-                lds_dma16(diag == 2 ? zero + (lane & 7) * 8 : win + (boff[q] + koffs), base + TILE_A + (wave * NB + q) * 1024);
-            } else {
-                const int j = q - NB;
-                const bool ok = ((amask[j] >> is_ti) & 1) && diag < 2;
-                const __bf16* src = ok ? xin + (aoff[j] + shift + aseg[j]) : zero + (lane & 7) * 8;
-                lds_dma16(src, base + (wave * NA + j) * 1024);
-            }
-        }
-    };
-    auto issue_next = [&]() {
-        if (++is_ti == T) { is_ti = 0; ++is_ci; }
-        if (++is_buf == NBUF) is_buf = 0;
-    };
-
-    // ---- prologue: NBUF - 1 tiles in flight, tile 0 landed and visible
-    issue(0, NL); issue_next();
-    if (NBUF == 3) {
-        if (nit > 1) { issue(0, NL); issue_next(); LBC_WAIT_VM(NL); }
-        else LBC_WAIT_VM(0);
-    } else {
-        LBC_WAIT_VM(0);
-    }
-    __builtin_amdgcn_s_barrier();
-    if (grp == 1) __builtin_amdgcn_s_barrier();        // stagger: group 1 runs half a phase behind group 0
-
-    int buf = 0;
-    for (int t = 0; t < nit; ++t) {
-        const char* bb = smem + buf * BUF;
-        const bool more = t + (NBUF - 1) < nit && diag != 1;   // a K-tile is left to prefetch (diag 1: timing run without the DMA stream)
-        bf16x8 af[2][4], bfr[4];
-#pragma unroll
-        for (int p = 0; p < P; ++p) {
-            // phase -> (pair of 32-row blocks, 32-column block): (0,0) (0,1) [(1,1) (1,0)]
-            const int ih = p >> 1;
-            const int jn = (p == 1 || p == 2) ? 1 : 0;
-            // ---- load segment
-            if (p == 0 || p == 2) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int g = 0; g < 4; ++g)
-                        af[i][g] = *reinterpret_cast<const bf16x8*>(bb + aBase + (ih * 2 + i) * 4096 + koff[g]);
-            }
-            if (p != 2) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) bfr[g] = *reinterpret_cast<const bf16x8*>(bb + bBase + jn * 4096 + koff[g]);
-            }
-            if (more) {
-                if (p == 0) issue(0, NH);
-                if (p == 1) { issue(NH, NL); issue_next(); }
-            }
-            if (p == P - 1) {
-                // this wave's pieces of tile t + 1 have landed; with a 3-deep ring the NL pieces of tile t + 2 (issued in this
-                // K-tile's phases 0 and 1, P = 2) may stay in flight
-                if (NBUF == 3 && more) LBC_WAIT_VM(NL);
-                else LBC_WAIT_VM(0);
-            }
-            LBC_WAIT_LGKM0();
-            __builtin_amdgcn_s_barrier();
-            // ---- MFMA segment
-            __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int g = 0; g < 4; ++g)
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-                    acc[ih * 2 + i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i][g], bfr[g], acc[ih * 2 + i][jn], 0, 0, 0);
-            __builtin_amdgcn_s_setprio(0);
-            __builtin_amdgcn_s_barrier();
-        }
-        if (++buf == NBUF) buf = 0;
-    }
-    if (grp == 0) __builtin_amdgcn_s_barrier();        // every wave passes the same number of barriers
-
-    // ---- epilogue (as conv_igemm.hip): affine / bias / residual / ReLU, bf16 store, per-channel (sum, sum^2) partial row
-    float s1[NT], s2[NT];
-#pragma unroll
-    for (int j = 0; j < NT; ++j) { s1[j] = 0.f; s2[j] = 0.f; }
-    __bf16* yout = static_cast<__bf16*>(a.y);
-    const __bf16* resid = static_cast<const __bf16*>(a.resid);
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi) {
-        float rv[16][NT];
-        if (resid) {        // fetched per 32-row block before its stores: inside the store loop every 2-byte load is waited for alone
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const size_t ob = (size_t)(m < a.M ? m : 0) * (size_t)a.K;
-#pragma unroll
-                for (int nj = 0; nj < NT; ++nj) rv[r][nj] = (float)resid[ob + (size_t)(n0 + wn * WTN + nj * 32 + l31)];
-            }
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            if (m < a.M) {
-                const size_t ob = (size_t)m * (size_t)a.K;
-#pragma unroll
-                for (int nj = 0; nj < NT; ++nj) {
-                    const int col = n0 + wn * WTN + nj * 32 + l31;
-                    float v = acc[mi][nj][r];
-                    if (a.post_scale) v = v * a.post_scale[col] + a.post_shift[col];
-                    if (a.bias) v += a.bias[col];
-                    if (resid) v += rv[r][nj];
-                    if (a.relu) v = fmaxf(v, 0.f);
-                    yout[ob + col] = (__bf16)v;
-                    s1[nj] += v;
-                    s2[nj] += v * v;
-                }
-            }
-        }
-    }
-    if (a.stats) {
-        float* red = reinterpret_cast<float*>(smem);   // [WM][2][BN]; every wave has left the main loop (last barrier above)
-#pragma unroll
-        for (int nj = 0; nj < NT; ++nj) {
-            s1[nj] += __shfl_xor(s1[nj], 32);
-            s2[nj] += __shfl_xor(s2[nj], 32);
-        }
-        if (kh == 0) {
-#pragma unroll
-            for (int nj = 0; nj < NT; ++nj) {
-                const int c = wn * WTN + nj * 32 + l31;
-                red[(wm * 2 + 0) * BN + c] = s1[nj];
-                red[(wm * 2 + 1) * BN + c] = s2[nj];
-            }
-        }
-        __syncthreads();
-        if (tid < BN) {
-            float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-            for (int w = 0; w < WM; ++w) { t1 += red[(w * 2 + 0) * BN + tid]; t2 += red[(w * 2 + 1) * BN + tid]; }
-            float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
-            dst[n0 + tid] = t1;
-            dst[a.K + n0 + tid] = t2;
-        }
-    }
-}
-
-
-// ---------------------------------------------------------------------------------------------------------------------
-// Second generation of the same GEMM (default; LBC_GLDS_V1=1 keeps the kernel above for A/B runs).  Measured on the kernel
-// above at batch 256 (LBC_GLDS_DIAG runs): with the DMA stream removed a 256 x 256 launch still needs 68 of 77 us, the
-// 2-byte output stores cost 12 us and the barrier-separated fragment reads 14 us -- the matrix pipe waits on the phase
+// Measured on the first generation at batch 256 (round 2): with the DMA stream removed a 256 x 256 launch still needed 68 of 77 us,
+// the 2-byte output stores cost 12 us and the barrier-separated fragment reads 14 us -- the matrix pipe waited on the phase
 // structure (two barriers per 8 MFMAs), not on memory.  Here
 //   * ONE barrier per K-tile (one filter tap x 32 or 64 channels: 16 / 32 MFMAs per wave); a DMA piece has ~2000 MFMA cycles to
 //     land (four 32-channel tiles or two 64-channel tiles in the ring).  A wave's fragment reads for the next depth step are
@@ -283,12 +39,10 @@ __global__ __launch_bounds__(512, 2) void conv_glds_k(IgemmArgs a, const void* z
 // PH = 1 (MODE 1 only): the four output-parity phases of a stride-2 transposed launch in one grid (input gradient of the stride-2
 // 3x3 convolutions, ConvTranspose2d forward): workgroups [ph * n, (ph + 1) * n) serve phase ph = 2 oy0 + ox0, whose output pixels
 // (2 ly + oy0, 2 lx + ox0) gather x at (ly + dy, lx + dx) through the 1 / 2 / 2 / 4 taps with (oy0 + 1 - r, ox0 + 1 - s) even.
-// EARLY (LBC_HDMA_EARLY=1, not yet measured): fragment reads issued a full depth step ahead with hand-counted waits, as in
-// conv_hdma.hip (see there and conv_lds_dma.hpp)
 // WM x WN = 8 waves (one workgroup per CU), or 4 (256 x 64 / 128 x 128 tiles in half the LDS: TWO workgroups per CU, for the launches
 // whose K loop is a handful of K-tiles -- the phased stride-2 transposed ones, the 1x1 downsamples -- where a workgroup is mostly
 // prologue and epilogue and a second one has something to overlap them with)
-template <int BM, int BN, int WM, int WN, int MODE, int KT, int DIAG = 0, int PH = 0, int EARLY = 0>   // DIAG: timing experiments (LBC_GLDS_DIAG), wrong results
+template <int BM, int BN, int WM, int WN, int MODE, int KT, int PH = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, const void* zero_page)
 {
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
@@ -430,10 +184,10 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, con
     auto issue = [&]() {
         char* base = smem + is_buf * BUF;
 #pragma unroll
-        for (int j = 0; j < NB; ++j) lds_dma16((DIAG == 2 || DIAG == 4) ? zero : win + (boff[j] + is_koffs), base + TILE_A + ((wave % BWAVES) * NB + j) * 1024);
+        for (int j = 0; j < NB; ++j) lds_dma16(win + (boff[j] + is_koffs), base + TILE_A + ((wave % BWAVES) * NB + j) * 1024);
 #pragma unroll
         for (int j = 0; j < NA; ++j) {
-            const bool ok = ((amask[j] >> is_ti) & 1) && DIAG != 2 && DIAG != 3;
+            const bool ok = ((amask[j] >> is_ti) & 1) != 0;
             const __bf16* src = ok ? xin + (aoff[j] + is_shift) : zero;
             lds_dma16(src, base + (wave * NA + j) * 1024);
         }
@@ -472,27 +226,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, con
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                           \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);     \
     } while (0)
-    unsigned ra = 0, rb = 0;               // EARLY: smem byte offsets of the next A / B reads (the 32-row blocks are immediates)
-#define LBC_AD(bufoff, G) do { ra = (unsigned)((bufoff) + aBase + koff[G]); rb = (unsigned)((bufoff) + bBase + koff[G]); } while (0)
-#define LBC_RDA(SET)                                                                                                 \
-    do {                                                                                                             \
-        lds_read16_early_n<MT, 32 * ROWB>(fa[SET], smem, ra);                                                        \
-        lds_read16_early_n<NT, 32 * ROWB>(fb[SET], smem, rb);                                                        \
-    } while (0)
-#define LBC_USE(SET) do { lds_frag_use(fa[SET]); lds_frag_use(fb[SET]); } while (0)
-#define LBC_WAIT_OLDER_READS() __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, MT + NT))
-    // EARLY: one depth step of K-tile `ob` (next tile `on`): reads of step g + 1, offsets of the reads after those, MFMAs of step g
-#define LBC_STEP_EARLY(ob, on, g)                                                                                    \
-    do {                                                                                                             \
-        LBC_RDA(((g) + 1) & 1);                                                                                      \
-        if ((g) + 2 < KS) LBC_AD(ob, (g) + 2 < KS ? (g) + 2 : 0);                                                    \
-        else LBC_AD(on, 0);                                                                                          \
-        LBC_WAIT_OLDER_READS();                                                                                      \
-        LBC_USE((g) & 1);                                                                                            \
-        LBC_MM((g) & 1);                                                                                             \
-        LBC_SG(0x100, MT + NT); LBC_SG(0x002, 2); LBC_SG(0x008, MT * NT);                                            \
-        __builtin_amdgcn_sched_barrier(0);                                                                           \
-    } while (0)
     // one MFMA, one fragment read, ...: the reads of the next depth step between the MFMAs of the current one
 #define LBC_MIX()                                                                                                    \
     do {                                                                                                             \
@@ -513,8 +246,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, con
         if (i < nit) issue();
     wait_tiles((nit < NBUF ? nit : NBUF) - 1);
     __builtin_amdgcn_s_barrier();
-    if constexpr (EARLY) { LBC_AD(0, 0); LBC_RDA(0); LBC_AD(0, KS > 1 ? 1 : 0); }
-    else LBC_RD(smem, 0, 0);
+    LBC_RD(smem, 0, 0);
 
     // Synchronisation of K-tile t (buffer t % NBUF), once per tile, in front of its LAST depth step:
     //   s_waitcnt vmcnt: own pieces of tile t + 1 landed (NBUF - 2 younger tiles may stay in flight);  lgkmcnt(0);  s_barrier
@@ -531,7 +263,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, con
         const char* bn = smem + on;
 #pragma unroll
         for (int g = 0; g + 1 < KS; ++g) {
-            if constexpr (EARLY) { LBC_STEP_EARLY(ob, on, g); continue; }
             LBC_RD(bb, g + 1, (g + 1) & 1);
             LBC_MM(g & 1);
             LBC_MIX();
@@ -541,15 +272,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, con
         LBC_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (EARLY) { LBC_RDA(0); LBC_AD(on, KS > 1 ? 1 : 0); LBC_USE((KS - 1) & 1); }
-        else LBC_RD(bn, 0, 0);
+        LBC_RD(bn, 0, 0);
         LBC_MM((KS - 1) & 1);
-        if (DIAG != 1) issue();
-        if (EARLY) LBC_SG(0x100, MT + NT);
+        issue();
 #pragma unroll
         for (int k = 0; k < MT * NT; ++k) {
             LBC_SG(0x008, 1);
-            if (!EARLY && k < MT + NT) LBC_SG(0x100, 1);
+            if (k < MT + NT) LBC_SG(0x100, 1);
             LBC_SG(0x036, 10);                    // VALU | SALU | VMEM: the address arithmetic and DMA pieces of tile t + NBUF
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -561,7 +290,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, con
         const char* bn = smem + on;
 #pragma unroll
         for (int g = 0; g + 1 < KS; ++g) {
-            if constexpr (EARLY) { LBC_STEP_EARLY(ob, on, g); continue; }
             LBC_RD(bb, g + 1, (g + 1) & 1);
             LBC_MM(g & 1);
             LBC_MIX();
@@ -571,24 +299,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void conv_glds2_k(IgemmArgs a, con
         wait_tiles(left < 0 ? 0 : (left > NBUF - 2 ? NBUF - 2 : left));
         LBC_WAIT_LGKM0();
         __builtin_amdgcn_s_barrier();
-        if constexpr (EARLY) {
-            __builtin_amdgcn_sched_barrier(0);
-            if (t + 1 < nit) { LBC_RDA(0); LBC_AD(on, KS > 1 ? 1 : 0); }
-            LBC_USE((KS - 1) & 1);
-        } else {
-            if (t + 1 < nit) LBC_RD(bn, 0, 0);
-        }
+        if (t + 1 < nit) LBC_RD(bn, 0, 0);
         LBC_MM((KS - 1) & 1);
-        if constexpr (EARLY) __builtin_amdgcn_sched_barrier(0);
     }
 #undef LBC_RD
 #undef LBC_MM
 #undef LBC_MIX
-#undef LBC_AD
-#undef LBC_RDA
-#undef LBC_USE
-#undef LBC_WAIT_OLDER_READS
-#undef LBC_STEP_EARLY
 
     // ---- epilogue (conv_lds_dma.hpp): affine / bias / residual / ReLU, LDS-staged 16-byte stores, statistics / fused BN-backward reduce
     lds_dma_epilogue<BM, BN, WM, WN, MT, NT>(a, acc, smem, m0, n0, stat_tile0 + mtile, PH ? 2 : 1, oy0, ox0);
@@ -607,22 +323,14 @@ const GldsCfg kGldsCfg[kLbcGldsCfgs] = {{256, 256, 1.0}, {256, 128, 0.62}, {128,
 static bool lbc_glds_phased(const IgemmArgs& a, int mode)
 {
     return mode == 1 && a.nphase == 4 && a.S == 2 && a.ostep == 2 && a.KH == 3 && a.KW == 3 && a.P == 1 && a.H == a.LH && a.W == a.LW &&
-           a.OH == 2 * a.LH && a.OW == 2 * a.LW && a.M == a.N * a.LH * a.LW && !a.resid && !a.bnb_y && !lbc_opt_on(kOptGldsV1) &&
-           !lbc_opt_on(kOptNoGldsPhased);
+           a.OH == 2 * a.LH && a.OW == 2 * a.LW && a.M == a.N * a.LH * a.LW && !a.resid && !a.bnb_y && !lbc_opt_on(kOptNoGldsPhased);
 }
 
-// The four-wave shapes (two workgroups per CU) take a launch only where measured better: see the policy's comment
-static bool lbc_glds_wants_four_waves(const IgemmArgs& a, int mode, bool phased, int i)
-{
-    const long long pol = lbc_opt(kOptGlds4w);       // LBC_GLDS_4W: 0 = never, 1 = wherever the shape fits, default = the measured policy
-    if (pol == 0) return false;
-    if (pol == 1) return true;
-    // measured at 256 images (profiles/r03_run34_glds_four_wave_*): the phased stride-2 transposed launches gain a little (layer 2's first
-    // input gradient 133 -> 115 us on 256 x 64, layers 3 / 4 76 / 65 -> 70 / 63 on 128 x 128; step -0.07 ms); the stride-2 forwards lose
-    // 10-30 %, the 1x1 downsamples are level -- a second workgroup per CU is not what these short-K launches lack
-    (void)a; (void)mode; (void)i;
-    return phased;
-}
+// The four-wave shapes (two workgroups per CU) take a launch only where measured better (256 images, profiles/r03_run34_glds_four_wave_*):
+// the phased stride-2 transposed launches gain a little (layer 2's first input gradient 133 -> 115 us on 256 x 64, layers 3 / 4
+// 76 / 65 -> 70 / 63 on 128 x 128; step -0.07 ms); the stride-2 forwards lose 10-30 %, the 1x1 downsamples are level -- a second
+// workgroup per CU is not what those short-K launches lack
+static bool lbc_glds_wants_four_waves(bool phased) { return phased; }
 
 // Tile configuration for a launch, or -1 when the launch keeps conv_igemm.hip / conv_halo.hip.
 int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
@@ -639,7 +347,7 @@ int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
         else {
             // stride 2: gather mode of the second-generation kernel only (forward of the stride-2 convolutions and downsamples,
             // input gradient of the transposed convolutions)
-            if (a.S != 2 || mode != 0 || lbc_opt_on(kOptGldsV1) || a.OH != (a.H + 2 * a.P - a.KH) / 2 + 1 || a.OW != (a.W + 2 * a.P - a.KW) / 2 + 1) return -1;
+            if (a.S != 2 || mode != 0 || a.OH != (a.H + 2 * a.P - a.KH) / 2 + 1 || a.OW != (a.W + 2 * a.P - a.KW) / 2 + 1) return -1;
         }
     }
     // One workgroup per CU: a tile shape qualifies when it fills at least three quarters of the 256 CUs; among the shapes
@@ -652,10 +360,10 @@ int lbc_conv_glds_pick(const IgemmArgs& a, int mode)
         const GldsCfg& c = kGldsCfg[i];
         if (a.K % c.bn) continue;
         if (forced >= 0 && forced != i) continue;
-        if (i >= 5 && forced != i && !lbc_glds_wants_four_waves(a, mode, phased, i)) continue;
+        if (i >= 5 && forced != i && !lbc_glds_wants_four_waves(phased)) continue;
         // 64 output channels: the stride-1 3x3 layer is better off in conv_halo.hip (0.187 vs 0.126 ms), so this shape is chosen only when
         // pinned -- or for the phased stride-2 transposed launches (layer 2's first input gradient: 0.173 -> 0.135 ms)
-        if (c.bn == 64 && (a.K != 64 || lbc_opt_on(kOptGldsV1) || (forced != i && !phased))) continue;
+        if (c.bn == 64 && (a.K != 64 || (forced != i && !phased))) continue;
         const long long tiles = (long long)lbc_cdiv(a.M, c.bm) * (a.K / c.bn) * (phased ? 4 : 1);
         if (tiles < fill) continue;
         const double score = c.eff * (double)tiles / (double)(((tiles + 255) / 256) * 256);
@@ -677,21 +385,13 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     if (rc) return rc;
     const bool phased = lbc_glds_phased(a, mode);
     const dim3 grid((unsigned)(lbc_cdiv(a.M, c.bm) * (a.K / c.bn) * (phased ? 4 : 1)));
-    // LBC_GLDS_DIAG (timing experiments only, results are wrong): 1 = no DMA stream in the main loop, 2 = every DMA piece from the
-    // zero page, 3 = the activation pieces from the zero page
-    const int diag = lbc_opt(kOptGldsDiag) > 0 ? (int)lbc_opt(kOptGldsDiag) : 0;
-    if (!lbc_opt_on(kOptGldsV1)) {
-        LBC_REQUIRE(a.C % 32 == 0, "conv_glds: channel count");
-        // K-tile depth: 64 channels (whole cache lines per DMA row, half the barriers), except the 512 x 128 shape on >= 128
-        // channels (measured at batch 256: layer 2 0.098 ms with 32-channel tiles, 0.104 with 64; everything else equal or
-        // better with 64); LBC_GLDS_KT = 32 / 64 pins one
-        const bool kt64 = lbc_opt(kOptGldsKt) > 0 ? lbc_opt(kOptGldsKt) != 32 : !(cfg == kLbcCfgGlds + 3 && a.C >= 128);
+    LBC_REQUIRE(a.C % 32 == 0, "conv_glds: channel count");
+    // K-tile depth: 64 channels (whole cache lines per DMA row, half the barriers), except the 512 x 128 shape on >= 128
+    // channels (measured at batch 256: layer 2 0.098 ms with 32-channel tiles, 0.104 with 64; everything else equal or better with 64)
+    const bool kt64 = !(cfg == kLbcCfgGlds + 3 && a.C >= 128);
 #define LBC_GL2(BMv, BNv, WMv, WNv)                                                                                          \
     do {                                                                                                                     \
-        if (kt64 && early) {                                                                                                 \
-            if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64, 0, 0, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero); \
-            else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 0, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero); \
-        } else if (kt64) {                                                                                                   \
+        if (kt64) {                                                                                                          \
             if (mode == 0) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 0, 64>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);    \
             else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);    \
         } else {                                                                                                             \
@@ -699,52 +399,25 @@ int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
             else           hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 32>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);    \
         }                                                                                                                    \
     } while (0)
-        const bool early = lbc_opt_on(kOptHdmaEarly);
-        const long long dg = lbc_opt(kOptGldsDiag);
-        if (dg > 0 && cfg == kLbcCfgGlds + 0 && mode == 0) {        // 1 = no DMA stream in the steady state, 2 = every piece from the zero page
-            // 1 = no DMA stream in the steady state, 2 = every piece from the zero page, 3 = activation pieces from the zero page, 4 = weight pieces
-            if (dg == 1)      hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 1>), grid, dim3(512), 0, s, a, zero);
-            else if (dg == 2) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 2>), grid, dim3(512), 0, s, a, zero);
-            else if (dg == 3) hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 3>), grid, dim3(512), 0, s, a, zero);
-            else              hipLaunchKernelGGL((conv_glds2_k<256, 256, 2, 4, 0, 64, 4>), grid, dim3(512), 0, s, a, zero);
-            return lbc_check_launch("conv_glds2");
-        }
-        if (phased) {
-#define LBC_GLP(BMv, BNv, WMv, WNv)                                                                                          \
-    do {                                                                                                                     \
-        if (early) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);   \
-        else       hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 0, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero);      \
-    } while (0)
-            if (cfg == kLbcCfgGlds + 0) LBC_GLP(256, 256, 2, 4);
-            else if (cfg == kLbcCfgGlds + 1) LBC_GLP(256, 128, 4, 2);
-            else if (cfg == kLbcCfgGlds + 2) LBC_GLP(128, 256, 2, 4);
-            else if (cfg == kLbcCfgGlds + 3) LBC_GLP(512, 128, 4, 2);
-            else if (cfg == kLbcCfgGlds + 4) LBC_GLP(512, 64, 8, 1);
-            else if (cfg == kLbcCfgGlds + 5) LBC_GLP(256, 64, 4, 1);
-            else LBC_GLP(128, 128, 2, 2);
+    if (phased) {
+#define LBC_GLP(BMv, BNv, WMv, WNv) hipLaunchKernelGGL((conv_glds2_k<BMv, BNv, WMv, WNv, 1, 64, 1>), grid, dim3(WMv * WNv * 64), 0, s, a, zero)
+        if (cfg == kLbcCfgGlds + 0) LBC_GLP(256, 256, 2, 4);
+        else if (cfg == kLbcCfgGlds + 1) LBC_GLP(256, 128, 4, 2);
+        else if (cfg == kLbcCfgGlds + 2) LBC_GLP(128, 256, 2, 4);
+        else if (cfg == kLbcCfgGlds + 3) LBC_GLP(512, 128, 4, 2);
+        else if (cfg == kLbcCfgGlds + 4) LBC_GLP(512, 64, 8, 1);
+        else if (cfg == kLbcCfgGlds + 5) LBC_GLP(256, 64, 4, 1);
+        else LBC_GLP(128, 128, 2, 2);
 #undef LBC_GLP
-            return lbc_check_launch("conv_glds2");
-        }
-        if (cfg == kLbcCfgGlds + 0) LBC_GL2(256, 256, 2, 4);
-        else if (cfg == kLbcCfgGlds + 1) LBC_GL2(256, 128, 4, 2);
-        else if (cfg == kLbcCfgGlds + 2) LBC_GL2(128, 256, 2, 4);
-        else if (cfg == kLbcCfgGlds + 3) LBC_GL2(512, 128, 4, 2);
-        else if (cfg == kLbcCfgGlds + 4) LBC_GL2(512, 64, 8, 1);
-        else if (cfg == kLbcCfgGlds + 5) LBC_GL2(256, 64, 4, 1);
-        else LBC_GL2(128, 128, 2, 2);
-#undef LBC_GL2
         return lbc_check_launch("conv_glds2");
     }
-#define LBC_GL(BMv, BNv, WMv, WNv, NBv)                                                                                       \
-    do {                                                                                                                     \
-        if (mode == 0) hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 0>), grid, dim3(512), 0, s, a, zero, diag);        \
-        else           hipLaunchKernelGGL((conv_glds_k<BMv, BNv, WMv, WNv, NBv, 1>), grid, dim3(512), 0, s, a, zero, diag);        \
-    } while (0)
-    if (cfg == kLbcCfgGlds + 0) LBC_GL(256, 256, 2, 4, 2);
-    else if (cfg == kLbcCfgGlds + 1) LBC_GL(256, 128, 4, 2, 3);
-    else if (cfg == kLbcCfgGlds + 2) LBC_GL(128, 256, 2, 4, 3);
-    else if (cfg == kLbcCfgGlds + 3) LBC_GL(512, 128, 4, 2, 2);
-    else { lbc_set_error("conv_glds: the 512 x 64 and four-wave shapes exist in the second-generation kernel only"); return LBC_EINVAL; }
-#undef LBC_GL
-    return lbc_check_launch("conv_glds");
+    if (cfg == kLbcCfgGlds + 0) LBC_GL2(256, 256, 2, 4);
+    else if (cfg == kLbcCfgGlds + 1) LBC_GL2(256, 128, 4, 2);
+    else if (cfg == kLbcCfgGlds + 2) LBC_GL2(128, 256, 2, 4);
+    else if (cfg == kLbcCfgGlds + 3) LBC_GL2(512, 128, 4, 2);
+    else if (cfg == kLbcCfgGlds + 4) LBC_GL2(512, 64, 8, 1);
+    else if (cfg == kLbcCfgGlds + 5) LBC_GL2(256, 64, 4, 1);
+    else LBC_GL2(128, 128, 2, 2);
+#undef LBC_GL2
+    return lbc_check_launch("conv_glds2");
 }

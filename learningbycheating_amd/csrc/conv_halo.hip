@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_c64_k(IgemmArgs a)
 
 bool lbc_conv3x3_halo_eligible(const IgemmArgs& a, int mode)
 {
-    return !lbc_opt_on(kOptNoHalo) && a.w_bf16 && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.ostep == 1 && a.oy0 == 0 &&
+    return a.w_bf16 && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.ostep == 1 && a.oy0 == 0 &&
            a.ox0 == 0 && a.C == 64 && a.K == 64 && a.H == a.OH && a.W == a.OW && a.M == a.N * a.H * a.W &&
            128 + 2 * a.W + 2 <= kHaloRowsMax && (mode == 0 || mode == 1);
 }

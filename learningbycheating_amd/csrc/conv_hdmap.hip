@@ -2,12 +2,13 @@
 // the 15 instantiations compile in parallel).
 #include "lbc_common.hpp"
 #include "lbc_act.hpp"
-#include "conv_hdmap.hpp"      // (hdmap_pre_channels<>: nothing is instantiated here)
+#include "conv_hdmap.hpp"      // (nothing is instantiated here)
 
 int lbc_conv_hdmap_launch_256x128_320(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_256x128_384(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_128x256_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_128x64_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s, int nsplit);
+int lbc_conv_hdmap_launch_128x128_256(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 
 namespace {
 
@@ -26,6 +27,7 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_k(IgemmArgs a, const 
     __bf16* y = static_cast<__bf16*>(a.y);
     const __bf16* resid = static_cast<const __bf16*>(a.resid);
     const __bf16* by = static_cast<const __bf16*>(a.bnb_y);
+    const __bf16* bmask = static_cast<const __bf16*>(a.bnb_mask);      // (nullptr: the mask is bn(bnb_y) > 0)
     size_t o[4];
     bool live[4];
     f32x8 v[4];
@@ -42,7 +44,7 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_k(IgemmArgs a, const 
     f32x8 u1 = ParamVec<8>::splat(0.f), u2 = u1;
     f32x8 bsc = u1, bsh = u1, bmu = u1, biv = u1;
     if constexpr (FUSED) {
-        bsc = ParamVec<8>::ld(a.bnb_scale + col); bsh = ParamVec<8>::ld(a.bnb_shift + col);
+        if (!bmask) { bsc = ParamVec<8>::ld(a.bnb_scale + col); bsh = ParamVec<8>::ld(a.bnb_shift + col); }
         bmu = ParamVec<8>::ld(a.bnb_mean + col); biv = ParamVec<8>::ld(a.bnb_invstd + col);
     }
     const f32x8 psc = a.post_scale ? ParamVec<8>::ld(a.post_scale + col) : ParamVec<8>::splat(1.f);
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_k(IgemmArgs a, const 
         if constexpr (FUSED) {
             const f32x8 yf = __builtin_convertvector(*reinterpret_cast<const bf16x8*>(by + o[q]), f32x8);
             f32x8 g = __builtin_convertvector(ch, f32x8);
-            const f32x8 z = yf * bsc + bsh;
+            const f32x8 z = bmask ? __builtin_convertvector(*reinterpret_cast<const bf16x8*>(bmask + o[q]), f32x8) : yf * bsc + bsh;
 #pragma unroll
             for (int e = 0; e < 8; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
             ch = __builtin_convertvector(g, bf16x8);
@@ -108,36 +110,28 @@ int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
     const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64), elems = (long long)a.M * a.K;
     auto fits = [&](long long n) { return n > 1 && nslab % n == 0 && elems * n <= a.split_ws_floats && elems * n < (1ll << 31); };
     if (opt > 1) return fits(opt) ? (int)opt : 1;
-    const long long max_tiles = lbc_opt(kOptHdmapSplitMaxTiles) > 0 ? lbc_opt(kOptHdmapSplitMaxTiles) : 64;
-    if (tiles > max_tiles || nslab < 8) return 1;
+    if (tiles > 64 || nslab < 8) return 1;
     return fits(4) ? 4 : 1;
 }
 
-// Persistent form of conv_hdma.hip's cfg 1 (256 x 128) and cfg 2 (128 x 256); false = the launch keeps conv_hdma_k
-// (BatchNorm-on-load, the 256 x 256 test shape, LBC_NO_HDMA_PERSIST=1).
+// Which launches the persistent kernel takes (cfg 1: 256 x 128, 2: 128 x 256, 4: 128 x 64 on four waves, 5: 128 x 128)
 bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg)
 {
-    if (lbc_opt_on(kOptNoHdmaPersist) || (mode != 0 && mode != 1)) return false;
-    if (a.bnb_y && (mode != 1 || a.resid)) return false;
-    if (a.pre_scale) {
-        // BatchNorm-on-load (conv_hdmap_k<.., PRE>; LBC_HDMAP_PRE=1): plain forward, and the coefficient table must fit next to the shape's LDS
-        if (!lbc_opt_on(kOptHdmapPre) || mode != 0 || a.resid || a.bnb_y) return false;
-        const int pc = cfg == kLbcCfgHdma + 1 ? (256 + 2 * a.W + 2 <= 320 - 8 ? hdmap_pre_channels<256, 128, 4, 2, 320, 16>() : hdmap_pre_channels<256, 128, 4, 2, 384, 8>())
-                       : cfg == kLbcCfgHdma + 2 ? hdmap_pre_channels<128, 256, 2, 4, 192, 8>()
-                       : cfg == kLbcCfgHdma + 4 ? hdmap_pre_channels<128, 64, 2, 2, 192, 16>() : 0;
-        if (a.C > pc) return false;
-    }
+    if (mode != 0 && mode != 1) return false;
+    if (a.pre_scale) return false;                       // no BatchNorm-on-load form (conv_hdma.hip)
+    if (a.bnb_y && (mode != 1 || (a.resid != nullptr) != (a.bnb_mask != nullptr))) return false;      // (form 2: no residual; form 4: residual + mask tensor)
     // the halo (BM + 2W + 2 rows) must end at least 8 rows before its LDS buffer does: the last 8-row DMA piece then comes from the
     // zero page as a whole and holds the zero row of the border select
     if (cfg == kLbcCfgHdma + 1) return 256 + 2 * a.W + 2 <= 384 - 8;
     if (cfg == kLbcCfgHdma + 2 || cfg == kLbcCfgHdma + 4) return 128 + 2 * a.W + 2 <= 192 - 8;
+    if (cfg == kLbcCfgHdma + 5) return 128 + 2 * a.W + 2 <= 256 - 8;
     return false;
 }
 
 int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
 {
     LBC_REQUIRE(lbc_conv_hdmap_eligible(a, mode, cfg), "conv_hdmap: launch not eligible");
-    const int bm = cfg == kLbcCfgHdma + 1 ? 256 : 128, bn = cfg == kLbcCfgHdma + 1 ? 128 : (cfg == kLbcCfgHdma + 4 ? 64 : 256);
+    const int bm = cfg == kLbcCfgHdma + 1 ? 256 : 128, bn = (cfg == kLbcCfgHdma + 1 || cfg == kLbcCfgHdma + 5) ? 128 : (cfg == kLbcCfgHdma + 4 ? 64 : 256);
     LBC_REQUIRE(a.K % bn == 0 && a.C % 64 == 0, "conv_hdmap: shape not tileable");
     const void* zero = nullptr;
     int rc = lbc_zero_page(&zero);
@@ -161,5 +155,6 @@ int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
         return lbc_conv_hdmap_launch_256x128_384(a, mode, zero, ntiles, tpw, grid, s);
     }
     if (cfg == kLbcCfgHdma + 4) return lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, tpw, grid, s, 1);
+    if (cfg == kLbcCfgHdma + 5) return lbc_conv_hdmap_launch_128x128_256(a, mode, zero, ntiles, tpw, grid, s);
     return lbc_conv_hdmap_launch_128x256_192(a, mode, zero, ntiles, tpw, grid, s);
 }

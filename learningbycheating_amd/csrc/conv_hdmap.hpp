@@ -39,35 +39,28 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p)
 
 // EPI: 0 = plain epilogue (affine / bias / ReLU / statistics), 1 = + residual, 2 = fused BatchNorm-backward reduce (IgemmArgs::bnb_*).
 // One instantiation per form: the residual prefetch (64 registers) and the BatchNorm-backward operands (64) never coexist.
+// EPI 4 (round 5) = 1 + 2 with the mask from a tensor: the input gradient of a block's conv1 (+ the identity-path gradient as residual) IS
+// the gradient wrt the previous block's output relu(bn2(y2) + identity); masking it with that output (IgemmArgs::bnb_mask > 0) and summing
+// (g, g * xhat(y2)) here removes the previous block's whole channel_reduce pass (three tensors read, one written).  The residual is added
+// to the f32 accumulator as in form 1 (same rounding as the unfused path), mask and sums happen in the chunk phase as in form 2.
+// KG = 2 (round 5; four-wave shape, launches of at most one tile per CU): an IN-WORKGROUP split of the channel contraction.  A launch with
+// <= 256 tiles of 128 x 64 puts one four-wave workgroup on a CU -- one wave per SIMD, nothing hides that wave's LDS / DMA-issue / barrier
+// latencies, and the serial K loop (36 - 72 K-tiles) IS the launch (layers 3 / 4 at 32 images per GPU: 15 / 22 us for 5.4 GFLOP).  With
+// KG = 2 the workgroup has eight waves = two independent instances of the four-wave pipeline (own halo buffers, own weight ring, own
+// staging: 2 x 78 KB of LDS), instance g contracting the slabs [g * nslab, (g + 1) * nslab); they share nothing but the workgroup
+// barriers (same K-tile count, same control flow).  After the K loop instance 1 hands its accumulators over through LDS (its halo
+// buffers are free by then), instance 0 adds them in a fixed order and does the epilogue: half the K loop, no partial tiles in HBM and
+// no second launch (what form 3 pays).  One tile per workgroup (the launcher guarantees it).
 // EPI 3 = split-K (round 4; launches with few tiles, i.e. the deep layers at the per-GPU batches of the 8-GPU run): workgroup p serves
 // (tile p / nsplit, slab range p % nsplit), contracts C / nsplit of the gathered channels and leaves its accumulators as an f32 partial
 // tile in IgemmArgs::split_ws [range][M][K]; conv_split_epilogue_k (conv_hdmap.hip) sums the ranges in a fixed order and does the
 // epilogue of form 0 / 1 / 2.  One tile per workgroup (the launcher guarantees ntiles * nsplit workgroups).
-// PRE (forward, plain epilogue; behind LBC_HDMAP_PRE=1 until it is measured): the producer's BatchNorm + ReLU applied to the input
-// (IgemmArgs::pre_*; a block's conv2 reads the raw conv1 output, resnet.py:38-54) as an in-place transform of the staged halo.  The
-// lane that requested a 16-byte piece of the NEXT slab's halo (8 channels of one row) transforms exactly those 16 bytes once they have
-// landed -- no other lane is involved, so the slab's closing barrier is the only synchronization it needs: the piece requested in
-// K-tile s is read back in the tail of K-tile s + 2 (the counted vmcnt wait in front of that K-tile's barrier covers it), transformed
-// and written under the MFMAs of K-tile s + 3.  The halo pieces are therefore requested in the first three K-tiles of a slab (ATAPS 4),
-// and the per-channel scale / shift sit in an LDS table (filled once; 2 x 8 floats per lane and slab re-read into registers).  The
-// extra LDS operations sit between the hand-counted fragment reads: a counted lgkmcnt wait can only become stricter by them.
-// PROF (diagnostic builds, LBC_HDMAP_PROF = device address of 8 x u64 per wave): s_memtime stamps around the waits of every K-tile;
-// per wave: [0] K-tiles, [1] cycles in the three leading depth steps, [2] in the vmcnt wait, [3] in lgkmcnt(0) + barrier, [4] in the
-// tail (step-0 reads of the next K-tile, last depth step, DMA issue), [5] in epilogues, [6] whole stream, [7] tiles
 template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
 constexpr int hdmap_lds_bytes() { return 2 * HRMAX * 128 + 3 * BN * 128 + WM * WN * SROWS * ((BN / WN) * 2 + 16) + WM * 2 * BN * 4; }
-// gathered channels the PRE form's LDS table has room for (the 384-row halo of layer 2 leaves 2 KB: 256 channels; so does the four-wave shape)
-template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
-constexpr int hdmap_pre_channels()
+template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, int KG = 1>
+__global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, const int nsplit)
 {
-    constexpr int used = hdmap_lds_bytes<BM, BN, WM, WN, HRMAX, SROWS>();
-    constexpr int room = WM * WN == 4 ? 80 * 1024 : 160 * 1024;          // (the four-wave shape must stay at two workgroups per CU)
-    return used + 4096 <= room ? 512 : (used + 2048 <= room ? 256 : (used + 1024 <= room ? 128 : 0));
-}
-
-template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EPI, bool PROF = false, int VAR = 0, bool PRE = false>
-__global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || (PRE && WM * WN == 8)) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, unsigned long long* prof, const int nsplit)
-{
+    static_assert(KG == 1 || (KG == 2 && WM * WN == 4 && EPI != 3), "conv_hdmap: the in-workgroup K split doubles the four-wave shape");
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
     constexpr int NW = WM * WN;                                 // waves per workgroup: 8 (256 x 128 / 128 x 256 tiles, one workgroup per CU) or
@@ -77,7 +70,6 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
     static_assert((NW == 8 || NW == 4) && (NT == 2 || NT == 1) && (MT == 2 || MT == 4), "conv_hdmap: wave tiling");
     static_assert(HRMAX % (8 * NW) == 0 && BN % (8 * NW) == 0 && (SROWS == 8 || SROWS == 16), "conv_hdmap: staging");
     constexpr int NB = 3;                                       // weight ring depth: slot of K-tile (slab, tap) = tap % 3 (9 taps per slab)
-    constexpr bool PRIO = (VAR & 1) != 0;                       // A/B variants: 1 = priority alternation, 2 = DMA pieces in the tail (one burst), 4 = reads interleaved with the MFMAs
     constexpr int KS = 4;                                       // depth steps of 16 channels per K-tile
     constexpr int ABYTES = HRMAX * 128;                         // one halo buffer: HRMAX rows x 64 channels
     constexpr int TILE_B = BN * 128;
@@ -85,17 +77,14 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
     constexpr int SROW_B = WTN * 2 + 16;                        // LDS pitch of a staged row (64 bf16 + 16 bytes); SROWS rows per copy-out step
     constexpr int STG = BRING + NB * TILE_B;                    // wave-private staging: NW x SROWS x SROW_B
     constexpr int RED = STG + NW * SROWS * SROW_B;              // [WM][2][BN] floats
-    constexpr int PTAB = RED + WM * 2 * BN * 4;                 // PRE: [2][PRE_C] floats, scale then shift of the gathered channels
-    constexpr int PRE_C = PRE ? hdmap_pre_channels<BM, BN, WM, WN, HRMAX, SROWS>() : 0;
-    static_assert(!PRE || (MODE == 0 && EPI == 0 && PRE_C > 0 && (VAR & 8) != 0), "conv_hdmap: BatchNorm-on-load is a form of the plain forward");
-    static_assert(PTAB == hdmap_lds_bytes<BM, BN, WM, WN, HRMAX, SROWS>(), "conv_hdmap: LDS layout");
-    constexpr int SMEM = PTAB + 2 * PRE_C * 4;
+    constexpr int SMEM = RED + WM * 2 * BN * 4;
+    static_assert(SMEM == hdmap_lds_bytes<BM, BN, WM, WN, HRMAX, SROWS>(), "conv_hdmap: LDS layout");
     constexpr int ZROW = (HRMAX - 1) * 128;                     // last row of either halo buffer: beyond the halo, filled from the zero page
-    static_assert(SMEM <= 160 * 1024, "conv_hdmap: LDS");
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];    // the ONLY LDS object
+    static_assert(SMEM * KG <= 160 * 1024, "conv_hdmap: LDS");
+    __shared__ __attribute__((aligned(16))) char smem_all[SMEM * KG];    // the ONLY LDS object (KG = 2: one SMEM-sized region per instance)
     constexpr int HPW = HRMAX / (8 * NW);                       // 1-KiB halo pieces (8 rows) per wave per slab
     constexpr int NBW = BN / (8 * NW);                          // 1-KiB weight pieces per wave per K-tile
-    constexpr int ATAPS = PRE ? 4 : 7;                          // taps of a slab whose issue slot may carry halo pieces of the next slab (PRE: early enough to be transformed in place before the slab ends)
+    constexpr int ATAPS = 7;                                    // taps of a slab whose issue slot may carry halo pieces of the next slab
     constexpr int PPT = (HPW + ATAPS - 1) / ATAPS;              // halo pieces of the next slab requested per tap (taps 0 .. ATAPS - 1)
     static_assert(PPT >= 1 && PPT <= 2, "conv_hdmap: halo pieces per tap");
     constexpr int NSTEP = WTM / SROWS;                          // copy-out steps per wave and tile
@@ -104,14 +93,17 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
     constexpr int RPP = 64 / SEGS;                              // rows per copy-out pass of the wave
     constexpr int NST = NSTEP * CPL;                            // 16-byte store instructions per wave and tile
 
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wave_all = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+    const int grp = KG == 2 ? wave_all / NW : 0;                 // K-split instance of this wave
+    const int wave = KG == 2 ? wave_all % NW : wave_all;         // its role inside the instance
+    const int tid = wave * 64 + lane;                           // thread id inside the instance
+    char* const smem = smem_all + grp * SMEM;
     const int wm = wave / WN, wn = wave % WN;
-    const int upper = wave / (NW / 2);      // the younger half of the workgroup's waves
     const int l31 = lane & 31, kh = lane >> 5;
     const int W = a.W, H = a.H, C = a.C;
     const int ntn = a.K / BN;
-    const int nslab = EPI == 3 ? C / 64 / nsplit : C / 64;     // slabs (64 gathered channels) this workgroup contracts
+    const int nslab = EPI == 3 ? C / 64 / nsplit : C / 64 / KG;     // slabs (64 gathered channels) this workgroup (KG = 2: this instance) contracts
 
     // this workgroup's tiles: [first, first + cnt), consecutive ids share the M-tile
     int first, cnt, split = 0;
@@ -131,8 +123,8 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
     if (cnt <= 0) return;
 
     // (split-K: the range's first slab is folded into the operand bases -- 128 bytes per slab in a pixel's row and in a weight row)
-    const __bf16* xin = static_cast<const __bf16*>(a.x) + (EPI == 3 ? split * nslab * 64 : 0);
-    const __bf16* win = static_cast<const __bf16*>(a.w) + (EPI == 3 ? split * nslab * 64 : 0);
+    const __bf16* xin = static_cast<const __bf16*>(a.x) + (EPI == 3 ? split * nslab * 64 : (KG == 2 ? grp * nslab * 64 : 0));
+    const __bf16* win = static_cast<const __bf16*>(a.w) + (EPI == 3 ? split * nslab * 64 : (KG == 2 ? grp * nslab * 64 : 0));
     const int prow = lane >> 3, pseg = lane & 7;
 
     // ---- DMA roles: per-thread constants + a wave-uniform origin per piece (the issue slots sit next to MFMAs that leave room
@@ -224,13 +216,13 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
     };
 
     bf16x8 fa[2][MT], fb[2][NT];            // two register sets: depth step g computes from set g & 1 while set (g + 1) & 1 is read
-    // ASMRD (VAR & 8): the fragment reads are inline asm the compiler does not track, waited for with hand-counted lgkmcnt.  With LDS-DMA
+    // ASMRD: the fragment reads are inline asm the compiler does not track, waited for with hand-counted lgkmcnt.  With LDS-DMA
     // in flight hipcc's own wait insertion puts `s_waitcnt lgkmcnt(0)` in front of every depth step's MFMAs -- which also waits for the
     // reads of the NEXT step issued just before it: a full LDS latency per depth step that only the SIMD's other wave can cover.  Here
     // the wait in front of step g leaves the MT + NT youngest reads (step g + 1) in flight; LBC_USE (an empty asm the MFMAs depend on)
     // keeps the MFMAs behind that wait.
-    constexpr bool ASMRD = (VAR & 8) != 0 && NB * TILE_B + (NT - 1) * 4096 < 65536;
-    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+    constexpr bool ASMRD = NB * TILE_B + (NT - 1) * 4096 < 65536;     // (the ring slot is an immediate offset of the read)
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem_all + (unsigned)(grp * SMEM);
 #ifdef LBC_HIP_EMULATED_FOR_TESTS
 #define LBC_RD1(DST, ADDR, OFF) DST = *reinterpret_cast<const bf16x8*>(smem + (ADDR) + (OFF))
 #define LBC_USE(SET) do { } while (0)
@@ -263,49 +255,6 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);                 \
     } while (0)
 
-    // ---- PRE: in-place BatchNorm (+ ReLU) of the halo pieces this lane requested.  16-byte LDS accesses of the same kind as the fragment
-    //      reads (inline asm with ASMRD: ordered among themselves and with the fragment reads, not tracked by the compiler)
-#ifdef LBC_HIP_EMULATED_FOR_TESTS
-#define LBC_LDS_RD16(DST, ADDR) DST = *reinterpret_cast<const std::remove_reference_t<decltype(DST)>*>(smem + (ADDR))
-#define LBC_LDS_WR16(ADDR, SRC) *reinterpret_cast<std::remove_cv_t<std::remove_reference_t<decltype(SRC)>>*>(smem + (ADDR)) = (SRC)
-#define LBC_FENCE(V) do { } while (0)
-#else
-#define LBC_LDS_RD16(DST, ADDR)                                                                                                  \
-    do {                                                                                                                         \
-        if constexpr (ASMRD) asm volatile("ds_read_b128 %0, %1" : "=v"(DST) : "v"(lds0 + (unsigned)(ADDR)));                     \
-        else DST = *reinterpret_cast<const std::remove_reference_t<decltype(DST)>*>(smem + (ADDR));                                                       \
-    } while (0)
-#define LBC_LDS_WR16(ADDR, SRC)                                                                                                  \
-    do {                                                                                                                         \
-        if constexpr (ASMRD) asm volatile("ds_write_b128 %0, %1" : : "v"(lds0 + (unsigned)(ADDR)), "v"(SRC) : "memory");         \
-        else *reinterpret_cast<std::remove_cv_t<std::remove_reference_t<decltype(SRC)>>*>(smem + (ADDR)) = (SRC);                                                           \
-    } while (0)
-#define LBC_FENCE(V) do { if constexpr (ASMRD) asm volatile("" : "+v"(V)); } while (0)
-#endif
-    // channel chunk (8 channels) of the lane's 16 bytes in pieces with even / odd index (the swizzle of the DMA source, aswz above)
-    const int pcs[2] = {pseg ^ ((arow0 >> 1) & 7), pseg ^ (((arow0 >> 1) + 4) & 7)};
-    f32x4 pco[PRE ? 2 : 1][4];              // [piece parity][scale lo, scale hi, shift lo, shift hi] of the slab being transformed
-    const float pfloor = a.pre_relu ? 0.f : -INFINITY;
-    auto pre_coef = [&](const int slab) {   // (consumed two K-tiles later at the earliest: behind at least one lgkmcnt(0) + barrier)
-#pragma unroll
-        for (int par = 0; par < 2; ++par) {
-            const int o = PTAB + (slab * 64 + pcs[par] * 8) * 4;
-            LBC_LDS_RD16(pco[par][0], o); LBC_LDS_RD16(pco[par][1], o + 16);
-            LBC_LDS_RD16(pco[par][2], o + PRE_C * 4); LBC_LDS_RD16(pco[par][3], o + PRE_C * 4 + 16);
-        }
-    };
-    auto pre_piece_addr = [&](const int buf, const int j) { return buf * ABYTES + (wave * HPW + j) * 1024 + lane * 16; };
-    auto pre_pad = [&](const int j) { return (wave * HPW + j) * 8 >= HR; };            // wave-uniform: the piece came from the zero page
-    auto pre_xform = [&](const bf16x8 raw, const int par) {
-        const f32x8 v = __builtin_convertvector(raw, f32x8);
-        f32x4 lo = __builtin_shufflevector(v, v, 0, 1, 2, 3) * pco[par][0] + pco[par][2];
-        f32x4 hi = __builtin_shufflevector(v, v, 4, 5, 6, 7) * pco[par][1] + pco[par][3];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) { lo[e] = fmaxf(lo[e], pfloor); hi[e] = fmaxf(hi[e], pfloor); }
-        return __builtin_convertvector(__builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7), bf16x8);
-    };
-    bf16x8 pxr[PRE ? PPT : 1];              // pieces read back in a K-tile's tail, transformed in the next K-tile
-
     // s_waitcnt vmcnt(n) for the handful of counts the stream produces (the immediate must be a constant)
     auto wait_vm = [&](const int n) {
         switch (n) {
@@ -324,46 +273,16 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
     int sg = 0;                             // slabs consumed so far: halo buffer sg & 1
     tap_mask(m0, amask);
 
-    if constexpr (PRE) {                    // the coefficient table, visible to every wave before the first piece is transformed
-        float* tab = reinterpret_cast<float*>(smem + PTAB);
-        for (int i = tid; i < C; i += NW * 64) { tab[i] = a.pre_scale[i]; tab[PRE_C + i] = a.pre_shift[i]; }
-        LBC_WAIT_LGKM0();
-        __builtin_amdgcn_s_barrier();
-    }
     // prologue: the halo of slab 0 and the first two weight tiles in flight; everything of K-tile 0 landed and visible
 #pragma unroll
     for (int j = 0; j < HPW; ++j) issue_a(m0, 0, 0, j);
     issue_b(n0, 0, 0, 0, 0, NBW);
     issue_b(n0, 0, 1, 1, 0, NBW);
     LBC_WAIT_VM(NBW);
-    if constexpr (PRE) {                    // the first halo: all of this wave's pieces at once
-        bf16x8 x0[HPW];
-        pre_coef(0);
-#pragma unroll
-        for (int j = 0; j < HPW; ++j)
-            if (!pre_pad(j)) LBC_LDS_RD16(x0[j], pre_piece_addr(0, j));
-        LBC_WAIT_LGKM0();
-#pragma unroll
-        for (int par = 0; par < 2; ++par)
-#pragma unroll
-            for (int q = 0; q < 4; ++q) LBC_FENCE(pco[par][q]);
-#pragma unroll
-        for (int j = 0; j < HPW; ++j)
-            if (!pre_pad(j)) { LBC_FENCE(x0[j]); const bf16x8 t = pre_xform(x0[j], j & 1); LBC_LDS_WR16(pre_piece_addr(0, j), t); }
-        LBC_WAIT_LGKM0();
-    }
     __builtin_amdgcn_s_barrier();
     tap_addr(0, 0, amask);
     LBC_RD(0, 0, 0);
     bool stores_pending = false;            // the previous tile's output stores may still be in this wave's VMEM queue
-    unsigned long long pf_steps = 0, pf_vm = 0, pf_bar = 0, pf_tail = 0, pf_epi = 0, pf_kt = 0, pf_t0 = 0, pf_prev = 0;
-#ifdef LBC_HIP_EMULATED_FOR_TESTS
-#define LBC_NOW() 0ull
-#else
-#define LBC_NOW() __builtin_amdgcn_s_memtime()
-#endif
-    if (PROF) { pf_t0 = LBC_NOW(); pf_prev = pf_t0; }
-
     for (int it = 0; it < cnt; ++it) {
         const bool more = it + 1 < cnt;
         const int tilen = tile + 1;
@@ -406,9 +325,6 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                 };
 #pragma unroll
                 for (int g = 0; g + 1 < KS; ++g) {
-                    if (PRIO) {     // the two waves of a SIMD take turns at the matrix pipe (equal priority = the older wave always wins)
-                        if ((g & 1) == upper) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                    }
                     LBC_RD(slot, g + 1, (g + 1) & 1);
                     // the reads of the last depth step are out: the addresses are free for the next K-tile's (tap, slab, tile)
                     if (g == KS - 2 && has_next) {
@@ -416,95 +332,73 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                         else if (!LAST) tap_addr(0, buf ^ 1, amask);
                         else tap_addr(0, buf ^ 1, amaskn);
                     }
-                    if (!(VAR & 2)) {
-                        if (g == 0) issue_w(0, NBW / 2);
-                        else if (g == 1) issue_w(NBW / 2, NBW);
-                        else issue_h();
-                    }
+                    if (g == 0) issue_w(0, NBW / 2);
+                    else if (g == 1) issue_w(NBW / 2, NBW);
+                    else issue_h();
                     LBC_WAIT_OLDER_READS();                              // set g & 1 is in (its reads were issued a full step ago)
                     LBC_USE(g & 1);
-                    if constexpr (PRE) {
-                        // the pieces requested in K-tile t - 3, read back in the tail of K-tile t - 1 (older than this step's fragment reads:
-                        // the wait above covers them): transform, write back -- complete by this K-tile's lgkmcnt(0) + barrier
-                        if (g == 0 && t >= 3 && follows) {
-#pragma unroll
-                            for (int q = 0; q < PPT; ++q)
-                                if ((t - 3) * PPT + q < HPW && !pre_pad((t - 3) * PPT + q)) {
-                                    LBC_FENCE(pxr[q]);
-                                    const bf16x8 tq = pre_xform(pxr[q], ((t - 3) * PPT + q) & 1);
-                                    LBC_LDS_WR16(pre_piece_addr(buf ^ 1, (t - 3) * PPT + q), tq);
-                                }
-                        }
-                    }
                     LBC_MM(g & 1);
-                    if (VAR & 4) {
+                    // the step's fragment reads first: a full step of MFMAs (128 cycles of this wave's own, 256 with its SIMD
+                    // partner) between a read and the wait that needs it -- a wave that runs alone no longer stalls on LDS latency
+                    LBC_SG(0x100, MT + NT);
 #pragma unroll
-                        for (int q = 0; q < MT + NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x100, 1); LBC_SG(0x036, 4); }
-                    } else {
-                        // the step's fragment reads first: a full step of MFMAs (128 cycles of this wave's own, 256 with its SIMD
-                        // partner) between a read and the wait that needs it -- a wave that runs alone no longer stalls on LDS latency
-                        LBC_SG(0x100, MT + NT);
-#pragma unroll
-                        for (int q = 0; q < MT * NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x036, 5); }
-                    }
+                    for (int q = 0; q < MT * NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x036, 5); }
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                unsigned long long pf_a = 0, pf_b = 0, pf_c = 0;
-                if (PROF) { LBC_WAIT_LGKM0(); pf_a = LBC_NOW(); }
                 // The weight tile of K-tile k + 1 (requested during K-tile k - 1) has landed, this wave's pieces.  Requested after it and
                 // allowed to stay in flight: the halo piece of K-tile k - 1, this K-tile's weight tile and halo piece -- and, in the first
                 // K-tile behind a tile boundary, the previous tile's stores (they sit between K-tile k - 1's requests and this one's)
                 {
                     int n = 0;
-                    if (VAR & 2) {      // burst variant: the requests of K-tile k - 1 came after its wait: [halo piece][weight tile k + 1] -> all landed
-                        n = (c == 0 && t == 0 && stores_pending) ? NST : 0;
-                    } else if (w2) {
+                    if (w2) {
                         n = NBW + (follows ? np_prev + np_here : 0);
                         if (c == 0 && t == 0 && stores_pending) n += NST;
                     }
                     wait_vm(n);
                 }
-                if (PROF) pf_b = LBC_NOW();
                 LBC_WAIT_LGKM0();
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-                if (PROF) pf_c = LBC_NOW();
-                if (PRIO) {
-                    if (((KS - 1) & 1) == upper) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-                }
                 if (has_next) LBC_RD(nslot, 0, 0);
-                if constexpr (PRE) {
-                    if (follows) {
-                        if (t == 0) pre_coef(LAST ? 0 : c + 1);          // (the previous slab's last piece was transformed in its K-tile 5)
-                        if (t >= 2) {
-                            // the pieces requested in K-tile t - 2 have landed (the vmcnt wait in front of this K-tile's barrier left only
-                            // the requests of K-tiles t - 1 and t in flight): read them back, behind the next K-tile's step-0 fragments
-#pragma unroll
-                            for (int q = 0; q < PPT; ++q)
-                                if ((t - 2) * PPT + q < HPW && !pre_pad((t - 2) * PPT + q)) LBC_LDS_RD16(pxr[q], pre_piece_addr(buf ^ 1, (t - 2) * PPT + q));
-                        }
-                    }
-                }
                 LBC_USE((KS - 1) & 1);                                   // in since the lgkmcnt(0) in front of the barrier
                 LBC_MM((KS - 1) & 1);
-                if (VAR & 2) {          // everything in one burst behind the barrier: K-tile k + 1's successor is K-tile k + 2 -> slot (t + 2) % 3
-                    issue_h();
-                    issue_w(0, NBW);
-                }
                 LBC_SG(0x100, MT + NT);
 #pragma unroll
                 for (int q = 0; q < MT * NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x036, 6); }
                 __builtin_amdgcn_sched_barrier(0);
-                if (PROF) {
-                    const unsigned long long pf_d = LBC_NOW();
-                    pf_steps += pf_a - pf_prev; pf_vm += pf_b - pf_a; pf_bar += pf_c - pf_b; pf_tail += pf_d - pf_c; pf_prev = pf_d; ++pf_kt;
-                }
             }
             ++sg;
         };
         for (int c = 0; c + 1 < nslab; ++c) slab_body(c, std::false_type{});
         slab_body(nslab - 1, std::true_type{});
 
+        // ---- KG = 2: instance 1's accumulators -> instance 0, through instance 1's halo buffers (idle: one tile per workgroup, nothing is
+        //      prefetched behind the last slab), [wave][register][lane] floats -- lane-contiguous, conflict-free both ways
+        if constexpr (KG == 2) {
+            static_assert(NW * MT * NT * 16 * 64 * 4 <= 2 * ABYTES, "conv_hdmap: accumulator hand-over buffer");
+            float* xch = reinterpret_cast<float*>(smem_all + SMEM) + (size_t)wave * (MT * NT * 16 * 64) + lane;
+            LBC_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();           // every wave of instance 1 has read its last fragments: its halo buffers may be overwritten
+            if (grp == 1) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) xch[((i * NT + j) * 16 + r) * 64] = acc[i][j][r];
+            }
+            LBC_WAIT_LGKM0();
+            __builtin_amdgcn_s_barrier();
+            if (grp == 0) {
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * NT + j) * 16 + r) * 64];
+            }
+        }
+        const bool epi_on = KG == 1 || grp == 0;   // (instance 1 only keeps the epilogue's workgroup barrier company)
         // ---- wave-private epilogue: affine / bias / residual / ReLU on the accumulators, 16 rows at a time through this wave's own
         //      staging rows, 16-byte stores; statistics (or the fused BatchNorm-backward sums) per tile
         if constexpr (EPI == 3) {
@@ -525,8 +419,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
             char* stg = smem + STG + wave * (SROWS * SROW_B);
             float* red = reinterpret_cast<float*>(smem + RED);
             __bf16* yout = static_cast<__bf16*>(a.y);
-            const __bf16* resid = EPI == 1 ? static_cast<const __bf16*>(a.resid) : nullptr;
-            const __bf16* by = EPI == 2 ? static_cast<const __bf16*>(a.bnb_y) : nullptr;
+            constexpr bool RES = EPI == 1 || EPI == 4, BNB = EPI == 2 || EPI == 4;
+            const __bf16* resid = RES ? static_cast<const __bf16*>(a.resid) : nullptr;
+            const __bf16* by = BNB ? static_cast<const __bf16*>(a.bnb_y) : nullptr;
+            const __bf16* bmask = EPI == 4 ? static_cast<const __bf16*>(a.bnb_mask) : nullptr;
             const int colw = n0 + wn * WTN;                     // first column of this wave
             const int crow = lane / SEGS, cseg = lane % SEGS;   // copy-out role: chunk lane + 64 q = (row crow + RPP q, segment cseg)
             float psc[NT], psh[NT], bia[NT];
@@ -537,9 +433,14 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                 psh[nj] = a.post_scale ? a.post_shift[col] : 0.f;
                 bia[nj] = a.bias ? a.bias[col] : 0.f;
             }
+            f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
+            float s1[NT], s2[NT];
+#pragma unroll
+            for (int nj = 0; nj < NT; ++nj) { s1[nj] = 0.f; s2[nj] = 0.f; }
+            if (epi_on) {
             // every load of the epilogue is requested before its first store (a load behind a store would wait for the store)
-            float rv[EPI == 1 ? MT : 1][16][NT];
-            if constexpr (EPI == 1) {
+            float rv[RES ? MT : 1][16][NT];
+            if constexpr (RES) {
 #pragma unroll
                 for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -552,28 +453,37 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                         for (int nj = 0; nj < NT; ++nj) rv[mi][r][nj] = (float)resid[ob + (unsigned)(nj * 32)];
                     }
             }
-            bf16x8 yv[EPI == 2 ? NSTEP : 1][CPL];
+            // Form 2 requests all of its side chunks up front (64 / 128 bytes per lane).  Form 4 has the residual's 64 registers as well: its two
+            // side tensors come one copy-out step ahead instead (two register sets; the loads of step s + 1 are requested before the stores
+            // of step s, so the wait for them covers stores that are two steps old) -- all up front the eight-wave shapes spilled 26-38 registers
+            constexpr int YSETS = EPI == 4 ? 2 : (BNB ? NSTEP : 1);
+            bf16x8 yv[YSETS][CPL], mv[EPI == 4 ? 2 : 1][CPL];
             f32x8 bsc, bsh, bmu, biv;
-            f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
-            if constexpr (EPI == 2) {
+            auto side_chunks = [&](const int s, const int set) {
+#pragma unroll
+                for (int q = 0; q < CPL; ++q) {
+                    const int m = m0 + wm * WTM + s * SROWS + crow + RPP * q;
+                    const unsigned o = (unsigned)(m < a.M ? m : 0) * (unsigned)a.K + (unsigned)(colw + cseg * 8);
+                    yv[set][q] = *reinterpret_cast<const bf16x8*>(by + o);
+                    if constexpr (EPI == 4) mv[set][q] = *reinterpret_cast<const bf16x8*>(bmask + o);
+                }
+            };
+            if constexpr (BNB) {
                 const int c0 = colw + cseg * 8;
-                bsc = ParamVec<8>::ld(a.bnb_scale + c0); bsh = ParamVec<8>::ld(a.bnb_shift + c0);
+                if constexpr (EPI == 2) { bsc = ParamVec<8>::ld(a.bnb_scale + c0); bsh = ParamVec<8>::ld(a.bnb_shift + c0); }
                 bmu = ParamVec<8>::ld(a.bnb_mean + c0); biv = ParamVec<8>::ld(a.bnb_invstd + c0);
+                if constexpr (EPI == 4) side_chunks(0, 0);
+                else {
 #pragma unroll
-                for (int s = 0; s < NSTEP; ++s)
-#pragma unroll
-                    for (int q = 0; q < CPL; ++q) {
-                        const int m = m0 + wm * WTM + s * SROWS + crow + RPP * q;
-                        yv[s][q] = *reinterpret_cast<const bf16x8*>(by + ((unsigned)(m < a.M ? m : 0) * (unsigned)a.K + (unsigned)(colw + cseg * 8)));
-                    }
+                    for (int s = 0; s < NSTEP; ++s) side_chunks(s, s);
+                }
             }
-            float s1[NT], s2[NT];
-#pragma unroll
-            for (int nj = 0; nj < NT; ++nj) { s1[nj] = 0.f; s2[nj] = 0.f; }
 #pragma unroll
             for (int s = 0; s < NSTEP; ++s) {
                 constexpr int SPB = 32 / SROWS, RPS = SROWS / 2;                      // steps per 32-row block, accumulator registers per step
                 const int mi = s / SPB;
+                const int yset = EPI == 4 ? (s & 1) : s;
+                if constexpr (EPI == 4) { if (s + 1 < NSTEP) side_chunks(s + 1, (s + 1) & 1); }
 #pragma unroll
                 for (int r8 = 0; r8 < RPS; ++r8) {
                     const int r = (s % SPB) * RPS + r8;
@@ -584,10 +494,10 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                         float v = acc[mi][nj][r];
                         if (a.post_scale) v = v * psc[nj] + psh[nj];
                         if (a.bias) v += bia[nj];
-                        if constexpr (EPI == 1) v += rv[mi][r][nj];
+                        if constexpr (RES) v += rv[mi][r][nj];
                         if (a.relu) v = fmaxf(v, 0.f);
                         *reinterpret_cast<__bf16*>(stg + lr * SROW_B + (nj * 32 + l31) * 2) = (__bf16)v;
-                        if (EPI != 2 && live) { s1[nj] += v; s2[nj] += v * v; }
+                        if (!BNB && live) { s1[nj] += v; s2[nj] += v * v; }
                     }
                 }
                 // (LDS operations of one wave execute in order: its reads below see its writes above, and the next step's writes
@@ -599,11 +509,14 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                     const int row = crow + RPP * q;
                     const int m = m0 + wm * WTM + s * SROWS + row;
                     bf16x8 ch = *reinterpret_cast<const bf16x8*>(stg + row * SROW_B + cseg * 16);
-                    if constexpr (EPI == 2) {
-                        // fused BatchNorm-backward reduce (IgemmArgs::bnb_*): mask the stored gradient with bn(y) > 0, sum (g, g * xhat)
-                        const f32x8 yf = __builtin_convertvector(yv[s][q], f32x8);
+                    if constexpr (BNB) {
+                        // fused BatchNorm-backward reduce (IgemmArgs::bnb_*): mask the stored gradient with bn(y) > 0 (form 4: with the given
+                        // ReLU output > 0), sum (g, g * xhat)
+                        const f32x8 yf = __builtin_convertvector(yv[yset][q], f32x8);
                         f32x8 g = __builtin_convertvector(ch, f32x8);
-                        const f32x8 z = yf * bsc + bsh;
+                        f32x8 z;
+                        if constexpr (EPI == 4) z = __builtin_convertvector(mv[yset][q], f32x8);
+                        else z = yf * bsc + bsh;
 #pragma unroll
                         for (int e = 0; e < 8; ++e) g[e] = z[e] > 0.f ? g[e] : 0.f;
                         ch = __builtin_convertvector(g, bf16x8);
@@ -613,8 +526,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                 }
                 __builtin_amdgcn_wave_barrier();
             }
+            }       // epi_on
             if (a.stats) {
-                if constexpr (EPI == 2) {
+                if (!epi_on) {
+                    // (instance 1 of a K-split workgroup: nothing to contribute)
+                } else if constexpr (BNB) {
                     // lanes with the same segment (lane % SEGS) hold partial sums of the same 8 channels: combine over lane / SEGS
 #pragma unroll
                     for (int off = SEGS; off < 64; off <<= 1)
@@ -643,7 +559,7 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
                 }
                 LBC_WAIT_LGKM0();
                 __builtin_amdgcn_s_barrier();
-                if (tid < BN) {
+                if (epi_on && tid < BN) {
                     float u1 = 0.f, u2 = 0.f;
 #pragma unroll
                     for (int w2 = 0; w2 < WM; ++w2) { u1 += red[(w2 * 2 + 0) * BN + tid]; u2 += red[(w2 * 2 + 1) * BN + tid]; }
@@ -655,20 +571,11 @@ __global__ __launch_bounds__(WM * WN * 64, ((BM / WM == 128 && WM * WN == 4) || 
             }
         }
         zero_acc();
-        if (PROF) { const unsigned long long t = LBC_NOW(); pf_epi += t - pf_prev; pf_prev = t; }
         stores_pending = true;
         tile = tilen; mtile = mtilen; n0 = n0n; m0 = m0n;
 #pragma unroll
         for (int i = 0; i < MT; ++i) amask[i] = amaskn[i];
     }
-    if (PROF && prof && lane == 0) {
-        unsigned long long* o = prof + ((size_t)blockIdx.x * 8 + wave) * 8;
-        o[0] = pf_kt; o[1] = pf_steps; o[2] = pf_vm; o[3] = pf_bar; o[4] = pf_tail; o[5] = pf_epi; o[6] = LBC_NOW() - pf_t0; o[7] = (unsigned long long)cnt;
-    }
-#undef LBC_NOW
-#undef LBC_LDS_RD16
-#undef LBC_LDS_WR16
-#undef LBC_FENCE
 #undef LBC_RD
 #undef LBC_RD1
 #undef LBC_USE
@@ -685,40 +592,22 @@ int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int 
         // split-K (EPI 3): one tile per workgroup, grid = ntiles * nsplit; the epilogue is the caller's second launch
         if constexpr (BM == 128 && BN == 64) {
             LBC_REQUIRE(a.split_ws && tpw == 1 && grid.x == (unsigned)(ntiles * nsplit) && (a.C / 64) % nsplit == 0, "conv_hdmap: bad split-K launch");
-            if (mode == 0) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 3, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, nsplit);
-            else hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 1, 3, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, nsplit);
+            if (mode == 0) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 3>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, nsplit);
+            else hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 1, 3>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, nsplit);
             return lbc_check_launch("conv_hdmap(split)");
         } else {
             LBC_REQUIRE(false, "conv_hdmap: split-K exists for the 128 x 64 shape only");
         }
     }
-    const int epi = a.bnb_y ? 2 : (a.resid ? 1 : 0);
-    if (a.pre_scale) {
-        constexpr int PC = hdmap_pre_channels<BM, BN, WM, WN, HRMAX, SROWS>();
-        if constexpr (PC > 0) {
-            LBC_REQUIRE(mode == 0 && epi == 0 && a.C <= PC, "conv_hdmap: BatchNorm-on-load is a form of the plain forward with at most %d gathered channels", PC);
-            hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, false, 8, true>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, 1);
-            return lbc_check_launch("conv_hdmap(pre)");
-        } else {
-            LBC_REQUIRE(false, "conv_hdmap: this tile shape has no LDS left for the BatchNorm-on-load table");
-        }
-    }
-    // A/B variants (plain forward only); 16 = the shipped schedule with compiler-managed fragment reads instead of the asm ones
-    const long long var = lbc_opt(kOptHdmapVar) > 0 ? lbc_opt(kOptHdmapVar) : 0;
-    unsigned long long* prof = lbc_opt(kOptHdmapProf) > 0 ? reinterpret_cast<unsigned long long*>((uintptr_t)lbc_opt(kOptHdmapProf)) : nullptr;
-    if ((prof || var) && mode == 0 && epi == 0) {
-#define LBC_HV(PROFv, VARv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 0, 0, PROFv, VARv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, prof, 1)
-        if (prof) { if (var == 16) LBC_HV(true, 0); else if (var == 2) LBC_HV(true, 2); else if (var == 4) LBC_HV(true, 4); else LBC_HV(true, 8); }
-        else      { if (var == 16) LBC_HV(false, 0); else if (var == 1) LBC_HV(false, 1); else if (var == 2) LBC_HV(false, 2); else if (var == 4) LBC_HV(false, 4); else LBC_HV(false, 8); }
-#undef LBC_HV
-        return lbc_check_launch("conv_hdmap");
-    }
-#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv, false, 8>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, (unsigned long long*)nullptr, 1)
+    const int epi = a.bnb_y ? (a.bnb_mask ? 4 : 2) : (a.resid ? 1 : 0);
+    LBC_REQUIRE(!a.pre_scale, "conv_hdmap: no BatchNorm-on-load form (measured slower on the MI355X, profiles/r05_call1_hdmap_pre_land_or_kill.txt)");
+#define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, 1)
     if (mode == 0) {
-        LBC_REQUIRE(epi != 2, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
+        LBC_REQUIRE(epi != 2 && epi != 4, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
         if (epi == 1) LBC_HP(0, 1); else LBC_HP(0, 0);
     } else {
-        if (epi == 2) LBC_HP(1, 2); else if (epi == 1) LBC_HP(1, 1); else LBC_HP(1, 0);
+        LBC_REQUIRE(epi != 4 || a.resid, "conv_hdmap: the tensor-masked BatchNorm-backward reduce is the residual form's (IgemmArgs::bnb_mask)");
+        if (epi == 4) LBC_HP(1, 4); else if (epi == 2) LBC_HP(1, 2); else if (epi == 1) LBC_HP(1, 1); else LBC_HP(1, 0);
     }
 #undef LBC_HP
     return lbc_check_launch("conv_hdmap");

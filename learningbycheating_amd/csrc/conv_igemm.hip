@@ -510,8 +510,15 @@ int lbc_igemm_rows(const IgemmArgs& a, int cfg)
 bool lbc_igemm_fuses_bn_bwd(const IgemmArgs& a, int wmajor, int mode, int cfg)
 {
     if (lbc_opt_on(kOptNoBnBwdFuse) || mode != 1 || !a.act_bf16) return false;
-    if (cfg >= kLbcCfgGlds) return !lbc_opt_on(kOptGldsV1);          // conv_glds2_k, conv_hdma_k (shared epilogue)
+    if (cfg >= kLbcCfgGlds) return true;          // conv_glds2_k (lds_dma_epilogue), conv_hdmap_k / conv_c64p_k (EPI 2)
     return wmajor && !a.resid && lbc_conv3x3_halo_eligible(a, mode); // conv3x3_c64_k<1, true>
+}
+
+bool lbc_igemm_fuses_bn_bwd_masked(const IgemmArgs& a, int wmajor, int mode, int cfg)
+{
+    (void)wmajor;
+    if (lbc_opt(kOptNoBnBwdFuse) >= 1 || mode != 1 || !a.act_bf16 || !a.resid) return false;     // (LBC_NO_BN_BWD_FUSE=2: only this form off)
+    return cfg > kLbcCfgHdma && cfg != kLbcCfgHdma + 3;      // conv_hdmap_k<.., EPI 4> (every shape) and its split-K epilogue; not the 64-channel kernel
 }
 
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode)

@@ -20,34 +20,6 @@ __device__ __forceinline__ void lds_dma16(const void* g, void* lds_wave_base)
     __builtin_amdgcn_global_load_lds((gas_ptr)g, (las_ptr)lds_wave_base, 16, 0, 0);
 }
 
-// Fragment reads the compiler does not track (LBC_HDMA_EARLY variants).  With LDS-DMA in flight the compiler's own wait insertion
-// puts lgkmcnt(0) in front of every depth step, which also waits for the reads just issued for the NEXT step; these loads are
-// inline asm, waited for with hand-counted lgkmcnt and handed to the MFMAs through lds_frag_use() placed after that wait.
-// smem + off + OFF must be 16-byte aligned; OFF is the instruction's immediate offset field (< 65536).
-#ifdef LBC_HIP_EMULATED_FOR_TESTS
-template <int OFF> inline void lds_read16_early(bf16x8& f, const char* smem, unsigned off) { f = *reinterpret_cast<const bf16x8*>(smem + off + OFF); }
-template <int N> inline void lds_frag_use(bf16x8 (&)[N]) {}
-#else
-template <int OFF> __device__ __forceinline__ void lds_read16_early(bf16x8& f, const char* smem, unsigned off)
-{
-    const unsigned addr = (unsigned)(size_t)(__attribute__((address_space(3))) const char*)smem + off;
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(f) : "v"(addr), "n"(OFF));
-}
-template <int N> __device__ __forceinline__ void lds_frag_use(bf16x8 (&f)[N])
-{
-#pragma unroll
-    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(f[i]));
-}
-#endif
-// N fragments STRIDE bytes apart from one address register
-template <int N, int STRIDE, int I = 0> __device__ __forceinline__ void lds_read16_early_n(bf16x8 (&f)[N], const char* smem, unsigned off)
-{
-    if constexpr (I < N) {
-        lds_read16_early<I * STRIDE>(f[I], smem, off);
-        lds_read16_early_n<N, STRIDE, I + 1>(f, smem, off);
-    }
-}
-
 // LDS the epilogue below needs: the staged output tile + the statistics rows
 template <int BM, int BN, int WM> constexpr int lds_dma_epilogue_bytes() { return BM * (BN * 2 + 16) + WM * 2 * BN * 4; }
 

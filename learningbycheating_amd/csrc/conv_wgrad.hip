@@ -472,7 +472,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_group_f32(const float* __re
 // and is neutral at batch 32.
 inline bool big_tile(const WgradArgs& a)
 {
-    const long long min_m = lbc_opt(kOptWgradBigM) >= 0 ? lbc_opt(kOptWgradBigM) : 4096;   // tuning knob
+    const long long min_m = 4096;
     return a.CP % 128 == 0 && a.CQ % 128 == 0 && (long long)a.N * a.OH * a.OW >= min_m;
 }
 
@@ -486,7 +486,7 @@ int lbc_wgrad_pick_split(const WgradArgs& a)
     const long long tiles = (long long)(a.CP / bp) * (a.CQ / bp) * a.KH * a.KW;
     const long long M = (long long)a.N * a.OH * a.OW;
     const long long chunks = (M + BR - 1) / BR;
-    const long long target = lbc_opt(kOptWgradBlocks) > 0 ? lbc_opt(kOptWgradBlocks) : 1024;   // tuning knob
+    const long long target = 1024;       // workgroups per launch the split count aims at (r01_run9_wgrad_block_target_*)
     long long ns = (target + tiles - 1) / tiles;
     if (ns < 1) ns = 1;
     if (ns > 256) ns = 256;
@@ -514,18 +514,13 @@ int lbc_wgrad_launch(const WgradArgs& a, hipStream_t s)
     const int bt = big_tile(a) ? 128 : 64;
     const long long ngroups = (long long)a.nsplit * (a.CP / bt) * (a.CQ / bt);
     const dim3 grid((unsigned)(((ngroups + 7) / 8) * 8 * a.KH * a.KW));
-    const int kb = (int)lbc_opt(kOptWgradKb);   // tuning knob (lane mapping, see the kernel); -1 = default
-#define LBC_WG(AT, KB)                                                                                                               \
-    do {                                                                                                                             \
-        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, AT, KB>), grid, dim3(256), 0, s, a, rows_per_split);        \
-        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, AT, KB>), grid, dim3(256), 0, s, a, rows_per_split);          \
-    } while (0)
+    // (KB = channel-group bits in the low lane bits of the staging writes, see wgrad_tile_coord: the measured best per element type and tile)
     if (a.act_bf16) {
-        if (kb == 0) LBC_WG(__bf16, 0); else if (kb == 2) LBC_WG(__bf16, 2); else if (kb == 3) LBC_WG(__bf16, 3); else if (kb == 1) LBC_WG(__bf16, 1);
-        else if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, __bf16, 1>), grid, dim3(256), 0, s, a, rows_per_split);
-        else                  hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, __bf16, 2>), grid, dim3(256), 0, s, a, rows_per_split);
+        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, __bf16, 1>), grid, dim3(256), 0, s, a, rows_per_split);
+        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, __bf16, 2>), grid, dim3(256), 0, s, a, rows_per_split);
     } else if (a.bf16) {
-        if (kb == 0) LBC_WG(float, 0); else if (kb == 1) LBC_WG(float, 1); else if (kb == 3) LBC_WG(float, 3); else LBC_WG(float, 2);
+        if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_bf16_k<128, 128, float, 2>), grid, dim3(256), 0, s, a, rows_per_split);
+        else             hipLaunchKernelGGL((conv_wgrad_bf16_k<64, 64, float, 2>), grid, dim3(256), 0, s, a, rows_per_split);
     } else if (big_tile(a)) hipLaunchKernelGGL((conv_wgrad_f32<128, 128>), grid, dim3(256), 0, s, a, rows_per_split);
     else                    hipLaunchKernelGGL((conv_wgrad_f32<64, 64>), grid, dim3(256), 0, s, a, rows_per_split);
     return lbc_check_launch("conv_wgrad_f32");

@@ -272,14 +272,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tr_k(WgradArgs a, WgradGrou
 
 bool lbc_wgrad_tr_eligible(const WgradArgs& a)
 {
-    const bool off = lbc_opt_on(kOptNoWgradTr);   // A/B switch
-    return !off && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.OH == a.H && a.OW == a.W && !a.p_scale &&
+    return a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 1 && a.P == 1 && a.OH == a.H && a.OW == a.W && !a.p_scale &&
            a.W >= 8 && 64 + 2 * a.W + 2 + 64 <= kRingWide && a.CP % 64 == 0 && a.CQ % 64 == 0;
 }
 
 int lbc_wgrad_tr_pick_split(const WgradArgs& a)
 {
-    const long long target = lbc_opt(kOptWgradTrBlocks) > 0 ? lbc_opt(kOptWgradTrBlocks) : 512;   // tuning knob
+    const long long target = 512;        // (r03_run4_wgrad_tr_blocks_ab.log: 256 / 384 / 768 / 1024 all slower)
     const long long tiles = (long long)(a.CP / 64) * (a.CQ / 64);
     const long long M = (long long)a.N * a.H * a.W;
     const long long chunks = (M + 63) / 64;
@@ -297,7 +296,7 @@ int lbc_wgrad_tr_pick_split(const WgradArgs& a)
 int lbc_wgrad_tr_group_split(const WgradArgs& a, int n)
 {
     if (n <= 1) return lbc_wgrad_tr_pick_split(a);
-    const long long slots = lbc_opt(kOptWgradTrBlocks) > 0 ? lbc_opt(kOptWgradTrBlocks) : 512;
+    const long long slots = 512;
     const long long tiles = (long long)(a.CP / 64) * (a.CQ / 64) * n;
     const long long chunks = ((long long)a.N * a.H * a.W + 63) / 64;
     long long maxns = chunks / 8 > 0 ? chunks / 8 : 1;
@@ -322,7 +321,7 @@ int lbc_wgrad_tr_group_launch(const WgradArgs& a0, const WgradGroup& g_in, hipSt
 {
     LBC_REQUIRE(g_in.n >= 1 && g_in.n <= kLbcWgradGroupMax, "wgrad_tr: group of %d", g_in.n);
     WgradGroup g = g_in;
-    g.linear_order = lbc_opt_on(kOptWgradTrLinear) ? 1 : 0;
+    g.linear_order = 0;       // XCD-major workgroup order (r03_run31: equal in time, half the fetched bytes)
     WgradArgs a = a0;
     a.p = g.p[0]; a.q = g.q[0]; a.q_scale = g.q_scale[0]; a.q_shift = g.q_shift[0]; a.partial = g.out[0];
     LBC_REQUIRE(lbc_wgrad_tr_eligible(a), "wgrad_tr: launch not eligible");

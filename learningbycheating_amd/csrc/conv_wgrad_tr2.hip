@@ -206,20 +206,19 @@ __global__ __launch_bounds__(512, 2) void conv_wgrad_tr2_k(WgradArgs a, int rows
 
 bool lbc_wgrad_tr2_eligible(const WgradArgs& a)
 {
-    const bool off = lbc_opt_on(kOptNoWgradTr2);      // A/B switch
     // One workgroup per CU, each paying a window prologue worth ~3.5 chunks of loads: worth it from ~192 workgroups of >= 16 chunks (measured:
     // -0.26 ms per step at 256 images, +0.08 ms at 32 where 60 workgroups remain; LBC_WGRAD_TR2_MIN_WGS overrides, tests use 1)
     const long long min_wgs = lbc_opt(kOptWgradTr2MinWgs) > 0 ? lbc_opt(kOptWgradTr2MinWgs) : 192;
     const long long chunks = ((long long)a.N * a.OH * a.OW + 31) / 32;
     if ((long long)(a.CP / 128) * (a.CQ / 64) * (chunks / 16) < min_wgs) return false;
-    return !off && a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 2 && a.P == 1 && a.H == 2 * a.OH && a.W == 2 * a.OW && !a.q_scale &&
+    return a.act_bf16 && a.KH == 3 && a.KW == 3 && a.S == 2 && a.P == 1 && a.H == 2 * a.OH && a.W == 2 * a.OW && !a.q_scale &&
            (!a.p_scale || a.p_shift) && a.OW % 4 == 0 && a.OW >= 12 && a.W <= 96 && a.CP % 128 == 0 && a.CQ % 64 == 0 &&
            (long long)a.N * a.H * a.W * 4 < (1ll << 31);
 }
 
 int lbc_wgrad_tr2_pick_split(const WgradArgs& a)
 {
-    const long long target = lbc_opt(kOptWgradTr2Blocks) > 0 ? lbc_opt(kOptWgradTr2Blocks) : 256;   // one workgroup per CU
+    const long long target = 256;        // one workgroup per CU (r03_run30_wgrad_stride2_blocks_sweep.log)
     const long long tiles = (long long)(a.CP / 128) * (a.CQ / 64);
     const long long M = (long long)a.N * a.OH * a.OW;
     const long long chunks = (M + 31) / 32;

@@ -74,12 +74,10 @@ Net::Net(const lbc_net_desc& d) : d_(d)
 {
     const size_t NB = (size_t)d.max_batch;
     const int Cin = d.in_channels, H0 = d.H, W0 = d.W;
-    fuse_z1_ = (int)lbc_opt(kOptNoFuseZ1);
-    dgrad_wt_ = lbc_opt_on(kOptDgradWt);
     side_allowed_ = !lbc_opt_on(kOptNoSideStream);
     bf16_ = d.precision >= 1;
     act_bf16_ = d.precision == 2;
-    defer_wgrad_ = act_bf16_ && !lbc_opt_on(kOptNoWgradDefer);
+    defer_wgrad_ = act_bf16_;
     if (defer_wgrad_) side_allowed_ = false;      // nothing is left for a side stream: the deferred launches fill the chip by themselves
     if (bf16_) dgrad_wt_ = true;   // the bf16 tiles are [row][depth] only: every weight operand must be depth-contiguous
 
@@ -120,7 +118,7 @@ Net::Net(const lbc_net_desc& d) : d_(d)
             // (with LBC_HDMA_PROLOGUE=1 the halo-staged kernel applies bn1 itself: fused again)
             // (the 64-channel layer keeps bn1 on load: conv_halo.hip transforms its register-staged halo for free, while the LDS-DMA kernel
             //  for that layer -- conv_c64p.hip -- would need the extra pass; its other launches take that kernel)
-            b.fuse_z1 = fuse_z1_ < 0 ? (planes == 64 || !conv_takes_glds(b.c2, (int)NB) || conv_takes_glds(b.c2, (int)NB, true)) : fuse_z1_ == 0;
+            b.fuse_z1 = planes == 64 || !conv_takes_glds(b.c2, (int)NB) || conv_takes_glds(b.c2, (int)NB, true);
             b.z1 = b.fuse_z1 ? 0 : alloc_act(NB * oh * ow * planes);
             b.out = alloc_act(NB * oh * ow * planes);
             blocks_.push_back(b);
@@ -173,7 +171,8 @@ Net::Net(const lbc_net_desc& d) : d_(d)
         pf = std::max(pf, (size_t)4 * lbc_cdiv((long long)NB * dec_[i].H * dec_[i].W, 64) * 2 * dec_[i].Cout);
     partial_floats_ = pf;
     partial_ = alloc(pf);
-    partial2_ = alloc(64 * 2 * 640);
+    partial2_floats_ = (size_t)64 * 2 * 640;
+    partial2_ = alloc(partial2_floats_);
 
     size_t wg = 0;
     auto wg_need = [&](int N, int OH, int OW, int CP, int Hq, int Wq, int CQ, int k, int s, int p) {
@@ -291,7 +290,7 @@ int Net::check_bound(bool need_grads) const
 
 // ---------------------------------------------------------------------------------------
 int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre, const BN* post,
-                  const float* resid, bool relu, float* out, float* stats_buf)
+                  const float* resid, bool relu, float* out, float* stats_buf, size_t stats_cap)
 {
     IgemmArgs a;
     memset(&a, 0, sizeof(a));
@@ -309,6 +308,9 @@ int Net::conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, h
     const int cfg = lbc_igemm_pick_for(a, 0);
     *rows = lbc_igemm_rows(a, cfg);
     a.stats = stats ? (stats_buf ? stats_buf : W(partial_)) : nullptr;
+    // (the row count is the kernel's, known before the launch: a caller-provided statistics buffer is checked BEFORE anything is written)
+    LBC_REQUIRE(!a.stats || (size_t)*rows * 2 * (size_t)c.Cout <= (stats_buf ? stats_cap : partial_floats_),
+                "net: %d statistics rows of %d channels exceed their buffer", *rows, c.Cout);
     return lbc_igemm_launch(a, 1, 0, cfg, s);
 }
 
@@ -449,9 +451,6 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
 {
     LBC_REQUIRE(N >= 1 && N <= d_.max_batch, "net.forward: batch %d outside [1,%d]", N, d_.max_batch);
     LBC_REQUIRE(image && velocity && command && pred_all, "net.forward: null argument");
-    // the timing-experiment switches select kernels with parts left out: a network must never run on them
-    LBC_REQUIRE(lbc_opt(kOptHdmaDiag) <= 0 && lbc_opt(kOptGldsDiag) <= 0,
-                "net.forward: LBC_HDMA_DIAG / LBC_GLDS_DIAG are set -- diagnostic kernels compute wrong results (per-kernel timing scripts only)");
     LBC_TRY(check_bound(false));
     lastN_ = N; last_train_ = train; ++generation_;
     const int H0 = d_.H, W0 = d_.W, Cin = d_.in_channels;
@@ -521,8 +520,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         }
         // (the downsample's rows must not overwrite conv2's before the folded pass has read them: they go to partial2_ -- idle while
         //  no row count needs pre-reduction -- when they are certain to fit; otherwise bn2 is finalized by its own launch as before)
-        const size_t p2_floats = (size_t)64 * 2 * 640;
-        const bool fold2 = can_fold(rows, b.b2.C) && (!b.has_ds || (size_t)lbc_cdiv(pix, 64) * 2 * b.bd.C <= p2_floats);
+        const bool fold2 = can_fold(rows, b.b2.C) && (!b.has_ds || (size_t)lbc_cdiv(pix, 64) * 2 * b.bd.C <= partial2_floats_);
         const int rows2 = rows;
         if (!fold2) LBC_TRY(bn_finalize(b.b2, rows, pix, N, train, s));
         memset(&ap, 0, sizeof(ap));
@@ -531,8 +529,7 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
         if (fold2) { ap.fold = 1; ap.fin = fin_args(b.b2, W(partial_), rows2, pix); }
         if (b.has_ds) {
             float* dsp = fold2 ? W(partial2_) : W(partial_);
-            LBC_TRY(conv_fwd(b.ds, x, N, tr, &rows, s, nullptr, nullptr, nullptr, false, nullptr, dsp));
-            LBC_REQUIRE(!fold2 || (size_t)rows * 2 * b.bd.C <= p2_floats, "net.forward: downsample statistics rows exceed their buffer");
+            LBC_TRY(conv_fwd(b.ds, x, N, tr, &rows, s, nullptr, nullptr, nullptr, false, nullptr, dsp, fold2 ? partial2_floats_ : partial_floats_));
             if (fold2 && can_fold(rows, b.bd.C)) { ap.rfold = 1; ap.rfin = fin_args(b.bd, dsp, rows, pix); }
             else if (fold2) LBC_TRY(lbc_bn_finalize(fin_args(b.bd, dsp, rows, pix), s));     // (can_fold implies local statistics and <= 1024 rows)
             else LBC_TRY(bn_finalize(b.bd, rows, pix, N, train, s));
@@ -589,9 +586,8 @@ int Net::forward(int N, int train, const void* image, int image_u8, const float*
             IgemmArgs b = a;
             b.pre_scale = nullptr; b.pre_shift = nullptr; b.x = W(gF_);
             const int c2 = lbc_igemm_pick_for(b, 1);
-            // (the 64-channel last stage too: 244 -> 167 + 25 us at 256 images, the teacher's 152 -> 112 + 15; LBC_DECODER_PASS_MIN_COUT=128 = without)
-            const int min_cout = lbc_opt(kOptDecoderPassMinCout) > 0 ? (int)lbc_opt(kOptDecoderPassMinCout) : 64;
-            if (c2 >= kLbcCfgGlds && D.Cout >= min_cout) {
+            // (the 64-channel last stage too: 244 -> 167 + 25 us at 256 images, the teacher's 152 -> 112 + 15)
+            if (c2 >= kLbcCfgGlds) {
                 BnApplyArgs ap;
                 memset(&ap, 0, sizeof(ap));
                 ap.x = din; ap.y = W(gF_); ap.pixels = (long long)N * D.H * D.W; ap.C = D.Cin;
@@ -794,7 +790,7 @@ int Net::conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const floa
 
 // dx[N,H,W,Cin] = dgrad(dy) (+ resid).  For the 1x1/2 downsample only the even-even phase is touched.
 int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s, const BN* bnb,
-                    const float* bnb_y, int* fused_rows)
+                    const float* bnb_y, int* fused_rows, const float* bnb_mask)
 {
     if (fused_rows) *fused_rows = 0;
     IgemmArgs a;
@@ -818,11 +814,14 @@ int Net::conv_dgrad(const Conv& c, const float* dy, const float* resid, float* d
         a.M = N * c.H * c.W;
         split_scratch(a);
         const int cfg = wmajor ? lbc_igemm_pick_for(a, 1) : lbc_igemm_pick(a.M, a.K);
-        if (bnb && bnb_y && fused_rows && lbc_igemm_fuses_bn_bwd(a, wmajor, 1, cfg)) {
+        if (bnb && bnb_y && fused_rows &&
+            (bnb_mask ? lbc_igemm_fuses_bn_bwd_masked(a, wmajor, 1, cfg) : lbc_igemm_fuses_bn_bwd(a, wmajor, 1, cfg))) {
             a.bnb_y = bnb_y; a.bnb_scale = W(bnb->scale); a.bnb_shift = W(bnb->shift);
             a.bnb_mean = W(bnb->mean); a.bnb_invstd = W(bnb->invstd);
+            a.bnb_mask = bnb_mask;
             a.stats = W(partial_);
             *fused_rows = lbc_igemm_rows(a, cfg);
+            LBC_REQUIRE((size_t)*fused_rows * 2 * (size_t)a.K <= partial_floats_, "net: %d rows of BatchNorm-backward sums exceed their buffer", *fused_rows);
         }
         return lbc_igemm_launch(a, wmajor, 1, cfg, s);
     }
@@ -845,7 +844,11 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
         float* E2 = dy_slot(pix * b.b2.C);
         float* E1 = dy_slot(pix * b.b1.C);
         LBC_REQUIRE(E1 && E2, "net.backward: dY arena exhausted");
-        LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E2, b.b2.C, s, nullptr, false));   // E2 = dY2
+        // (D may arrive masked and reduced: the input gradient that produced it -- conv1 of the block behind this one -- did bn2's reduce
+        //  pass in its epilogue, bwd_pre_rows_ rows of sums in partial_)
+        const int pre_rows = bwd_pre_rows_;
+        bwd_pre_rows_ = 0;
+        LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E2, b.b2.C, s, nullptr, false, pre_rows));   // E2 = dY2
         int fr = 0;
         LBC_TRY(conv_dgrad(b.c2, E2, nullptr, F, N, s, &b.b1, W(b.c1.y), &fr));                       // F = dZ1 (masked when fr > 0)
         if (b.fuse_z1) {
@@ -857,7 +860,14 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
         }
         pending_.push_back({&b.c1, xin, nullptr, E1});
         if (!b.has_ds) {
-            LBC_TRY(conv_dgrad(b.c1, E1, D, Gbuf, N, s));                                 // G = dgrad + identity gradient
+            // G = dgrad + identity gradient = the gradient wrt the PREVIOUS block's output relu(bn2(y2) + identity) (resnet.py:51-54): where
+            // the kernel can, its epilogue also masks G with that output and sums bn2's backward reduce -- the previous block's
+            // channel_reduce pass (g, out, y2 read, g written) disappears
+            Block* pb = (&b == &blocks_.front()) ? nullptr : (&b - 1);
+            int pr = 0;
+            if (pb) LBC_TRY(conv_dgrad(b.c1, E1, D, Gbuf, N, s, &pb->b2, W(pb->c2.y), &pr, W(pb->out)));
+            else    LBC_TRY(conv_dgrad(b.c1, E1, D, Gbuf, N, s));
+            bwd_pre_rows_ = pr;
         } else {
             float* Fd = dy_slot(pix * b.bd.C);
             LBC_REQUIRE(Fd, "net.backward: dY arena exhausted");
@@ -905,7 +915,7 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
 int Net::backward(const float* d_sel, const float* d_all, int stage, hipStream_t s)
 {
     const int rc = backward_impl(d_sel, d_all, stage, s);
-    if (rc != LBC_OK) { pending_.clear(); dy_used_ = 0; }
+    if (rc != LBC_OK) { pending_.clear(); dy_used_ = 0; bwd_pre_rows_ = 0; }
     if (rc != LBC_OK && side_dirty_) {
         // an early return between fork() and join(): weight gradients may still be in flight on the side stream; let them
         // finish before anything (a retry, the next forward) reuses the gradient ping-pong buffers or the split-K slabs
@@ -1033,6 +1043,7 @@ int Net::backward_impl(const float* d_sel, const float* d_all, int stage, hipStr
     for (int li = 3; li >= 0; --li) {
         const int st = 4 - li;   // layer4 -> stage 1 ... layer1 -> stage 4
         if (stage != -1 && stage != st) continue;
+        bwd_pre_rows_ = 0;       // (a stage's last block gets its gradient from the stage behind it through a downsample block or the decoder: never pre-reduced)
         const int first = stage_first_block_[li];
         const int lastb = li == 3 ? (int)blocks_.size() : stage_first_block_[li + 1];
         for (int bi = lastb - 1; bi >= first; --bi) LBC_TRY(block_backward(blocks_[bi], bwd_D_, bwd_G_, E, F, s));

@@ -105,7 +105,8 @@ private:
     // pre: BatchNorm(+ReLU) of the producer applied on load.  Eval mode folds the consumer-side BatchNorm into the epilogue:
     // y = relu?(conv * post.scale + post.shift + resid), written to `out` (default: the layer's raw-output buffer).
     int conv_fwd(const Conv& c, const float* x, int N, bool stats, int* rows, hipStream_t s, const BN* pre = nullptr,
-                 const BN* post = nullptr, const float* resid = nullptr, bool relu = false, float* out = nullptr, float* stats_buf = nullptr);
+                 const BN* post = nullptr, const float* resid = nullptr, bool relu = false, float* out = nullptr, float* stats_buf = nullptr,
+                 size_t stats_cap = 0);
     // the arguments of a training-mode forward finalize of `bn` over `rows` partial rows at `part` (one launch of its own, or folded
     // into the consuming bn_apply pass: BnApplyArgs::fold)
     BnFinalizeArgs fin_args(const BN& bn, const float* part, int rows, long long count, bool update_running = true) const;
@@ -120,11 +121,10 @@ private:
     }
     int bn_eval_prep(hipStream_t s);
     int conv_wgrad_pre(const Conv& c, const float* x, const BN* pre, const float* dy, int N, hipStream_t s);
-    bool dgrad_wt_ = false;  // optional: input-gradient GEMMs read a per-step transposed copy of the weights (measured: no gain)
+    bool dgrad_wt_ = false;  // bf16 operands on f32 tensors (precision 1): input-gradient GEMMs read a per-step transposed copy of the weights
     size_t wt_ = 0;
     bool bf16_ = false;      // precision >= 1: bf16 MFMA operands in the convolution family
     bool act_bf16_ = false;  // precision 2: activations and activation gradients are stored as bf16 in HBM
-    int fuse_z1_ = -1;       // LBC_NO_FUSE_Z1: 1 = every block writes z1, 0 = no block does, -1 = per block (Net::Net)
     int weight_prep(hipStream_t s);
     bool conv_takes_glds(const Conv& c, int N, bool with_prologue = false) const;
     // synced: partial_ rows were all-reduced already by sync_rows() (several BatchNorms finalized from the same sums)
@@ -155,8 +155,11 @@ private:
     int conv_wgrad(const Conv& c, const float* x, const float* dy, int N, hipStream_t s);
     // bnb (+ bnb_y): fuse the reduce pass of that BatchNorm's backward into the epilogue when the kernel can (*fused_rows = partial
     // rows written to partial_, else 0)
+    // bnb / bnb_y: fuse the BatchNorm-backward reduce of relu(bnb(bnb_y)) into the epilogue (mask = bnb(bnb_y) > 0); with bnb_mask the mask
+    // is that tensor > 0 (the ReLU output of a block: relu(bnb(bnb_y) + identity)) and the launch may carry a residual.  *fused_rows > 0:
+    // the launch did it (dx is the masked gradient, partial_ holds that many rows of sums)
     int conv_dgrad(const Conv& c, const float* dy, const float* resid, float* dx, int N, hipStream_t s, const BN* bnb = nullptr,
-                   const float* bnb_y = nullptr, int* fused_rows = nullptr);
+                   const float* bnb_y = nullptr, int* fused_rows = nullptr, const float* bnb_mask = nullptr);
     int block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, hipStream_t s);
     // Stage-deferred weight gradients (bf16 tensors): the 3x3 weight gradients of a stage wait for the stage's last block and leave as
     // one grouped launch per shape (lbc_wgrad_tr_group_launch); until then every dY keeps its own slot of the dy arena.
@@ -191,13 +194,14 @@ private:
     size_t partial_ = 0, partial2_ = 0, wg_partial_ = 0, head_partial_ = 0, head_coef_ = 0, head_stats_ = 0;
     size_t pred_all_ = 0, rowstat_ = 0;
     size_t gD_ = 0, gE_ = 0, gF_ = 0, gG_ = 0, g0_ = 0;
-    size_t partial_floats_ = 0;
+    size_t partial_floats_ = 0, partial2_floats_ = 0;      // capacities of partial_ / partial2_ (checked against a launch's row count before it runs)
 
     // state of the last forward
     bool frozen_ = false, derived_valid_ = false;     // lbc_net_set_frozen: weight copies / eval-mode affines derived once
     int lastN_ = 0;
     int last_train_ = 0;
     float* bwd_D_ = nullptr;   // running "gradient wrt block output" buffer between stages
+    int bwd_pre_rows_ = 0;     // > 0: the gradient in bwd_D_ is already masked with its block's ReLU output and partial_ holds that many rows of bn2's backward sums (the producing input gradient did both: IgemmArgs::bnb_mask)
     float* bwd_G_ = nullptr;
 };
 

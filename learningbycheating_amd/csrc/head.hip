@@ -783,7 +783,7 @@ int lbc_head_fwd(const HeadArgs& a, hipStream_t s)
     LBC_REQUIRE(a.N > 0 && a.OH > 0 && a.OW > 0, "head_fwd: bad shape");
     LbcProfScope prof("head_fwd", 2.0 * a.N * a.OH * a.OW * 64.0 * 20, 4.0 * a.N * (double)a.OH * a.OW * 64, s);
     const bool no_mfma = lbc_opt_on(kOptHeadNoMfma);   // A/B switch
-    const int wsplit = (a.act_bf16 && !lbc_opt_on(kOptHeadNoSplit)) ? 1 : 0;
+    const int wsplit = a.act_bf16 ? 1 : 0;
     if (a.act_bf16 && !no_mfma) {
         HeadArgs b = a;
         b.nslice = 1; b.wsplit = wsplit;
@@ -818,7 +818,7 @@ int lbc_head_bwd_max_rows(int max_batch) { return max_batch + 1024; }
 int lbc_head_bwd_reduce(const HeadBwdArgs& a0, hipStream_t s)
 {
     HeadBwdArgs a = a0;
-    a.f.wsplit = (a.f.act_bf16 && !lbc_opt_on(kOptHeadNoSplit)) ? 1 : 0;
+    a.f.wsplit = a.f.act_bf16 ? 1 : 0;
     LBC_REQUIRE(a.f.mean[0] == a.f.mean[1] && a.f.mean[0] == a.f.mean[2] && a.f.mean[0] == a.f.mean[3],
                 "head backward requires training-mode (shared batch) statistics");
     LbcProfScope prof("head_bwd_reduce", 4.0 * a.f.N * a.f.OH * a.f.OW * 64.0 * 20, 4.0 * a.f.N * (double)a.f.OH * a.f.OW * 64, s);
@@ -843,7 +843,7 @@ int lbc_head_bwd_finalize(const HeadBwdFinalizeArgs& a, hipStream_t s)
 int lbc_head_bwd_apply(const HeadBwdArgs& a0, hipStream_t s)
 {
     HeadBwdArgs a = a0;
-    a.f.wsplit = (a.f.act_bf16 && !lbc_opt_on(kOptHeadNoSplit)) ? 1 : 0;
+    a.f.wsplit = a.f.act_bf16 ? 1 : 0;
     const int HW = a.f.OH * a.f.OW;
     LbcProfScope prof("head_bwd_apply", 4.0 * a.f.N * (double)HW * 64.0 * 20, 8.0 * a.f.N * (double)HW * 64, s);
     if (head_bwd_mfma(a.f)) {

@@ -32,54 +32,27 @@ static inline int lbc_cdiv(long long a, long long b) { return (int)((a + b - 1) 
 // the library is loaded and changed afterwards only through lbc_config_set() (include/lbc_hip.h) -- a launch path never reads
 // the environment, and every option can be toggled inside one process.  -1 = unset (the built-in policy applies).
 enum LbcOpt {
+    // (round 5: 50 -> 18.  Every variant that was measured equal or slower is gone with its kernel -- conv_hdma_k, conv_glds_k, the first
+    //  bf16 stem, BatchNorm-on-load inside the halo-staged kernels, schedule variants, timing-experiment builds -- and every tuning knob
+    //  whose sweep ended is a constant next to its use.  What is left: switches the tests use to reach a kernel at test sizes or to
+    //  compare a specialised kernel with the generic one, and two the bench uses.)
     kOptForceCfg = 0,      // LBC_FORCE_CFG: tile policy of the generic convolution (0: 128x64, 1: 128x128, 2: 64x64)
-    kOptNoHalo,            // LBC_NO_HALO: 1 = never use the halo-staged layer-1 kernel
-    kOptHaloBlocks,        // LBC_HALO_BLOCKS: cap on its persistent workgroups (tests: force multi-tile workgroups)
-    kOptWgradBigM,         // LBC_WGRAD_BIGM
-    kOptWgradBlocks,       // LBC_WGRAD_BLOCKS
-    kOptWgradKb,           // LBC_WGRAD_KB
-    kOptNoWgradTr,         // LBC_NO_WGRAD_TR: 1 = never use the tap-fused weight gradient
-    kOptWgradTrBlocks,     // LBC_WGRAD_TR_BLOCKS
-    kOptHeadNoMfma,        // LBC_HEAD_NO_MFMA
-    kOptNoFuseZ1,          // LBC_NO_FUSE_Z1 (read when a network is created): 1 = every block writes z1 = relu(bn1(y1)), 0 = none does
-    kOptDgradWt,           // LBC_DGRAD_WT (read when a network is created)
+    kOptHaloBlocks,        // LBC_HALO_BLOCKS: cap on the persistent workgroups of the 64-channel kernels (tests: force multi-tile workgroups)
+    kOptHeadNoMfma,        // LBC_HEAD_NO_MFMA: 1 = the f32 head kernels in the bf16 mode too (tests)
     kOptNoSideStream,      // LBC_NO_SIDE_STREAM (read when a network is created)
-    kOptNoGemm256,         // LBC_NO_GEMM256: 1 = never use the 8-wave direct-to-LDS convolution (conv_glds.hip)
-    kOptGemm256MinTiles,   // LBC_GEMM256_MIN_TILES: minimum tile count for that kernel (default 192; tests set 1)
-    kOptGemm256Cfg,        // LBC_GEMM256_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128)
-    kOptGldsDiag,          // LBC_GLDS_DIAG: timing experiments on conv_glds.hip (wrong results): see lbc_conv_glds_launch
-    kOptGldsV1,            // LBC_GLDS_V1: 1 = the first-generation (phase-barrier) kernel of conv_glds.hip
-    kOptGldsKt,            // LBC_GLDS_KT: 32 = 32-channel K-tiles in conv_glds2 (default 64)
-    kOptStemV1,            // LBC_STEM_V1: 1 = the first-generation bf16 stem forward (seven staged chunks per tile)
-    kOptNoBnBwdFuse,       // LBC_NO_BN_BWD_FUSE: 1 = BatchNorm-backward reduce always as its own pass (A/B, tests)
-    kOptNoHdma,            // LBC_NO_HDMA: 1 = never use the halo-staged LDS-DMA convolution (conv_hdma.hip)
-    kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (0: 256x256, 1: 256x128, 2: 128x256)
-    kOptNoHdma64,          // LBC_NO_HDMA64: 1 = the 64-channel layer keeps conv_halo.hip
-    kOptNoGldsPhased,      // LBC_NO_GLDS_PHASED: 1 = the stride-2 transposed launches keep conv_igemm.hip
-    kOptHdmaPrologue,      // LBC_HDMA_PROLOGUE: 1 = conv_hdma.hip takes forward launches with BatchNorm-on-load (in-LDS transform of the halo)
-    kOptHdmaEarly,         // LBC_HDMA_EARLY: 1 = conv_hdma.hip issues each depth step's fragment reads a full step ahead (not yet measured)
-    kOptHdmaDiag,          // LBC_HDMA_DIAG: timing experiments on conv_hdma.hip (bit mask of parts left out; wrong results)
-    kOptNoHdmaPersist,     // LBC_NO_HDMA_PERSIST: 1 = the halo-staged convolution keeps its one-tile-per-workgroup form (conv_hdma_k)
-    kOptHdmaPersistWgs,    // LBC_HDMA_PERSIST_WGS: cap on the persistent workgroups of conv_hdmap.hip (default 256 = one per CU; tests: fewer)
-    kOptHdmapProf,         // LBC_HDMAP_PROF: device address of a u64[grid][8 waves][8] buffer -> the s_memtime-stamped build of conv_hdmap_k (diagnostic)
-    kOptHdmapVar,          // LBC_HDMAP_VAR: A/B variants of conv_hdmap_k's plain forward (1 priority alternation, 2 DMA burst in the tail, 4 reads interleaved with MFMAs)
-    kOptNoWgradDefer,      // LBC_NO_WGRAD_DEFER (read when a network is created): 1 = every weight gradient launched next to its input gradient (A/B)
-    kOptDecoderPassMinCout, // LBC_DECODER_PASS_MIN_COUT: transposed convolutions with at least this many output channels pay a bn_apply pass for the LDS-DMA kernel (default 64: all three)
-    kOptWgradTrLinear,     // LBC_WGRAD_TR_LINEAR: 1 = the tap-fused weight gradient takes workgroup ids as logical ids (A/B of the XCD-major order)
-    kOptNoWgradTr2,        // LBC_NO_WGRAD_TR2: 1 = the stride-2 / transposed weight gradients stay on the generic kernel (A/B)
-    kOptWgradTr2MinWgs,    // LBC_WGRAD_TR2_MIN_WGS: the stride-2 tap-fused weight gradient takes a launch that yields at least this many workgroups of 16 chunks (default 192)
-    kOptWgradTr2Blocks,    // LBC_WGRAD_TR2_BLOCKS: workgroups per launch the split count aims at (default 256)
-    kOptGlds4w,            // LBC_GLDS_4W: the four-wave (two workgroups per CU) shapes of conv_glds2_k: 0 = never, 1 = wherever they fit, unset = measured policy
-    kOptNoC64pPre,         // LBC_NO_C64P_PRE: 1 = forward launches of the 64-channel layer with BatchNorm-on-load stay on conv_halo.hip (A/B)
-    kOptHdmaSmallMinTiles, // LBC_HDMA_SMALL_MIN_TILES: fill threshold (tiles) from which a launch with few rows takes the four-wave 128 x 64 persistent shape (default 48; tests set 1)
+    kOptNoGemm256,         // LBC_NO_GEMM256: 1 = never use the LDS-DMA convolutions (conv_glds.hip, conv_hdmap.hpp, conv_c64p.hip)
+    kOptGemm256MinTiles,   // LBC_GEMM256_MIN_TILES: minimum tile count for those kernels (default 96 / 192; tests set 1)
+    kOptGemm256Cfg,        // LBC_GEMM256_CFG: pin the tile shape of conv_glds2_k (0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64)
+    kOptNoBnBwdFuse,       // LBC_NO_BN_BWD_FUSE: 1 = BatchNorm-backward reduce always as its own pass (A/B, tests); 2 = only bn2's (the tensor-masked form of round 5) as its own pass
+    kOptNoHdma,            // LBC_NO_HDMA: 1 = never use the halo-staged LDS-DMA convolution (conv_hdmap.hpp / conv_c64p.hip)
+    kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (1: 256x128, 2: 128x256, 3: the 64-channel kernel, 4: 128x64 four waves, 5: 128x128)
+    kOptNoGldsPhased,      // LBC_NO_GLDS_PHASED: 1 = the stride-2 transposed launches keep conv_igemm.hip (tests compare the two)
+    kOptHdmaPersistWgs,    // LBC_HDMA_PERSIST_WGS: cap on the persistent workgroups of conv_hdmap_k (default one / two per CU; tests: fewer)
+    kOptWgradTr2MinWgs,    // LBC_WGRAD_TR2_MIN_WGS: the stride-2 tap-fused weight gradient takes a launch that yields at least this many workgroups of 16 chunks (default 192; tests: 1 = always, a huge value = never)
+    kOptNoC64pPre,         // LBC_NO_C64P_PRE: 1 = forward launches of the 64-channel layer with BatchNorm-on-load stay on conv_halo.hip (tests compare the two)
     kOptNoBnFold,          // LBC_NO_BN_FOLD: 1 = every BatchNorm finalize is its own launch (A/B, tests); default: folded into the consuming elementwise pass where the partial rows are few
-    kOptC64pBm,            // LBC_C64P_BM: tile rows of conv_c64p_k: 256 = eight waves, double-buffered halo, one workgroup per CU (round 3); 128 (default) = four waves, one halo buffer, two workgroups per CU
-    kOptC64pProf,          // LBC_C64P_PROF: device address of a u64[grid][8 waves][8] buffer -> conv_c64p_k stamps s_memtime around its phases (diagnostic, scripts/c64p_prof.py)
-    kOptHeadNoSplit,       // LBC_HEAD_NO_SPLIT: 1 = the MFMA head multiplies with ONE bf16 copy of its folded weights (round 3's form; A/B) instead of the high + low pair
-    kOptAdamElems,         // LBC_ADAM_ELEMS: parameter elements behind the optimizer's chunk table (set by FusedAdam; only books the launch profiler's bytes)
-    kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs (tests, A/B), unset / 1 = policy (lbc_conv_hdmap_nsplit: layer 4 at up to 16 images)
-    kOptHdmapSplitMaxTiles, // LBC_HDMAP_SPLIT_MAX_TILES: the policy splits launches of at most this many tiles (default 64)
-    kOptHdmapPre,          // LBC_HDMAP_PRE: 1 = the persistent halo-staged convolution takes forward launches with BatchNorm-on-load (in-place transform of the staged halo, conv_hdmap_k<.., PRE>; read when a network is planned: blocks then keep bn1 fused into conv2).  Built in round 4 without a GPU left to measure it.
+    kOptC64pBm,            // LBC_C64P_BM: tile rows of conv_c64p_k: 256 = eight waves, double-buffered halo, one workgroup per CU; 128 = four waves, ring halo, two per CU; unset = policy
+    kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs (tests, A/B), unset / 1 = policy (lbc_conv_hdmap_nsplit)
     kOptHdmaSmallBelow,    // LBC_HDMA_SMALL_BELOW: launches whose best eight-wave shape has fewer tiles than this take the four-wave 128 x 64 shape instead where it fits (default 160; 0 = never)
     kOptCount
 };
@@ -147,6 +120,11 @@ struct IgemmArgs {
     const float* bnb_shift;
     const float* bnb_mean;
     const float* bnb_invstd;
+    // ... with the ReLU mask given as a tensor (round 5): the output is the gradient wrt relu(bn(bnb_y) + identity) -- the block output of
+    // a BasicBlock, resnet.py:51-54 -- so the mask is bnb_mask > 0 (bnb_mask = that block output, like y) instead of bn(bnb_y) > 0, and the
+    // launch may carry a residual (the identity-path gradient of the block BEHIND it).  bnb_scale / bnb_shift are not read then.
+    // Only kernels for which lbc_igemm_fuses_bn_bwd_masked() is true honour it.
+    const void* bnb_mask;
     // Split-K scratch (nullable): launches with few output tiles may cut the gathered channels into ranges, one workgroup per (tile,
     // range), f32 partial tiles [range][M][K] here and a second launch that sums them and does the epilogue (conv_hdmap.hip).
     float* split_ws;
@@ -154,6 +132,8 @@ struct IgemmArgs {
 };
 // true when the kernel a (cfg, wmajor, mode) launch takes implements IgemmArgs::bnb_*
 bool lbc_igemm_fuses_bn_bwd(const IgemmArgs& a, int wmajor, int mode, int cfg);
+// ... and IgemmArgs::bnb_mask (+ a residual): conv_hdmap_k<.., EPI 4> and the split-K epilogue
+bool lbc_igemm_fuses_bn_bwd_masked(const IgemmArgs& a, int wmajor, int mode, int cfg);
 
 // One launch converts every convolution weight of a network to bf16, in its own layout w[A][T][B] and transposed
 // wt[B][T][A] (the depth-contiguous operand of the input-gradient / transposed-convolution GEMMs).
@@ -181,7 +161,7 @@ int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
 constexpr int kLbcGldsCfgs = 7;
 constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 persistent (C = K = 64)}
-constexpr int kLbcHdmaCfgs = 5;                             // ... 4: 128 x 64, four waves, two workgroups per CU (launches with few rows)
+constexpr int kLbcHdmaCfgs = 6;                             // ... 4: 128 x 64, four waves, two workgroups per CU (launches with few rows)
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);

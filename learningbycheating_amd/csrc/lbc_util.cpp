@@ -32,8 +32,9 @@ extern "C" const char* lbc_last_error(void) { return g_err; }
 #include <string.h>
 namespace {
 const char* const kOptNames[kOptCount] = {
-    "LBC_FORCE_CFG", "LBC_NO_HALO", "LBC_HALO_BLOCKS", "LBC_WGRAD_BIGM", "LBC_WGRAD_BLOCKS", "LBC_WGRAD_KB", "LBC_NO_WGRAD_TR",
-    "LBC_WGRAD_TR_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_FUSE_Z1", "LBC_DGRAD_WT", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256", "LBC_GEMM256_MIN_TILES", "LBC_GEMM256_CFG", "LBC_GLDS_DIAG", "LBC_GLDS_V1", "LBC_GLDS_KT", "LBC_STEM_V1", "LBC_NO_BN_BWD_FUSE", "LBC_NO_HDMA", "LBC_HDMA_CFG", "LBC_NO_HDMA64", "LBC_NO_GLDS_PHASED", "LBC_HDMA_PROLOGUE", "LBC_HDMA_EARLY", "LBC_HDMA_DIAG", "LBC_NO_HDMA_PERSIST", "LBC_HDMA_PERSIST_WGS", "LBC_HDMAP_PROF", "LBC_HDMAP_VAR", "LBC_NO_WGRAD_DEFER", "LBC_DECODER_PASS_MIN_COUT", "LBC_WGRAD_TR_LINEAR", "LBC_NO_WGRAD_TR2", "LBC_WGRAD_TR2_MIN_WGS", "LBC_WGRAD_TR2_BLOCKS", "LBC_GLDS_4W", "LBC_NO_C64P_PRE", "LBC_HDMA_SMALL_MIN_TILES", "LBC_NO_BN_FOLD", "LBC_C64P_BM", "LBC_C64P_PROF", "LBC_HEAD_NO_SPLIT", "LBC_ADAM_ELEMS", "LBC_HDMAP_SPLIT", "LBC_HDMAP_SPLIT_MAX_TILES", "LBC_HDMAP_PRE", "LBC_HDMA_SMALL_BELOW"};
+    "LBC_FORCE_CFG", "LBC_HALO_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256", "LBC_GEMM256_MIN_TILES", "LBC_GEMM256_CFG",
+    "LBC_NO_BN_BWD_FUSE", "LBC_NO_HDMA", "LBC_HDMA_CFG", "LBC_NO_GLDS_PHASED", "LBC_HDMA_PERSIST_WGS", "LBC_WGRAD_TR2_MIN_WGS", "LBC_NO_C64P_PRE",
+    "LBC_NO_BN_FOLD", "LBC_C64P_BM", "LBC_HDMAP_SPLIT", "LBC_HDMA_SMALL_BELOW"};
 struct OptTable {
     long long v[kOptCount];
     OptTable()

@@ -211,132 +211,6 @@ __global__ __launch_bounds__(256) void stem_fwd_k(StemArgs a)
     }
 }
 
-// bf16-MFMA variant (precision >= 1): the same walk, operands rounded to bf16 when the chunk is written to LDS, k padded
-// to a multiple of 16 (32 or 64 columns per filter row; the pad columns are zeroed once and never written again),
-// v_mfma_f32_32x32x16_bf16 with f32 accumulation.  16x the MFMA rate turns the stem from MFMA-bound into staging-bound.
-template <int CIN, typename T, typename XT>
-__global__ __launch_bounds__(256) void stem_fwd_bf16_k(StemArgs a)
-{
-    const XT* xpad = static_cast<const XT*>(a.xp);
-    constexpr int L = 7 * CIN;
-    constexpr int L8 = (L + 7) / 8 * 8;        // 24 or 56: what the staging covers (two threads per pixel row)
-    constexpr int L16 = (L + 15) / 16 * 16;    // 32 or 64: what the MFMAs read
-    constexpr int LD = L16 + 8;                // 80- or 144-byte rows: conflict-free ds_read_b128
-    constexpr int BM = 128, BN = 64, MT = 2;
-    constexpr int HALF = L8 / 2;               // floats per thread per pixel row (12 or 28), a multiple of 4
-    constexpr int NB = BN * L8 / 256;          // weight elements per thread per chunk (6 or 14)
-    __shared__ __attribute__((aligned(16))) __bf16 sA[2][BM * LD];
-    __shared__ __attribute__((aligned(16))) __bf16 sB[2][BN * LD];
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, kh = lane >> 5;
-    const int OH = a.H / 2, OW = a.W / 2;
-    const int Hp = a.H + 6, Wp = a.W + 6;
-    const int M = a.N * OH * OW;
-    const int m0 = blockIdx.x * BM;
-
-    // zero both buffers once: the columns [L8, L16) are never staged
-    for (int i = tid; i < 2 * BM * LD / 8; i += 256) reinterpret_cast<bf16x8*>(&sA[0][0])[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-    for (int i = tid; i < 2 * BN * LD / 8; i += 256) reinterpret_cast<bf16x8*>(&sB[0][0])[i] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-
-    const int arow = tid >> 1, half = tid & 1;
-    const bool rowok = (m0 + arow) < M;
-    long long abase;
-    {
-        const int m = rowok ? m0 + arow : 0;      // rows past M read pixel 0 and are zeroed when written to LDS
-        const int n = m / (OH * OW);
-        const int rem = m - n * OH * OW;
-        const int oy = rem / OW, ox = rem - oy * OW;
-        abase = (long long)((n * Hp + 2 * oy) * Wp + 2 * ox) * CIN + half * HALF;
-    }
-    int wrow[NB], wcol[NB];
-#pragma unroll
-    for (int q = 0; q < NB; ++q) {
-        const int idx = tid + 256 * q;
-        wrow[q] = idx / L8;
-        wcol[q] = idx - wrow[q] * L8;
-    }
-
-    f32x16 acc[MT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) acc[i][e] = 0.f;
-
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2 ra[HALF / 2];
-    float rb[NB];
-    __syncthreads();
-    for (int r = -1; r < 7; ++r) {
-        const bool more = r + 1 < 7;
-        if (more) {
-#pragma unroll
-            for (int q = 0; q < HALF / 2; ++q)
-                ra[q] = load2(xpad + abase + (long long)((r + 1) * Wp * CIN + 2 * q));   // all offsets even
-#pragma unroll
-            for (int q = 0; q < NB; ++q) {
-                const int j = wcol[q] < L ? wcol[q] : 0;
-                rb[q] = a.w[(size_t)wrow[q] * (7 * L) + (size_t)((r + 1) * L + j)];
-            }
-        }
-        if (r >= 0) {
-            const int buf = r & 1;
-#pragma unroll
-            for (int g = 0; g < L16 / 16; ++g) {
-                const bf16x8 bf = *reinterpret_cast<const bf16x8*>(&sB[buf][(wn * 32 + l31) * LD + g * 16 + kh * 8]);
-#pragma unroll
-                for (int mi = 0; mi < MT; ++mi) {
-                    const bf16x8 af = *reinterpret_cast<const bf16x8*>(&sA[buf][((wm * MT + mi) * 32 + l31) * LD + g * 16 + kh * 8]);
-                    acc[mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bf, acc[mi], 0, 0, 0);
-                }
-            }
-        }
-        if (more) {
-            const int buf = (r + 1) & 1;
-#pragma unroll
-            for (int q = 0; q < HALF / 4; ++q) {
-                f32x4 v = {ra[2 * q][0], ra[2 * q][1], ra[2 * q + 1][0], ra[2 * q + 1][1]};
-#pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    v[e] = (rowok && (half * HALF + 4 * q + e) < L) ? v[e] : 0.f;     // pad columns: exact zeros
-                *reinterpret_cast<bf16x4*>(&sA[buf][arow * LD + half * HALF + 4 * q]) = __builtin_convertvector(v, bf16x4);
-            }
-#pragma unroll
-            for (int q = 0; q < NB; ++q)
-                sB[buf][wrow[q] * LD + wcol[q]] = (__bf16)(wcol[q] < L ? rb[q] : 0.f);
-        }
-        __syncthreads();
-    }
-
-    float s1 = 0.f, s2 = 0.f;
-    const int col = wn * 32 + l31;
-#pragma unroll
-    for (int mi = 0; mi < MT; ++mi)
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-            const int row = (wm * MT + mi) * 32 + (e & 3) + 8 * (e >> 2) + 4 * kh;
-            const int m = m0 + row;
-            if (m < M) {
-                const float v = acc[mi][e];
-                Act<T>::st1(static_cast<T*>(a.y) + (size_t)m * BN + col, v);
-                s1 += v; s2 += v * v;
-            }
-        }
-    if (a.stats) {
-        float* red = reinterpret_cast<float*>(&sA[0][0]);   // [2 wm][2][64]; the main loop's last barrier has passed
-        s1 += __shfl_xor(s1, 32);
-        s2 += __shfl_xor(s2, 32);
-        if (kh == 0) { red[(wm * 2 + 0) * BN + col] = s1; red[(wm * 2 + 1) * BN + col] = s2; }
-        __syncthreads();
-        if (tid < BN) {
-            float* dst = a.stats + (size_t)blockIdx.x * 2 * BN;
-            dst[tid] = red[tid] + red[2 * BN + tid];
-            dst[BN + tid] = red[BN + tid] + red[3 * BN + tid];
-        }
-    }
-}
-
 // dW[co][r][j] = sum_m dy[m][co] * xp_row(m, r)[j]; grid (split, r)
 template <int CIN, typename T>
 __global__ __launch_bounds__(256) void stem_wgrad_k(StemWgradArgs a, int rows_per_split)
@@ -915,7 +789,7 @@ static int stem_rows_grid(int N, int H, int W, int Cin)
     const long long grid = 256 * (Cin == 3 ? 3 : 2);
     return (int)(tiles < grid ? tiles : grid);
 }
-static bool stem_fwd_rows(const StemArgs& a) { return a.bf16 && a.xp_bf16 && !lbc_opt_on(kOptStemV1); }
+static bool stem_fwd_rows(const StemArgs& a) { return a.bf16 != 0; }     // (the bf16 modes always hand over a bf16 padded image)
 
 }  // namespace
 
@@ -973,6 +847,7 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
     LbcProfScope prof("stem_fwd", 2.0 * Ms * 64 * 49 * a.Cin, (a.xp_bf16 ? 2.0 : 4.0) * (double)a.N * (a.H + 6) * (a.W + 6) * a.Cin + (a.act_bf16 ? 2.0 : 4.0) * Ms * 64, s);
     LBC_REQUIRE(!a.act_bf16 || a.bf16, "stem: bf16 output needs bf16 = 1");
     if (stem_fwd_rows(a)) {
+        LBC_REQUIRE(a.xp_bf16, "stem: the bf16 kernels read a bf16 padded image");
         const int tx = lbc_cdiv(a.W / 2, 64);
         const int ntiles = a.N * (a.H / 2) * tx;
 #define LBC_K(T, CI) hipLaunchKernelGGL((stem_fwd_rows_k<CI, T>), grid, dim3(256), 0, s, a, ntiles, tx)
@@ -981,16 +856,8 @@ int lbc_stem_fwd(const StemArgs& a, hipStream_t s)
 #undef LBC_K
         return lbc_check_launch("stem_fwd");
     }
-    if (a.bf16) {
-        LBC_REQUIRE(a.xp_bf16, "stem: the bf16 kernels read a bf16 padded image");
-#define LBC_K(T, CI) hipLaunchKernelGGL((stem_fwd_bf16_k<CI, T, __bf16>), grid, dim3(256), 0, s, a)
-        if (a.Cin == 3) LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 3);
-        else            LBC_DISPATCH_ACT(a.act_bf16, LBC_K, 7);
-#undef LBC_K
-    } else {
-        if (a.Cin == 3) hipLaunchKernelGGL((stem_fwd_k<3, float>), grid, dim3(256), 0, s, a);
-        else            hipLaunchKernelGGL((stem_fwd_k<7, float>), grid, dim3(256), 0, s, a);
-    }
+    if (a.Cin == 3) hipLaunchKernelGGL((stem_fwd_k<3, float>), grid, dim3(256), 0, s, a);
+    else            hipLaunchKernelGGL((stem_fwd_k<7, float>), grid, dim3(256), 0, s, a);
     return lbc_check_launch("stem_fwd");
 }
 

@@ -44,7 +44,7 @@ class FusedAdam:
             table[i] = r + (0,)
         assert table.itemsize == ctypes.sizeof(_lib.AdamChunk)
         self.nchunks = len(rows)
-        _lib.config_set("LBC_ADAM_ELEMS", sum(params[n].numel() for n in self.names))     # (books the launch profiler's 28 bytes per element)
+        _lib.get().lbc_adam_profile_elems(sum(params[n].numel() for n in self.names))     # (books the launch profiler's 28 bytes per element)
         self.table = torch.from_numpy(table.view(np.uint8).copy()).to(dev)
         self._keep = (params, grads)
 

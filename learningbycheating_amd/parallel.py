@@ -70,6 +70,22 @@ class StageAllReducer:
         else:
             self._reduce(lo, hi)
 
+    def participants(self):
+        """how many ranks the buckets' communicator really joins: a one from every rank, summed on the path the buckets take (same
+        group, same stream, the staging dtype if there is one).  bench.py reports it as `rccl_ranks` -- read back from the communicator,
+        not from the launcher's environment"""
+        if not self.active:
+            return 1
+        one = torch.ones(1, dtype=self.staging.dtype if self.staging is not None else self.flat.dtype, device=self.flat.device)
+        if self.comm is not None:
+            self.comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(self.comm):
+                dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.group)
+            torch.cuda.current_stream().wait_stream(self.comm)
+        else:
+            dist.all_reduce(one, op=dist.ReduceOp.SUM, group=self.group)
+        return int(round(float(one.float().item())))
+
     def fence(self):
         """the current stream waits for everything launched on the communication stream so far (gloo / CPU: launches are synchronous
         or waited for here)"""

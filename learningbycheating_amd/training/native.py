@@ -39,6 +39,7 @@ class NativeTrainer:
             # the privileged teacher is frozen (train_image_phase1.py:244-248: loaded, eval(), never stepped): its bf16 weight copies and
             # folded BatchNorm affines are derived on the first forward only
             self.teng.set_frozen(True)
+            self._teacher_versions = self._versions(teacher)
         self.cam = camera or camera_struct()
         self.opt = FusedAdam(list(student.named_parameters()), self.eng.grad_views, lr=lr)
         self.reducer = StageAllReducer(self.eng.grad_flat, self.eng.grad_spans, group, grad_dtype=grad_dtype)   # grad_dtype: see parallel.py
@@ -59,6 +60,12 @@ class NativeTrainer:
         self.side = torch.cuda.Stream(device=device) if (teacher is not None and torch.device(device).type == "cuda") else None
         self.overlap_teacher = True      # False: one stream (per-kernel timing of an instrumented step stays meaningful)
 
+    @staticmethod
+    def _versions(module):
+        """torch's in-place version counters of a module's tensors: an optimizer step, an EMA update or a `p.copy_()` on the frozen teacher
+        moves them (writes through `p.data` do not: after those call `trainer.teng.invalidate()`)"""
+        return tuple(t._version for t in list(module.parameters()) + list(module.buffers()))
+
     def _loss(self, kind, pred, target, rows, dpred):
         n = pred.shape[0]
         _lib.check(_lib.get().lbc_loss(kind, ctypes.byref(self.cam), _lib.ptr(pred), _lib.ptr(target), n, rows,
@@ -78,6 +85,12 @@ class NativeTrainer:
         if birdview is not None:
             birdview = birdview.contiguous()
         if self.phase in (0, 1):
+            if not getattr(self.teng, "_frozen", False):        # (somebody ran the teacher through its module API since: the promise is ours again)
+                self.teng.set_frozen(True)
+            v = self._versions(self.teacher)
+            if v != self._teacher_versions:                     # the "frozen" teacher was written in place: derive its weight copies again
+                self.teng.invalidate()
+                self._teacher_versions = v
             if self.side is not None and self.overlap_teacher:
                 main = torch.cuda.current_stream(self.device)
                 self.side.wait_stream(main)                      # inputs (and last step's use of the teacher outputs) are ordered before

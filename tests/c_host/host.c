@@ -14,6 +14,7 @@ typedef int (*info_fn)(const lbc_net*, int, char*, int, int*, int*, int*);
 typedef size_t (*ws_fn)(const lbc_net*);
 typedef const char* (*str_fn)(void);
 typedef int (*stages_fn)(void);
+typedef size_t (*desc_ws_fn)(const lbc_conv_desc*);
 
 int main(int argc, char** argv)
 {
@@ -26,6 +27,19 @@ int main(int argc, char** argv)
     if (argc < 2) return 2;
     h = dlopen(argv[1], RTLD_NOW);
     if (!h) { fprintf(stderr, "%s\n", dlerror()); return 3; }
+    /* the library must be the ABI this header describes */
+    if (((stages_fn)dlsym(h, "lbc_version"))() != LBC_HIP_ABI_VERSION) { fprintf(stderr, "ABI %d != header %d\n", ((stages_fn)dlsym(h, "lbc_version"))(), LBC_HIP_ABI_VERSION); return 7; }
+    {
+        /* descriptors: one initialised as the header says is accepted (a size query: no device work), a zeroed / stale one refused */
+        lbc_conv_desc c = LBC_CONV_DESC_INIT, stale;
+        c.N = 2; c.H = 8; c.W = 8; c.C = 64; c.K = 64; c.KH = 3; c.KW = 3; c.S = 1; c.P = 1;
+        if (c.struct_size != sizeof(lbc_conv_desc) || c.split_workspace != NULL || c.relu != 0) return 8;
+        if (((desc_ws_fn)dlsym(h, "lbc_conv2d_wgrad_workspace"))(&c) == 0) return 9;
+        memset(&stale, 0, sizeof(stale));
+        stale.N = 2; stale.H = 8; stale.W = 8; stale.C = 64; stale.K = 64; stale.KH = 3; stale.KW = 3; stale.S = 1; stale.P = 1;
+        if (((desc_ws_fn)dlsym(h, "lbc_conv2d_wgrad_workspace"))(&stale) != 0) return 10;
+        if (!strstr(((str_fn)dlsym(h, "lbc_last_error"))(), "struct_size")) return 11;
+    }
     memset(&d, 0, sizeof(d));
     d.arch = 34; d.in_channels = 3; d.H = 160; d.W = 384; d.normalize = 1; d.max_batch = 2; d.precision = 0;
     if (((create_fn)dlsym(h, "lbc_net_create"))(&d, &net) != 0) {

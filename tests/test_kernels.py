@@ -383,7 +383,7 @@ WTR2_REAL = [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128), (64, 20
 @pytest.mark.parametrize("cfg", WTR2_SMALL + WTR2_REAL)
 def test_conv_wgrad_stride2_tap_fused(env, cfg, lbc_config):
     """image borders (top / left taps), several images per split, output rows that end inside a 16-pixel group, ring wrap; bit-compared with
-    nothing (its summation order is its own): against torch on bf16-rounded operands, and against the generic kernel (LBC_NO_WGRAD_TR2=1)"""
+    nothing (its summation order is its own): against torch on bf16-rounded operands, and against the generic kernel (LBC_WGRAD_TR2_MIN_WGS huge = never)"""
     dev, _ = env
     lbc_config("LBC_WGRAD_TR2_MIN_WGS", 1)       # (the kernel is selected from ~192 workgroups of work; here at any size)
     N, H, W, C, K = cfg
@@ -395,7 +395,7 @@ def test_conv_wgrad_stride2_tap_fused(env, cfg, lbc_config):
     F.conv2d(x, w1, None, 2, 1).backward(dy)
     dw = Conv(dev).wgrad(x, dy, 3, 2, 1, bf16=2)
     assert relerr(dw, w1.grad) < 1e-4
-    lbc_config("LBC_NO_WGRAD_TR2", 1)
+    lbc_config("LBC_WGRAD_TR2_MIN_WGS", 1 << 40)
     assert relerr(dw, Conv(dev).wgrad(x, dy, 3, 2, 1, bf16=2)) < 1e-5
 
 
@@ -419,7 +419,7 @@ def test_deconv_wgrad_stride2_tap_fused(env, cfg, lbc_config):
     F.conv_transpose2d(xn, w1, None, 2, 1, 1).backward(dy)
     _, dw = bwd(dy)
     assert relerr(dw, w1.grad) < 5e-4      # (fma vs mul + add in front of the operand's bf16 rounding)
-    lbc_config("LBC_NO_WGRAD_TR2", 1)
+    lbc_config("LBC_WGRAD_TR2_MIN_WGS", 1 << 40)
     _, dw0 = bwd(dy)
     assert relerr(dw, dw0) < 1e-5
 
@@ -472,27 +472,17 @@ def test_conv_glds_stride2_transposed_phases(env, case, lbc_config):
     yy.backward(dy)
     dx = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
     assert relerr(dx, xg.grad) < 1e-4 + OUT_TOL[2]
-    if early_reads_checked(dev):
-        lbc_config("LBC_HDMA_EARLY", 1)
-        assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True), dx)
-        lbc_config("LBC_HDMA_EARLY", 0)
     lbc_config("LBC_NO_GLDS_PHASED", 1)
     dx2 = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
     assert relerr(dx, dx2) < 2.0 ** -7
-
-
-def early_reads_checked(dev):
-    """the LBC_HDMA_EARLY variants (fragment reads a full depth step ahead, hand-counted lgkmcnt waits) are compared bit for bit with
-    the default kernels: on the emulator, which checks their address pipeline, and on the GPU, which checks their wait counts (they
-    ran there in round 3: profiles/r03_run1_early_pytest.log; LBC_TEST_EXPERIMENTAL=0 skips them)"""
-    return dev.type == "cpu" or os.environ.get("LBC_TEST_EXPERIMENTAL", "1") != "0"
 
 
 def test_conv_launch_policy_at_the_per_gpu_batches(env, lbc_config):
     """which tile shape a 3x3 / stride-1 launch of the ResNet-34 layers (resnet.py:164) gets at the per-GPU batches of the 1 / 2 / 4 / 8
     GPU runs -- host logic only, read off the statistics-row count of a query call (rows = M / tile rows).  Eight-wave 256 x 128 tiles
     where they fill the CUs; launches that would be fewer than 160 of them take the four-wave 128 x 64 shape where its 184-row halo holds
-    the image rows (layers 3 / 4; measured in profiles/r04_run16_small_tiles_at_120.log); LBC_HDMA_SMALL_BELOW=0 switches that off."""
+    the image rows (layers 3 / 4; measured in profiles/r04_run16_small_tiles_at_120.log) and the eight-wave 128 x 128 shape where it does
+    not (layer 2 at 32 images: round 5); LBC_HDMA_SMALL_BELOW=0 switches both off."""
     from learningbycheating_amd import _lib
     lib = _lib.get()
 
@@ -506,30 +496,24 @@ def test_conv_launch_policy_at_the_per_gpu_batches(env, lbc_config):
     expect = {(256, L2): 256, (256, L3): 256, (256, L4): 256,      # 960 / 480 / 240 eight-wave tiles
               (128, L2): 256, (128, L3): 256, (128, L4): 128,      # layer 4: 120 eight-wave tiles -> 480 four-wave tiles
               (64, L2): 256, (64, L3): 128, (64, L4): 128,         # layer 3: 120 -> 480; layer 4: 60 eight-wave tiles are below the fill threshold anyway
-              (32, L2): 256, (32, L3): 128, (32, L4): 128}         # layer 2 (120 tiles): its 48-pixel rows need a 226-row halo, the four-wave shape holds 184
+              (32, L2): 128, (32, L3): 128, (32, L4): 128}         # layer 2 (120 eight-wave tiles): its 48-pixel rows need a 226-row halo, the four-wave shape holds 184 -> 240 tiles of 128 x 128
     for (N, shape), bm in expect.items():
         r, M = rows(N, *shape)
         assert r == -(-M // bm), (N, shape, r, M, bm)
     lbc_config("LBC_HDMA_SMALL_BELOW", 0)
     assert rows(128, *L4)[0] == -(-128 * 60 // 256) and rows(64, *L3)[0] == -(-64 * 240 // 256)
     assert rows(64, *L4)[0] == -(-64 * 60 // 128)                  # (below the eight-wave fill threshold: unchanged)
-
-
-def hdmap_pre_checked(dev):
-    """BatchNorm-on-load inside the persistent convolution (LBC_HDMAP_PRE=1, off by default) was built after the round's GPU time was
-    spent: its addressing and schedule are checked on the emulator; what only the GPU can check -- that the counted vmcnt wait really
-    covers the piece a lane reads back -- runs there with LBC_TEST_HDMAP_PRE=1 (first thing to do before measuring it)."""
-    return dev.type == "cpu" or os.environ.get("LBC_TEST_HDMAP_PRE", "0") == "1"
+    assert rows(32, *L2)[0] == -(-32 * 960 // 256)
 
 
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
-HDMA_BM = {0: 256, 1: 256, 2: 128, 3: 256, 4: 128}      # tile rows of LBC_HDMA_CFG 0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves)
-HDMA_SMALL = [(2, 9, 17, 64, 256, 0), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
-              (1, 20, 24, 64, 512, 0), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2), (3, 10, 24, 128, 128, 4), (2, 5, 12, 192, 256, 4), (1, 9, 27, 64, 192, 4),
+HDMA_BM = {1: 256, 2: 128, 3: 256, 4: 128, 5: 128}      # tile rows of LBC_HDMA_CFG 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves), 5: 128x128 (round 5)
+HDMA_SMALL = [(2, 9, 17, 64, 256, 5), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
+              (1, 20, 24, 64, 512, 5), (1, 3, 30, 192, 256, 2), (2, 16, 48, 128, 128, 5), (3, 7, 59, 128, 256, 5), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2), (3, 10, 24, 128, 128, 4), (2, 5, 12, 192, 256, 4), (1, 9, 27, 64, 192, 4),
               (2, 6, 12, 512, 128, 4),
               (2, 9, 17, 64, 64, 3), (5, 12, 40, 64, 64, 3), (1, 7, 96, 64, 64, 3)]       # the last three: several tiles per persistent workgroup needs LBC_HALO_BLOCKS-like forcing on the GPU only
 HDMA_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, -1), (64, 10, 24, 256, 256, -1), (256, 5, 12, 512, 512, -1),
-                                                   (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 0),
+                                                   (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 5), (32, 20, 48, 128, 128, 5),
                                                    (32, 40, 96, 64, 64, -1), (40, 48, 48, 64, 64, -1),
                                                    (32, 5, 12, 512, 512, 4), (32, 10, 24, 256, 256, 4)]]      # (the last two: layer 4 / 3 at 32 images, split-K)
 
@@ -577,46 +561,6 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         rr = rbf(torch.randn(x.shape, generator=g))
         dx = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
         assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
-    # BatchNorm(+ReLU) of the producer on load: an in-place transform of the staged halo (LBC_HDMA_PROLOGUE=1), against the reference
-    # and against the register-staged kernel (same rounding points: f32 affine of the bf16 input, rounded to bf16 once)
-    if not (C == 64 and K == 64) and cfgid != 4:          # (the four-wave persistent shape has no on-load transform)
-        ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
-        xin = rbf(F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)))
-        refp = F.conv2d(xin, rbf(w), None, 1, 1)
-        lbc_config("LBC_HDMA_PROLOGUE", 1)
-        yp, stp = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
-        assert relerr(yp, refp) < 5e-4 + OUT_TOL[2]      # fma vs mul+add before a rounding boundary, see test_conv_fwd_bf16_mode
-        assert torch.allclose(stp[:, 0].sum(0), refp.sum((0, 2, 3)), rtol=2e-3, atol=2e-2)
-        lbc_config("LBC_HDMA_PROLOGUE", 0)
-        yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
-        assert relerr(yp, yq) < 2.0 ** -7
-    # The same transform inside the PERSISTENT kernel (conv_hdmap_k<.., PRE>, LBC_HDMAP_PRE=1): every lane transforms the 16-byte halo
-    # pieces it requested itself, two K-tiles after the request, under the MFMAs of the third.  Against the reference and the
-    # register-staged kernel; with one / two workgroups for the whole launch (several tiles per workgroup: the next tile's first halo
-    # is transformed during the current tile's last slab) bit-identical to the default grid.
-    pre_fits = {1: W <= 59 and C <= (256 if W > 30 else 512), 2: W <= 27 and C <= 256, 4: W <= 27 and C <= 256, -1: True}      # the persistent shape's halo rows, its LDS left for the coefficient table
-    if not (C == 64 and K == 64) and pre_fits.get(cfgid, False) and hdmap_pre_checked(dev):
-        ps, pt = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g)
-        xin = rbf(F.relu(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)))
-        refp = F.conv2d(xin, rbf(w), None, 1, 1)
-        lbc_config("LBC_HDMAP_PRE", 1)
-        yp, stp = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
-        if cfgid >= 0:
-            assert stp.shape[0] == -(-M // HDMA_BM[cfgid])       # (the kernel under test, not the generic kernel's 64-row tiles)
-        assert relerr(yp, refp) < 5e-4 + OUT_TOL[2]
-        assert torch.allclose(stp[:, 0].sum(0), refp.sum((0, 2, 3)), rtol=2e-3, atol=2e-2)
-        assert torch.allclose(stp[:, 1].sum(0), (refp * refp).sum((0, 2, 3)), rtol=2e-3)
-        ynr, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, False), bf16=3)           # no ReLU on load
-        assert relerr(ynr, F.conv2d(rbf(x * ps.view(1, -1, 1, 1) + pt.view(1, -1, 1, 1)), rbf(w), None, 1, 1)) < 5e-4 + OUT_TOL[2]
-        if cfgid >= 0:
-            for wgs in (1, 2):
-                lbc_config("LBC_HDMA_PERSIST_WGS", wgs)
-                yb, stb = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), stats=True, bf16=3)
-                assert torch.equal(yb, yp) and torch.equal(stb, stp), wgs
-            lbc_config("LBC_HDMA_PERSIST_WGS", -1)
-        lbc_config("LBC_HDMAP_PRE", 0)
-        yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
-        assert relerr(yp, yq) < 2.0 ** -7
     if C == 64 and K == 64 and cfgid in (3, -1):
         # the 64-channel persistent kernel transforms its staged halo in place (conv_c64p_k<0, 0, true>): against the reference, and against
         # the register-staged kernel it replaces (LBC_NO_C64P_PRE=1 -> conv_halo.hip); same rounding points
@@ -632,27 +576,12 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         yq, _ = Conv(dev).fwd(x, w, 1, 1, pre=(ps, pt, True), bf16=3)
         assert relerr(yp, yq) < 2.0 ** -7
         lbc_config("LBC_NO_C64P_PRE", 0)
-    # LBC_HDMA_EARLY=1 (fragment reads issued a full depth step ahead, hand-counted lgkmcnt waits): the same MFMAs in the same
-    # order -> bit-identical (the emulator checks its address pipeline, the GPU its wait counts)
-    if cfgid not in (3, 4) and early_reads_checked(dev):
-        lbc_config("LBC_HDMA_EARLY", 1)
-        ye, ste = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
-        assert torch.equal(ye, y) and torch.equal(ste, st)
-        if K % 64 == 0 and C % 128 == 0:
-            dxe = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
-            assert torch.equal(dxe, dx)
-        lbc_config("LBC_HDMA_EARLY", 0)
-    # cfg 1 / 2 run the PERSISTENT form (conv_hdmap.hpp) by default.  One / two workgroups for the whole launch: a workgroup walks
-    # several tiles (halo and weight prefetch across the tile boundary, wave-private copy-out, stores in flight under the next
-    # tile) -- and the one-tile-per-workgroup kernel (conv_hdma_k): same MFMAs in the same order, same order of the statistics
-    # sums -> bit-identical outputs and statistics rows
-    if cfgid in (1, 2, 4):
+    # The PERSISTENT kernel (conv_hdmap.hpp) with one / two workgroups for the whole launch: a workgroup walks several tiles (halo and
+    # weight prefetch across the tile boundary, wave-private copy-out, stores in flight under the next tile) -- same MFMAs in the same
+    # order, same order of the statistics sums -> bit-identical outputs and statistics rows
+    if cfgid in (1, 2, 4, 5):
         have_dx = K % 64 == 0 and (C % 128 == 0 or (cfgid == 4 and C % 64 == 0))
-        # (LBC_HDMAP_VAR=16: compiler-managed fragment reads in place of the shipped inline-asm reads with hand-counted lgkmcnt waits -- same arithmetic; what it exercises, the
-        #  wait counts, exists on the GPU only)
-        for opt, val in (("LBC_HDMA_PERSIST_WGS", 1), ("LBC_HDMA_PERSIST_WGS", 2), ("LBC_NO_HDMA_PERSIST", 1), ("LBC_HDMAP_VAR", 16)):
-            if cfgid == 4 and opt == "LBC_NO_HDMA_PERSIST":
-                continue                  # (the four-wave shape exists in the persistent form only)
+        for opt, val in (("LBC_HDMA_PERSIST_WGS", 1), ("LBC_HDMA_PERSIST_WGS", 2)):
             lbc_config(opt, val)
             yb, stb = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
             assert torch.equal(yb, y) and torch.equal(stb, st), (opt, val)
@@ -712,11 +641,6 @@ def test_conv_glds_stride2_gather(env, case, lbc_config):
     y, st = Conv(dev).fwd(x, w, 2, p, stats=True, bf16=3)
     assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
     assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
-    if early_reads_checked(dev):
-        lbc_config("LBC_HDMA_EARLY", 1)
-        ye, ste = Conv(dev).fwd(x, w, 2, p, stats=True, bf16=3)
-        assert torch.equal(ye, y) and torch.equal(ste, st)
-        lbc_config("LBC_HDMA_EARLY", 0)
     lbc_config("LBC_NO_GEMM256", 1)
     y3, _ = Conv(dev).fwd(x, w, 2, p, bf16=3)
     assert relerr(y, y3) < 2.0 ** -7
@@ -896,19 +820,14 @@ GLDS_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, 3, -1),
                                                    (7, 20, 48, 128, 128, 3, 1), (7, 20, 48, 128, 128, 3, 3)]]
 
 
-@pytest.mark.parametrize("gen", [2, 1])
 @pytest.mark.parametrize("case", _glds_cases() + GLDS_REAL)
-def test_conv_glds_fwd_dgrad(env, case, gen, lbc_config):
+def test_conv_glds_fwd_dgrad(env, case, lbc_config):
     """forward with the epilogue variants (statistics; residual + ReLU) and the input gradient (flipped taps, identity
     gradient added) against f32 convolutions of the bf16-rounded operands, for every tile shape; ragged M tails, image
     borders inside a tile, several images per tile, 1 .. 18 depth steps"""
     dev, _ = env
     from learningbycheating_amd import _lib
     N, H, W, C, K, k, cfgid = case
-    if gen == 1:
-        if cfgid >= 4:
-            pytest.skip("512 x 64 and four-wave tiles exist in the second-generation kernel only")
-        lbc_config("LBC_GLDS_V1", 1)       # the first-generation (phase-barrier) kernel, kept for A/B runs
     lbc_config("LBC_NO_HDMA", 1)           # this test is about conv_glds.hip (3x3 stride-1 launches prefer conv_hdma.hip otherwise)
     if cfgid >= 0:
         lbc_config("LBC_GEMM256_MIN_TILES", 1)
@@ -941,13 +860,6 @@ def test_conv_glds_fwd_dgrad(env, case, gen, lbc_config):
         rr = rbf(torch.randn(x.shape, generator=g))
         dx = Conv(dev).dgrad(dy, w, H, W, 1, p, resid=rr, bf16=3, transposed=True)
         assert relerr(dx, xg.grad + rr) < 1e-4 + OUT_TOL[2]
-    if gen == 2 and early_reads_checked(dev):
-        lbc_config("LBC_HDMA_EARLY", 1)
-        ye, ste = Conv(dev).fwd(x, w, 1, p, stats=True, bf16=3)
-        assert torch.equal(ye, y) and torch.equal(ste, st)
-        if C % 128 == 0:
-            assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 1, p, resid=rr, bf16=3, transposed=True), dx)
-        lbc_config("LBC_HDMA_EARLY", 0)
     # 4. A/B: the generic kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_GEMM256", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, p, bf16=3)

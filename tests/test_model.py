@@ -665,13 +665,24 @@ def test_bn_backward_reduce_fused_into_dgrad_epilogue(env, kind, backbone, h, w,
     x, speed, cmd = _inputs(kind, n, h, w, 9)
     g = torch.Generator().manual_seed(6)
     d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g), torch.randn((n, 5, 2), generator=g)
-    grads = []
+    grads, reduces = [], []
     for nofuse in (0, 1):
         lbc_config("LBC_NO_BN_BWD_FUSE", nofuse)
         eng, _ = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=2)
         eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
-        eng.backward(d_sel.to(dev), d_all.to(dev))
+        reduces.append(_launch_counts(lambda: eng.backward(d_sel.to(dev), d_all.to(dev))).get("bn_bwd_reduce", 0))
         grads.append({k: v.detach().cpu().clone() for k, v in eng.grad_views.items()})
+    # Passes left: bn1's reduce rides on conv2's input gradient in every block; bn2's (round 5) on the input gradient of the NEXT block's
+    # conv1 -- which IS the gradient wrt this block's output -- wherever that launch takes the persistent halo-staged kernel
+    # (conv_hdmap_k<.., EPI 4>: mask with the block output, residual = the next block's identity gradient) and the next block has no
+    # downsample.  Unfused: bn1 + bn2 per block, the three downsamples, and per decoder stage the BatchNorm and the ReLU / bias pass.
+    nblk = {"resnet18": 8, "resnet34": 16}[backbone]
+    assert reduces[1] == 2 * nblk + 9, reduces
+    if glds or h >= 160:
+        pairs = {"resnet18": 3, "resnet34": 10}[backbone]      # blocks of layers 2-4 behind a block without downsample
+        assert reduces[0] == nblk + 9 - pairs, reduces
+    else:
+        assert reduces[0] < reduces[1], reduces
     rel = []
     for k in grads[0]:
         a, b = grads[0][k], grads[1][k]
@@ -817,42 +828,6 @@ def test_split_k_convolutions_inside_the_network(env, kind, backbone, h, w, n, l
     #  the float64 frozen-decision oracle instead: above for the small network, test_bf16_gradients_with_frozen_decisions_full_size[2] on the GPU)
 
 
-@pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 32, marks=gpu)])
-def test_bn1_on_load_in_the_persistent_convolution(env, kind, backbone, h, w, n, lbc_config):
-    """LBC_HDMAP_PRE=1 (off by default; built without a GPU left to measure it): conv2 of every BasicBlock of layers 2-4 (resnet.py:38-54)
-    reads the raw conv1 output and applies bn1 + ReLU to the staged halo itself -- the z1 pass of those blocks disappears, conv2's weight
-    gradient and bn1's backward take bn1 on load as they do in layer 1.  Fewer bn_apply launches, no generic-kernel launch in their place,
-    and the gradients under the float64 frozen-decision oracle bound of the mode."""
-    from test_kernels import hdmap_pre_checked
-    dev, _ = env
-    if not hdmap_pre_checked(dev):
-        pytest.skip("LBC_HDMAP_PRE has not run on a GPU yet: LBC_TEST_HDMAP_PRE=1 to include it")
-    small = h < 160
-    if small:
-        lbc_config("LBC_GEMM256_MIN_TILES", 1)
-    sd = O.make_state_dict(kind, backbone, 43, h, w)
-    x, speed, cmd = _inputs(kind, n, h, w, 44)
-    g = torch.Generator().manual_seed(45)
-    d_all, d_sel = torch.randn((n, 4, 5, 2), generator=g), torch.randn((n, 5, 2), generator=g)
-    counts = []
-    for pre in (0, 1):
-        lbc_config("LBC_HDMAP_PRE", pre)
-        eng, tens = engine_from_state_dict(sd, kind, backbone, h, w, n, dev, precision=2)
-
-        def step():
-            eng.forward(x.to(dev), speed.to(dev), cmd.to(dev), True)
-            eng.backward(d_sel.to(dev), d_all.to(dev))
-        counts.append(_launch_counts(step))
-        if pre:
-            _frozen_gradient_check(dev, kind, backbone, h, w, n, 2, 0.35 if small else BF16_FROZEN_MAX * 1.5)
-    c0, c1 = counts
-    deep_blocks = {"resnet18": 6, "resnet34": 13}[backbone]
-    _diag(dev, "bn1 on load in the persistent convolution %s %s %dx%d N=%d: bn_apply launches %d -> %d, generic-kernel forward launches %d -> %d"
-          % (kind, backbone, h, w, n, c0.get("bn_apply", 0), c1.get("bn_apply", 0), c0.get("conv_igemm_gather", 0), c1.get("conv_igemm_gather", 0)))
-    assert c1.get("bn_apply", 0) == c0.get("bn_apply", 0) - deep_blocks, (c0, c1)
-    assert c1.get("conv_igemm_gather", 0) <= c0.get("conv_igemm_gather", 0), (c0, c1)
-
-
 @pytest.mark.parametrize("precision", ["bf16"])
 def test_frozen_teacher_derives_its_weight_copies_once(env, precision):
     """lbc_net_set_frozen (NativeTrainer sets it on the privileged teacher, train_image_phase1.py:244-248): the second eval-mode
@@ -938,7 +913,7 @@ def test_batch_below_the_planned_maximum(env, kind, backbone, h, w, nmax, n, lbc
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
-@pytest.mark.parametrize("precision", [1, 2, "2-tiles128", "2-glds", "2-hdma-prologue", "2-hdmap-pre"])
+@pytest.mark.parametrize("precision", [1, 2, "2-tiles128", "2-glds"])
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 4), pytest.param("image", "resnet34", 160, 384, 8, marks=gpu),
                                                  pytest.param("birdview", "resnet18", 192, 192, 8, marks=gpu)])
 def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, lbc_config):
@@ -952,20 +927,6 @@ def test_engine_bf16_mfma_mode(env, kind, backbone, h, w, n, precision, lbc_conf
         # the tile policy of large batches (128-row tiles: the halo-staged layer-1 kernel, 128 x 64 / 128 x 128 igemm tiles)
         # on a test-sized batch
         lbc_config("LBC_FORCE_CFG", 0)
-        precision = 2
-    if precision == "2-hdma-prologue":
-        # as "2-glds", and the halo-staged kernel applies bn1 on load itself (in-LDS transform): conv2 reads y1 again, no z1 pass
-        lbc_config("LBC_GEMM256_MIN_TILES", 1)
-        lbc_config("LBC_HDMA_PROLOGUE", 1)
-        precision = 2
-    if precision == "2-hdmap-pre":
-        # as "2-glds", and the PERSISTENT halo-staged kernel applies bn1 on load (LBC_HDMAP_PRE=1, off by default and not yet run on a
-        # GPU: tests/test_kernels.py hdmap_pre_checked): the blocks of layers 2-4 fuse bn1 into conv2, its weight gradient and bn1's backward
-        from test_kernels import hdmap_pre_checked
-        if not hdmap_pre_checked(dev):
-            pytest.skip("LBC_HDMAP_PRE has not run on a GPU yet: LBC_TEST_HDMAP_PRE=1 to include it")
-        lbc_config("LBC_GEMM256_MIN_TILES", 1)
-        lbc_config("LBC_HDMAP_PRE", 1)
         precision = 2
     if precision == "2-glds":
         # the 8-wave LDS-DMA convolution (conv_glds.hip) for every stride-1 3x3 layer with >= 128 output channels, which

@@ -90,6 +90,7 @@ def _reduce_worker(rank, world, port, q, grad_dtype=None):
     for st in range(6):
         red.launch(st)
     red.wait()
+    ranks_seen = red.participants()       # read back from the buckets' communicator (bench.py's `rccl_ranks`)
     # initial weights: rank 0's values everywhere, including the channels_last 4-D tensors
     from learningbycheating_amd.parallel import broadcast_module
     from learningbycheating_amd.bird_view.models import BirdViewPolicyModelSS
@@ -99,7 +100,7 @@ def _reduce_worker(rank, world, port, q, grad_dtype=None):
     w = net.conv.layer2[0].conv1.weight.data
     assert not w.is_contiguous() and w.is_contiguous(memory_format=torch.channels_last)
     # numpy: pickled by value (a torch tensor is passed as a shared-memory handle that dies with this process)
-    q.put((rank, mine[::100003].numpy().copy(), flat[::100003].numpy().copy(), w.contiguous().numpy().copy(), net.deconv[1].bias.data.numpy().copy()))
+    q.put((rank, mine[::100003].numpy().copy(), flat[::100003].numpy().copy(), w.contiguous().numpy().copy(), net.deconv[1].bias.data.numpy().copy(), ranks_seen))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -113,6 +114,31 @@ def test_staged_allreduce_gloo_world2():
     want = res[0][1] + res[1][1]
     assert torch.allclose(res[0][2], want) and torch.allclose(res[1][2], want)
     assert torch.equal(res[0][3], res[1][3]) and torch.equal(res[0][4], res[1][4])      # broadcast_module
+    assert res[0][5] == 2 and res[1][5] == 2                                               # StageAllReducer.participants
+
+
+def test_staged_allreduce_gloo_world8():
+    """the world size of the metric (8 x 32 images): eight ranks, six stage buckets each, f32 on the wire -- every rank ends with the sum of
+    the eight shards, rank 0's initial weights, and reads 8 participants back from the buckets' communicator"""
+    res = _as_tensors(_run_world(_reduce_worker, 8, timeout=900))
+    assert [r[0] for r in res] == list(range(8))
+    want = sum(r[1].double() for r in res)
+    for r in res:
+        assert torch.allclose(r[2].double(), want, rtol=1e-5, atol=1e-5), r[0]
+        assert torch.equal(r[2], res[0][2]) and torch.equal(r[3], res[0][3]) and torch.equal(r[4], res[0][4]), r[0]
+        assert r[5] == 8, r[5]
+
+
+def test_staged_allreduce_bf16_buckets_gloo_world8():
+    """bf16 on the wire at world 8 (BASELINE config 3's bucket dtype): all ranks identical, within the roundings of a bf16 reduction of
+    eight bf16-rounded shards (<= 8 x 2^-9 of the magnitudes summed), and 8 participants read back through the bf16 staging path"""
+    res = _as_tensors(_run_world(_reduce_worker, 8, extra=(torch.bfloat16,), timeout=900))
+    shards = [r[1].bfloat16().double() for r in res]
+    want, mag = sum(shards), sum(s.abs() for s in shards)
+    for r in res:
+        assert torch.equal(r[2], res[0][2]), r[0]
+        assert r[5] == 8, r[5]
+    assert ((res[0][2].double() - want).abs() <= mag * 8 * 2.0 ** -9 + 1e-6).all()
 
 
 def test_staged_allreduce_bf16_buckets_gloo_world2():
