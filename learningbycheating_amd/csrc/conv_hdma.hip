@@ -29,9 +29,10 @@ namespace {
 
 struct HdmaCfg { int bm, bn, hrmax; };
 // cfg ids kLbcCfgHdma + i.  0 (256 x 256) existed in the one-tile-per-workgroup kernel only: retired, the id stays reserved.
-// 3: conv_c64p.hip; 4: four waves, two workgroups per CU; 5 (round 5): eight waves on a 128 x 128 tile, for launches whose 256 x 128
-// tiling would leave half the CUs idle and whose image rows do not fit the four-wave shape's 184-row halo (layer 2 at 32 images per GPU)
-const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{0, 0, 0}, {256, 128, 384}, {128, 256, 192}, {256, 64, 456}, {128, 64, 192}, {128, 128, 256}};
+// 3: conv_c64p.hip; 4: four waves, two workgroups per CU.  (Round 5 also tried eight waves on 128 x 128 tiles, 124 KB of LDS, for
+// launches whose 256 x 128 tiling leaves half the CUs idle and whose image rows do not fit the four-wave halo -- layer 2 at 32 images per
+// GPU, 240 instead of 120 workgroups: 4.24 vs 4.22 ms per step, profiles/r05_call3_*: not kept.)
+const HdmaCfg kHdmaCfg[kLbcHdmaCfgs] = {{0, 0, 0}, {256, 128, 384}, {128, 256, 192}, {256, 64, 456}, {128, 64, 192}};
 constexpr long long kHdmaSmallMinTiles = 48;      // fill threshold of the four-wave shape (r03_run13: below it the 64 x 64 register-staged tiles win)
 
 }  // namespace
@@ -78,14 +79,8 @@ int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
     // 160 tiles (62 % of the CUs).  LBC_HDMA_SMALL_BELOW=0: never.
     const long long below = lbc_opt(kOptHdmaSmallBelow) >= 0 ? lbc_opt(kOptHdmaSmallBelow) : 160;
     // (not under LBC_GEMM256_MIN_TILES: the tests' switch that sends small launches to the eight-wave shapes keeps its meaning)
-    const bool few = best >= 0 && forced < 0 && best_tiles < below && lbc_opt(kOptGemm256MinTiles) <= 0;
-    const bool prefer_small = few && a.K % 64 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4);
-    // ... and where the four-wave shape's halo is too short for the image rows (layer 2: W = 48), as 128 x 128 tiles on eight waves:
-    // twice the workgroups of the 256 x 128 tiling, one per CU (round 5)
-    const bool prefer_mid = few && !prefer_small && a.K % 128 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 5) &&
-                            (long long)lbc_cdiv(a.M, 128) * (a.K / 128) <= 256;
-    if (forced == 5 && a.K % 128 == 0 && lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 5)) return kLbcCfgHdma + 5;
-    if (prefer_mid) return kLbcCfgHdma + 5;
+    const bool prefer_small = best >= 0 && forced < 0 && best_tiles < below && a.K % 64 == 0 && lbc_opt(kOptGemm256MinTiles) <= 0 &&
+                              lbc_conv_hdmap_eligible(a, mode, kLbcCfgHdma + 4);
     if (best >= 0 && !prefer_small) return kLbcCfgHdma + best;
     // Few rows (the per-GPU load of the 8-GPU run: layer 3 / 4 at 32 images have 7680 / 1920 output pixels): 128 x 64 tiles, four waves,
     // two workgroups per CU (conv_hdmap.hpp) instead of the 64 x 64 register-staged tiles of conv_igemm.hip (31 us per 9-GFLOP launch)

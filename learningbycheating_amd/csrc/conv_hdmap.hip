@@ -7,8 +7,7 @@
 int lbc_conv_hdmap_launch_256x128_320(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_256x128_384(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_128x256_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
-int lbc_conv_hdmap_launch_128x64_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s, int nsplit);
-int lbc_conv_hdmap_launch_128x128_256(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
+int lbc_conv_hdmap_launch_128x64_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s, int nsplit, int kgroups);
 
 namespace {
 
@@ -114,7 +113,7 @@ int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
     return fits(4) ? 4 : 1;
 }
 
-// Which launches the persistent kernel takes (cfg 1: 256 x 128, 2: 128 x 256, 4: 128 x 64 on four waves, 5: 128 x 128)
+// Which launches the persistent kernel takes (cfg 1: 256 x 128, 2: 128 x 256, 4: 128 x 64 on four waves)
 bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg)
 {
     if (mode != 0 && mode != 1) return false;
@@ -124,14 +123,13 @@ bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg)
     // zero page as a whole and holds the zero row of the border select
     if (cfg == kLbcCfgHdma + 1) return 256 + 2 * a.W + 2 <= 384 - 8;
     if (cfg == kLbcCfgHdma + 2 || cfg == kLbcCfgHdma + 4) return 128 + 2 * a.W + 2 <= 192 - 8;
-    if (cfg == kLbcCfgHdma + 5) return 128 + 2 * a.W + 2 <= 256 - 8;
     return false;
 }
 
 int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
 {
     LBC_REQUIRE(lbc_conv_hdmap_eligible(a, mode, cfg), "conv_hdmap: launch not eligible");
-    const int bm = cfg == kLbcCfgHdma + 1 ? 256 : 128, bn = (cfg == kLbcCfgHdma + 1 || cfg == kLbcCfgHdma + 5) ? 128 : (cfg == kLbcCfgHdma + 4 ? 64 : 256);
+    const int bm = cfg == kLbcCfgHdma + 1 ? 256 : 128, bn = cfg == kLbcCfgHdma + 1 ? 128 : (cfg == kLbcCfgHdma + 4 ? 64 : 256);
     LBC_REQUIRE(a.K % bn == 0 && a.C % 64 == 0, "conv_hdmap: shape not tileable");
     const void* zero = nullptr;
     int rc = lbc_zero_page(&zero);
@@ -141,20 +139,24 @@ int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const int cap = lbc_opt(kOptHdmaPersistWgs) > 0 ? (int)lbc_opt(kOptHdmaPersistWgs) : (cfg == kLbcCfgHdma + 4 ? 512 : 256);
     const int nsplit = lbc_conv_hdmap_nsplit(a, mode, cfg);
     if (nsplit > 1) {
-        rc = lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, 1, (unsigned)(ntiles * nsplit), s, nsplit);
+        rc = lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, 1, (unsigned)(ntiles * nsplit), s, nsplit, 1);
         if (rc) return rc;
         const dim3 eg((unsigned)lbc_cdiv(a.M, 128), (unsigned)(a.K / 64));
         if (a.bnb_y) hipLaunchKernelGGL(conv_split_epilogue_k<true>, eg, dim3(256), 0, s, a, nsplit);
         else hipLaunchKernelGGL(conv_split_epilogue_k<false>, eg, dim3(256), 0, s, a, nsplit);
         return lbc_check_launch("conv_split_epilogue");
     }
+    // In-workgroup K split of the four-wave shape (conv_hdmap_k<.., KG = 2>): a launch of at most one tile per CU would run one wave per
+    // SIMD; as eight-wave workgroups of two K-range instances it runs two, on half the K loop each.  LBC_HDMAP_SPLIT=0: never, = n > 1: only the cross-workgroup ranges (tests
+    // that compare launches bit for bit); LBC_HDMA_PERSIST_WGS (tests: several tiles per workgroup) keeps the plain form too.
+    if (cfg == kLbcCfgHdma + 4 && ntiles <= 256 && (a.C / 64) % 2 == 0 && (lbc_opt(kOptHdmapSplit) < 0 || lbc_opt(kOptHdmapSplit) == 1) && lbc_opt(kOptHdmaPersistWgs) <= 0)
+        return lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, 1, (unsigned)ntiles, s, 1, 2);
     const int tpw = lbc_cdiv(ntiles, cap);
     const unsigned grid = (unsigned)lbc_cdiv(ntiles, tpw);
     if (cfg == kLbcCfgHdma + 1) {
         if (256 + 2 * a.W + 2 <= 320 - 8) return lbc_conv_hdmap_launch_256x128_320(a, mode, zero, ntiles, tpw, grid, s);   // W <= 30: layers 3 / 4
         return lbc_conv_hdmap_launch_256x128_384(a, mode, zero, ntiles, tpw, grid, s);
     }
-    if (cfg == kLbcCfgHdma + 4) return lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, tpw, grid, s, 1);
-    if (cfg == kLbcCfgHdma + 5) return lbc_conv_hdmap_launch_128x128_256(a, mode, zero, ntiles, tpw, grid, s);
+    if (cfg == kLbcCfgHdma + 4) return lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, tpw, grid, s, 1, 1);
     return lbc_conv_hdmap_launch_128x256_192(a, mode, zero, ntiles, tpw, grid, s);
 }

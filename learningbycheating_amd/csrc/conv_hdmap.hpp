@@ -586,7 +586,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
 
 // launches the instantiation for (mode, epilogue form) of one tile shape
 template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS>
-int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, dim3 grid, hipStream_t s, int nsplit = 1)
+int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, dim3 grid, hipStream_t s, int nsplit = 1, int kgroups = 1)
 {
     if (nsplit > 1) {
         // split-K (EPI 3): one tile per workgroup, grid = ntiles * nsplit; the epilogue is the caller's second launch
@@ -601,6 +601,24 @@ int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int 
     }
     const int epi = a.bnb_y ? (a.bnb_mask ? 4 : 2) : (a.resid ? 1 : 0);
     LBC_REQUIRE(!a.pre_scale, "conv_hdmap: no BatchNorm-on-load form (measured slower on the MI355X, profiles/r05_call1_hdmap_pre_land_or_kill.txt)");
+    if (kgroups == 2) {
+        // in-workgroup K split (KG = 2): eight waves, one tile per workgroup
+        if constexpr (BM == 128 && BN == 64) {
+            LBC_REQUIRE(tpw == 1 && grid.x == (unsigned)ntiles && (a.C / 64) % 2 == 0, "conv_hdmap: bad K-split launch");
+#define LBC_HK(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv, 2>), grid, dim3(WM * WN * 128), 0, s, a, zero, ntiles, tpw, 1)
+            if (mode == 0) {
+                LBC_REQUIRE(epi != 2 && epi != 4, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");
+                if (epi == 1) LBC_HK(0, 1); else LBC_HK(0, 0);
+            } else {
+                LBC_REQUIRE(epi != 4 || a.resid, "conv_hdmap: the tensor-masked BatchNorm-backward reduce is the residual form's (IgemmArgs::bnb_mask)");
+                if (epi == 4) LBC_HK(1, 4); else if (epi == 2) LBC_HK(1, 2); else if (epi == 1) LBC_HK(1, 1); else LBC_HK(1, 0);
+            }
+#undef LBC_HK
+            return lbc_check_launch("conv_hdmap(kg2)");
+        } else {
+            LBC_REQUIRE(false, "conv_hdmap: the in-workgroup K split exists for the 128 x 64 shape only");
+        }
+    }
 #define LBC_HP(MODEv, EPIv) hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, MODEv, EPIv>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, 1)
     if (mode == 0) {
         LBC_REQUIRE(epi != 2 && epi != 4, "conv_hdmap: the fused BatchNorm-backward reduce belongs to input-gradient launches");

@@ -45,7 +45,7 @@ enum LbcOpt {
     kOptGemm256Cfg,        // LBC_GEMM256_CFG: pin the tile shape of conv_glds2_k (0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64)
     kOptNoBnBwdFuse,       // LBC_NO_BN_BWD_FUSE: 1 = BatchNorm-backward reduce always as its own pass (A/B, tests); 2 = only bn2's (the tensor-masked form of round 5) as its own pass
     kOptNoHdma,            // LBC_NO_HDMA: 1 = never use the halo-staged LDS-DMA convolution (conv_hdmap.hpp / conv_c64p.hip)
-    kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (1: 256x128, 2: 128x256, 3: the 64-channel kernel, 4: 128x64 four waves, 5: 128x128)
+    kOptHdmaCfg,           // LBC_HDMA_CFG: pin its tile shape (1: 256x128, 2: 128x256, 3: the 64-channel kernel, 4: 128x64 four waves)
     kOptNoGldsPhased,      // LBC_NO_GLDS_PHASED: 1 = the stride-2 transposed launches keep conv_igemm.hip (tests compare the two)
     kOptHdmaPersistWgs,    // LBC_HDMA_PERSIST_WGS: cap on the persistent workgroups of conv_hdmap_k (default one / two per CU; tests: fewer)
     kOptWgradTr2MinWgs,    // LBC_WGRAD_TR2_MIN_WGS: the stride-2 tap-fused weight gradient takes a launch that yields at least this many workgroups of 16 chunks (default 192; tests: 1 = always, a huge value = never)
@@ -161,7 +161,7 @@ int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
 constexpr int kLbcGldsCfgs = 7;
 constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 persistent (C = K = 64)}
-constexpr int kLbcHdmaCfgs = 6;                             // ... 4: 128 x 64, four waves, two workgroups per CU (launches with few rows)
+constexpr int kLbcHdmaCfgs = 5;                             // ... 4: 128 x 64, four waves, two workgroups per CU (launches with few rows)
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);

@@ -481,8 +481,7 @@ def test_conv_launch_policy_at_the_per_gpu_batches(env, lbc_config):
     """which tile shape a 3x3 / stride-1 launch of the ResNet-34 layers (resnet.py:164) gets at the per-GPU batches of the 1 / 2 / 4 / 8
     GPU runs -- host logic only, read off the statistics-row count of a query call (rows = M / tile rows).  Eight-wave 256 x 128 tiles
     where they fill the CUs; launches that would be fewer than 160 of them take the four-wave 128 x 64 shape where its 184-row halo holds
-    the image rows (layers 3 / 4; measured in profiles/r04_run16_small_tiles_at_120.log) and the eight-wave 128 x 128 shape where it does
-    not (layer 2 at 32 images: round 5); LBC_HDMA_SMALL_BELOW=0 switches both off."""
+    the image rows (layers 3 / 4; measured in profiles/r04_run16_small_tiles_at_120.log); LBC_HDMA_SMALL_BELOW=0 switches that off."""
     from learningbycheating_amd import _lib
     lib = _lib.get()
 
@@ -496,24 +495,23 @@ def test_conv_launch_policy_at_the_per_gpu_batches(env, lbc_config):
     expect = {(256, L2): 256, (256, L3): 256, (256, L4): 256,      # 960 / 480 / 240 eight-wave tiles
               (128, L2): 256, (128, L3): 256, (128, L4): 128,      # layer 4: 120 eight-wave tiles -> 480 four-wave tiles
               (64, L2): 256, (64, L3): 128, (64, L4): 128,         # layer 3: 120 -> 480; layer 4: 60 eight-wave tiles are below the fill threshold anyway
-              (32, L2): 128, (32, L3): 128, (32, L4): 128}         # layer 2 (120 eight-wave tiles): its 48-pixel rows need a 226-row halo, the four-wave shape holds 184 -> 240 tiles of 128 x 128
+              (32, L2): 256, (32, L3): 128, (32, L4): 128}         # layer 2 (120 tiles): its 48-pixel rows need a 226-row halo, the four-wave shape holds 184
     for (N, shape), bm in expect.items():
         r, M = rows(N, *shape)
         assert r == -(-M // bm), (N, shape, r, M, bm)
     lbc_config("LBC_HDMA_SMALL_BELOW", 0)
     assert rows(128, *L4)[0] == -(-128 * 60 // 256) and rows(64, *L3)[0] == -(-64 * 240 // 256)
     assert rows(64, *L4)[0] == -(-64 * 60 // 128)                  # (below the eight-wave fill threshold: unchanged)
-    assert rows(32, *L2)[0] == -(-32 * 960 // 256)
 
 
 # ---- halo-staged LDS-DMA convolution (conv_hdma.hip): 3x3 stride 1, bf16 tensors + bf16 weight copies -------------------------
-HDMA_BM = {1: 256, 2: 128, 3: 256, 4: 128, 5: 128}      # tile rows of LBC_HDMA_CFG 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves), 5: 128x128 (round 5)
-HDMA_SMALL = [(2, 9, 17, 64, 256, 5), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
-              (1, 20, 24, 64, 512, 5), (1, 3, 30, 192, 256, 2), (2, 16, 48, 128, 128, 5), (3, 7, 59, 128, 256, 5), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2), (3, 10, 24, 128, 128, 4), (2, 5, 12, 192, 256, 4), (1, 9, 27, 64, 192, 4),
+HDMA_BM = {1: 256, 2: 128, 3: 256, 4: 128}      # tile rows of LBC_HDMA_CFG 1: 256x128, 2: 128x256, 3: 256x64 (persistent, C = K = 64), 4: 128x64 (four waves)
+HDMA_SMALL = [(2, 9, 17, 64, 256, 2), (1, 12, 13, 128, 256, 2), (3, 7, 9, 64, 128, 1), (2, 16, 48, 128, 128, 1), (5, 9, 13, 128, 128, 1),
+              (1, 20, 24, 64, 512, 1), (1, 3, 30, 192, 256, 2), (2, 30, 12, 64, 256, 2), (3, 20, 24, 128, 256, 1), (2, 13, 30, 64, 512, 2), (3, 10, 24, 128, 128, 4), (2, 5, 12, 192, 256, 4), (1, 9, 27, 64, 192, 4),
               (2, 6, 12, 512, 128, 4),
               (2, 9, 17, 64, 64, 3), (5, 12, 40, 64, 64, 3), (1, 7, 96, 64, 64, 3)]       # the last three: several tiles per persistent workgroup needs LBC_HALO_BLOCKS-like forcing on the GPU only
 HDMA_REAL = [pytest.param(c, marks=gpu) for c in [(32, 20, 48, 128, 128, -1), (64, 10, 24, 256, 256, -1), (256, 5, 12, 512, 512, -1),
-                                                   (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 5), (32, 20, 48, 128, 128, 5),
+                                                   (64, 24, 24, 128, 128, -1), (16, 12, 12, 256, 256, 2), (8, 6, 6, 512, 512, 1),
                                                    (32, 40, 96, 64, 64, -1), (40, 48, 48, 64, 64, -1),
                                                    (32, 5, 12, 512, 512, 4), (32, 10, 24, 256, 256, 4)]]      # (the last two: layer 4 / 3 at 32 images, split-K)
 
@@ -531,6 +529,8 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         lbc_config("LBC_HDMA_CFG", cfgid)
     if cfgid == 3:
         lbc_config("LBC_HALO_BLOCKS", 2)       # two persistent workgroups: several tiles each (the halo double buffer)
+    if cfgid == 4:
+        lbc_config("LBC_HDMAP_SPLIT", 0)       # the plain form first (what the bit-for-bit comparisons below are about); the K splits at the end
     x, w = make((N, H, W, C, K, 3, 1, 1), 290 + C + K)
     x = rbf(x)
     ref = F.conv2d(x, rbf(w), None, 1, 1)
@@ -579,7 +579,7 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
     # The PERSISTENT kernel (conv_hdmap.hpp) with one / two workgroups for the whole launch: a workgroup walks several tiles (halo and
     # weight prefetch across the tile boundary, wave-private copy-out, stores in flight under the next tile) -- same MFMAs in the same
     # order, same order of the statistics sums -> bit-identical outputs and statistics rows
-    if cfgid in (1, 2, 4, 5):
+    if cfgid in (1, 2, 4):
         have_dx = K % 64 == 0 and (C % 128 == 0 or (cfgid == 4 and C % 64 == 0))
         for opt, val in (("LBC_HDMA_PERSIST_WGS", 1), ("LBC_HDMA_PERSIST_WGS", 2)):
             lbc_config(opt, val)
@@ -611,7 +611,22 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
             small = Conv(dev, split_floats=ns * M * K - 1)
             yb, stb = small.fwd(x, w, 1, 1, stats=True, bf16=3)
             assert torch.equal(yb, y) and torch.equal(stb, st) and torch.isnan(small.split_ws).all()
-            lbc_config("LBC_HDMAP_SPLIT", -1)
+            lbc_config("LBC_HDMAP_SPLIT", 0)
+        # The in-workgroup K split (round 5; conv_hdmap_k<.., KG = 2>: the policy's choice for launches of at most one tile per CU with an
+        # even number of channel slabs -- every case here that has one): two four-wave instances per workgroup contract half the slabs
+        # each, instance 1 hands its accumulators over through LDS.  Same products, the f32 sums regrouped once: every epilogue form
+        # against the reference and within one bf16 rounding of the plain launch; statistics rows within f32 noise
+        lbc_config("LBC_HDMAP_SPLIT", -1)
+        yk, stk = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
+        assert relerr(yk, ref) < 1e-4 + OUT_TOL[2] and relerr(yk, y) < 2.0 ** -7
+        assert stk.shape == st.shape and torch.allclose(stk, st, rtol=1e-4, atol=1e-3), (stk - st).abs().max()
+        if (C // 64) % 2 == 0:
+            assert not torch.equal(stk, st), "the K-split launch did not run (its f32 sums are grouped differently)"
+        yk2, _ = Conv(dev).fwd(x, w, 1, 1, resid=r, relu=1, bf16=3)
+        assert relerr(yk2, F.relu(ref + r)) < 1e-4 + OUT_TOL[2] and relerr(yk2, y2) < 2.0 ** -7
+        if K % 64 == 0 and C % 64 == 0:
+            dxk = Conv(dev).dgrad(dy, w, H, W, 1, 1, resid=rr, bf16=3, transposed=True)
+            assert relerr(dxk, xg.grad + rr) < 1e-4 + OUT_TOL[2] and relerr(dxk, dx) < 2.0 ** -7
     # A/B: the per-tap LDS-DMA kernel on the same launch gives the same result up to summation order
     lbc_config("LBC_NO_HDMA", 1)
     y3, _ = Conv(dev).fwd(x, w, 1, 1, bf16=3)

@@ -678,9 +678,13 @@ def test_bn_backward_reduce_fused_into_dgrad_epilogue(env, kind, backbone, h, w,
     # downsample.  Unfused: bn1 + bn2 per block, the three downsamples, and per decoder stage the BatchNorm and the ReLU / bias pass.
     nblk = {"resnet18": 8, "resnet34": 16}[backbone]
     assert reduces[1] == 2 * nblk + 9, reduces
-    if glds or h >= 160:
+    if glds:
         pairs = {"resnet18": 3, "resnet34": 10}[backbone]      # blocks of layers 2-4 behind a block without downsample
         assert reduces[0] == nblk + 9 - pairs, reduces
+    elif h >= 160:
+        # 16 images on the GPU: layer 2 (60 tiles of 256 x 128, 48-pixel rows) stays on the generic kernel, which fuses neither reduce:
+        # bn1 of layers 1, 3, 4 (3 + 6 + 3) and bn2 behind the 5 + 2 plain blocks of layers 3 / 4 ride on input gradients
+        assert reduces[0] == reduces[1] - (12 + 7), reduces
     else:
         assert reduces[0] < reduces[1], reduces
     rel = []
