@@ -535,6 +535,8 @@ int lbc_bn_eval_prep(const BnEvalArgs& a, hipStream_t s)
 
 // Folding a finalize into its consumer: every workgroup reads rows x 2C floats from L2 (64 B / clk / CU) -- worth it where that is
 // a microsecond and the consumer's grid is small, i.e. where launches are the cost
+// (round 5 swept both at 32 / 64 images per GPU -- grid 256 / 512 / 1024, 64 / 128 / 256 KB of rows, no fold at all: every arm within
+//  0.5 % of the others, profiles/r05_call5_*: the fold costs what the finalize launches cost)
 constexpr long long kFoldBytes = 128 * 1024;
 constexpr int kFoldGrid = 512;           // workgroups of a folding consumer (two per CU)
 int lbc_bn_fold_max_rows(int C) { return (int)(kFoldBytes / (8ll * C)); }

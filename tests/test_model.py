@@ -204,11 +204,17 @@ def _frozen_gradient_check(dev, kind, backbone, h, w, n, precision, tol, head_to
         errs.append((relerr(v.cpu().double(), ref), k))
     errs.sort()
     es = [e for e, _ in errs]
-    _diag(dev, "frozen-decision gradient check, precision %d %s %s %dx%d N=%d: forward |pred - frozen float64 oracle| %.2e; gradients "
-               "rel-to-max over %d tensors: median %.2e p90 %.2e max %.2e (%s)"
-          % (precision, kind, backbone, h, w, n, fwd, len(es), es[len(es) // 2], es[int(len(es) * 0.9)], es[-1], errs[-1][1]))
+    group = lambda k: "head" if k.startswith("location_pred") else ("decoder" if k.startswith("deconv") else ("stem+layer1" if k.startswith(("conv.conv1", "conv.bn1", "conv.layer1")) else "layers2-4"))
+    gmax = {}
     for e, k in errs:
-        t = head_tol if (head_tol is not None and k.startswith("location_pred")) else tol
+        gmax[group(k)] = max(gmax.get(group(k), 0.0), e)
+    _diag(dev, "frozen-decision gradient check, precision %d %s %s %dx%d N=%d: forward |pred - frozen float64 oracle| %.2e; gradients "
+               "rel-to-max over %d tensors: median %.2e p90 %.2e max %.2e (%s); worst per group: %s"
+          % (precision, kind, backbone, h, w, n, fwd, len(es), es[len(es) // 2], es[int(len(es) * 0.9)], es[-1], errs[-1][1],
+             ", ".join("%s %.2e" % (g, v) for g, v in sorted(gmax.items()))))
+    for e, k in errs:
+        # tol: one bound, or one per tensor group {"head", "decoder", "layers2-4", "stem+layer1"}
+        t = tol[group(k)] if isinstance(tol, dict) else (head_tol if (head_tol is not None and k.startswith("location_pred")) else tol)
         assert e < t, ("frozen-decision gradient", k, e, t)
     return es
 
@@ -246,9 +252,11 @@ def test_bf16_gradients_with_frozen_decisions_full_size(env, split, lbc_config):
     trained-like (warm-started) ResNet-34: every parameter gradient against the float64 oracle that takes the executor's own
     ReLU / max-pool decisions AND rounds where the executor rounds (MFMA operands, stored activations and activation gradients to
     bf16: oracle flags MFMA_BF16 / ACT_BF16) -- an ABSOLUTE statement about the mode, next to the autocast-relative one below.
-    Bound: every tensor within BF16_FROZEN_MAX of its largest entry, the median tensor within BF16_FROZEN_MEDIAN (each stored tensor
-    carries 2^-9 relative rounding noise and ~1e6 such terms meet in one weight-gradient entry; the two evaluations round the same
-    quantities but not bit-identical ones, so the noise does not cancel).  Measured values: the frozen-decision line in profiles/."""
+    Bound: every tensor within BF16_FROZEN_MAX[its group] of its largest entry -- head, decoder, layers 2-4, stem + layer 1, each 1.5x
+    the value measured for that group (round 4 had ONE bound at 2x the global maximum: loose enough to pass a 2x mis-scale in a layer-4
+    BatchNorm bias) -- and the median tensor within BF16_FROZEN_MEDIAN (each stored tensor carries 2^-9 relative rounding noise and ~1e6
+    such terms meet in one weight-gradient entry; the two evaluations round the same quantities but not bit-identical ones, so the
+    noise does not cancel).  Inputs are seeded and the kernels deterministic: the measured values only move with the code."""
     from learningbycheating_amd.bird_view.models import ImagePolicyModelSS
     from learningbycheating_amd.training.native import NativeTrainer
     dev, _ = env
@@ -272,9 +280,11 @@ def test_bf16_gradients_with_frozen_decisions_full_size(env, split, lbc_config):
     assert es[len(es) // 2] < BF16_FROZEN_MEDIAN, es[len(es) // 2]
 
 
-#: bounds of test_bf16_gradients_with_frozen_decisions_full_size (rel-to-max per tensor; set from the measured values with ~2x margin)
-# measured on MI355X (profiles/r04_*_grad_diag.txt): median 2.3e-2, 90th percentile 4.0e-2, max 6.1e-2 (a layer-4 BatchNorm bias)
-BF16_FROZEN_MAX, BF16_FROZEN_MEDIAN = 0.12, 4.5e-2
+#: bounds of test_bf16_gradients_with_frozen_decisions_full_size (rel-to-max per tensor): 1.5x the larger of the two measured arms
+# (the shipped launch policy / LBC_HDMAP_SPLIT=2), profiles/r05_call5_bf16_accuracy_diag_and_fold_sweep.txt:
+#   head 7.13e-2 / 6.87e-2, decoder 5.68e-2 / 4.96e-2, layers 2-4 5.35e-2 / 5.19e-2, stem + layer 1 3.21e-2 / 3.69e-2; median 2.30e-2 / 2.42e-2
+BF16_FROZEN_MAX = {"head": 0.107, "decoder": 0.085, "layers2-4": 0.080, "stem+layer1": 0.055}
+BF16_FROZEN_MEDIAN = 3.6e-2
 
 
 @gpu
@@ -1029,18 +1039,17 @@ def test_bf16_mode_declared_accuracy(env):
         m.precision = precision
         return m.to(dev)
 
-    # (1) forward accuracy on inputs the warm start has not seen
-    x2, s2, c2 = seeded_inputs("image", n, 46)
-    oh2 = O.one_hot(c2)
-    outs = {}
-    for prec in ("fp32", "bf16"):
-        m = fresh(prec)
-        for train in (False, True):
+    # (1) forward accuracy on inputs the warm start has not seen: three batches
+    tol = pkg.WAYPOINT_TOLERANCE["bf16"]
+    for in_seed, train in [(sd_, tr_) for sd_ in (46, 146, 246) for tr_ in (False, True)]:
+        x2, s2, c2 = seeded_inputs("image", n, in_seed)
+        oh2 = O.one_hot(c2)
+        outs = {}
+        for prec in ("fp32", "bf16"):
+            m = fresh(prec)
             m.train(train)
             with torch.no_grad():
                 outs[(prec, train)] = m(x2.to(dev), s2.to(dev), oh2.to(dev))[1].cpu()
-    tol = pkg.WAYPOINT_TOLERANCE["bf16"]
-    for train in (False, True):
         with torch.no_grad():
             _, oa = O.policy_forward({k: v.clone() for k, v in ckpt.items()}, "image", "resnet34", x2, s2, oh2, train)
             with torch.autocast("cpu", dtype=torch.bfloat16):
@@ -1048,18 +1057,22 @@ def test_bf16_mode_declared_accuracy(env):
         e32 = (outs[("fp32", train)] - oa).abs().max().item()
         d = (outs[("bf16", train)] - outs[("fp32", train)]).abs()
         dc = (oc.float() - oa).abs()
-        _diag(dev, "bf16 vs f32 executor, warm-started r34 N=%d train=%s: |dwaypoint| max %.3e mean %.3e (bound %.0e); the oracle under torch "
-                   "bf16 autocast vs its own f32: max %.3e mean %.3e; f32 executor vs f32 oracle max %.2e"
-              % (n, train, d.max().item(), d.mean().item(), tol, dc.max().item(), dc.mean().item(), e32))
+        _diag(dev, "bf16 vs f32 executor, warm-started r34 N=%d inputs %d train=%s: |dwaypoint| max %.3e mean %.3e (declared %.0e); the oracle under torch "
+                   "bf16 autocast vs its own f32: max %.3e mean %.3e (ratio of the maxima %.2f, of the means %.2f); f32 executor vs f32 oracle max %.2e"
+              % (n, in_seed, train, d.max().item(), d.mean().item(), tol, dc.max().item(), dc.mean().item(), d.max().item() / dc.max().item(),
+                 d.mean().item() / dc.mean().item(), e32))
         assert e32 < 1e-4, e32
-        # the MAXIMUM over the 1280 coordinates of a batch is a noisy statistic in training mode (the batch statistics move with every
-        # rounding: one evidence run measured 2.4e-2, the next -- after a change in the ORDER of the float64 statistics sums -- 3.2e-2,
-        # with torch's own bf16 autocast of the oracle at 2.7e-2 and 4.0e-2 on the same batches): held to the declared bound in eval
-        # mode, and to the reference arithmetic's own bf16 deviation in training mode; the mean is held absolutely in both
-        bound = tol if not train else max(tol, 1.1 * dc.max().item())
-        assert d.max().item() <= bound and d.mean().item() <= pkg.WAYPOINT_MEAN_TOLERANCE["bf16"], ("bf16 waypoint deviation", train, d.max().item(), d.mean().item(), bound)
-        # as accurate as the reference under bf16 autocast (mean deviation: the max over 1280 coordinates is a noisy statistic)
-        assert d.mean().item() <= 1.5 * dc.mean().item() + 5e-4, ("bf16 executor vs autocast oracle", train, d.mean().item(), dc.mean().item())
+        # Round 5: the bound is a RATIO to what the reference arithmetic itself loses under torch's bf16 autocast on the same weights and
+        # the same batch, measured in this test (round 4 held the training-mode maximum to the constant 3e-2, which one seed met with 4 %
+        # headroom -- 2.88e-2 -- while autocast sat at 3.98e-2 on that batch: the constant tested the batch, not the mode).  Maximum
+        # within 1.25x of autocast's maximum (measured 0.6 - 0.9x), mean within 1.25x of autocast's mean (measured ~0.9x), on three
+        # batches and in both modes; eval mode additionally within the declared absolute tolerance (measured 1.2e-2 of 3e-2), and the
+        # mean within the declared mean tolerance in both
+        assert d.max().item() <= 1.25 * dc.max().item() + 1e-3, ("bf16 waypoint maximum vs autocast", in_seed, train, d.max().item(), dc.max().item())
+        assert d.mean().item() <= 1.25 * dc.mean().item() + 2e-4, ("bf16 waypoint mean vs autocast", in_seed, train, d.mean().item(), dc.mean().item())
+        assert d.mean().item() <= pkg.WAYPOINT_MEAN_TOLERANCE["bf16"], ("bf16 waypoint mean", in_seed, train, d.mean().item())
+        if not train:
+            assert d.max().item() <= tol, ("bf16 eval-mode waypoint deviation", in_seed, d.max().item(), tol)
     # (2) loss curves from the common checkpoint, same data every step.
     # (a) The warm start's own objective (L1 towards below-horizon targets in camera space: well conditioned), 200 steps: the bf16 run
     #     stays within 10 % of the f32 run at EVERY step (measured: 1.4 % over the first 50).
@@ -1117,7 +1130,7 @@ def test_bf16_phase1_fit_matches_f32_over_seeds(env):
     0.96x) -- but the synthetic phase-1 objective is chaotic (1 / y unprojection, train_image_phase1.py:43-64, one fixed batch): over
     three seeds EVERY arm, the exact-f32 run with 1e-3 input noise included, lands between 0.2x and 20x of the clean f32 run
     (profiles/r04_run1_bf16_seeds.log), so a single ratio says nothing and "within 1.25x on every seed" holds for no arm at all.
-    What can be asserted is distributional.  Six seeds (weights, data, teacher reseeded), 200 steps from an f32 warm start, three
+    What can be asserted is distributional.  Twelve seeds (weights, data, teacher reseeded), 200 steps from an f32 warm start, three
     arms: f32, f32 + 1e-3 input noise (the control: what ANY rounding-sized perturbation does), bf16.  Every run must be finite and
     descend; the bf16 arm's median tail-loss ratio to f32 must not exceed 2.5x the control's (the median of 6 log-ratios with
     sigma ~ 1.1 has a standard error of e^0.55); and bf16 must beat-or-match f32 (<= 1.25x) on no fewer seeds than the control
@@ -1125,7 +1138,7 @@ def test_bf16_phase1_fit_matches_f32_over_seeds(env):
     from learningbycheating_amd.bird_view.models import ImagePolicyModelSS, BirdViewPolicyModelSS
     from learningbycheating_amd.training.native import NativeTrainer
     dev, _ = env
-    n, steps, nseeds = 32, 200, 6
+    n, steps, nseeds = 32, 200, 12
     tails = {"fp32": [], "fp32_eps": [], "bf16": []}
     firsts = []
     for seed in range(nseeds):
@@ -1176,6 +1189,9 @@ def test_bf16_phase1_fit_matches_f32_over_seeds(env):
         assert all(t < 0.95 * f for t, f in zip(tails[arm], firsts)), (arm, tails[arm], firsts)       # every run descends
     assert med(rb) <= 2.5 * max(1.0, med(rc)), (med(rb), med(rc))
     assert sum(r <= 1.25 for r in rb) >= sum(r <= 1.25 for r in rc) - 2, (rb, rc)
+    # round 5 (12 seeds instead of 6): the bf16 arm's WORST seed is no worse than twice the control's worst -- a mode that fits badly on
+    # some inputs shows in its tail, not in its median (round 4: bf16 worst 1.19x, control worst 1.70x over six seeds)
+    assert max(rb) <= 2.0 * max(1.0, max(rc)), ("bf16 worst tail-loss ratio vs the control's worst", max(rb), max(rc))
 
 
 @pytest.mark.parametrize("kind,backbone,h,w,n", [("image", "resnet18", 64, 128, 3), pytest.param("image", "resnet34", 160, 384, 4, marks=gpu)])
