@@ -60,6 +60,10 @@ if [[ "$PHASES" == *tables* ]]; then
     python scripts/trace_gaps.py $(find $R/trace -name "*kernel_trace.csv" | head -1) 2 > $R/trace_gaps_bs$B.txt 2>&1; head -1 $R/trace_gaps_bs$B.txt | cut -c1-260 >> $S
     rm -rf $R/trace
   done
+  # free-running per-kernel durations at the metric's 8-GPU operating point (32 images per GPU)
+  rm -rf $R/prof_b32
+  (cd /tmp && timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OLDPWD/$R/prof_b32" -o lbc -- python "$OLDPWD/bench.py" --global-batch 32 --steps 20 --warmup 5 --init-steps 2 --no-cpu-baseline --no-alt) > $R/prof_b32.log 2>&1
+  cp $(find $R/prof_b32 -name "*kernel_stats.csv" | head -1) $R/kernel_stats_b32.csv 2>/dev/null; rm -rf $R/prof_b32
   timeout 200 python scripts/bench_ops.py 256 3 fwd,dgrad,wgrad > $R/per_shape_bs256.txt 2>&1
   timeout 120 python scripts/bench_ops.py 32 3 fwd,dgrad,wgrad > $R/per_shape_bs32.txt 2>&1
 fi
