@@ -580,7 +580,8 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
                         : halo ? (mode == 0 ? "conv_halo_gather" : "conv_halo_transposed")
                                : (mode == 0 ? "conv_igemm_gather" : "conv_igemm_transposed");
     LbcProfScope prof(pname, 2.0 * a.M * nph * a.K * (double)a.C * taps,
-                      (a.act_bf16 ? 2.0 : 4.0) * (in_elems + nph * (double)a.M * a.K * (a.resid ? 2 : 1)) +
+                      // (+ the side tensors of the fused BatchNorm-backward reduce: the pre-BatchNorm activation, and in the tensor-masked form the ReLU output)
+                      (a.act_bf16 ? 2.0 : 4.0) * (in_elems + nph * (double)a.M * a.K * (1 + (a.resid ? 1 : 0) + (a.bnb_y ? 1 : 0) + (a.bnb_mask ? 1 : 0))) +
                           (a.w_bf16 ? 2.0 : 4.0) * taps * nph * a.C * a.K, s);
     if (cfg >= kLbcCfgHdma) {
         LBC_REQUIRE(wmajor && lbc_conv_hdma_pick(a, mode) >= 0, "igemm: launch not eligible for the halo-staged LDS-DMA kernel");
