@@ -10,6 +10,17 @@
 
 namespace {
 
+// Workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own.  Both passes below re-read rows across workgroup boundaries
+// (a 3 x 3 / 2 window shares an input row with the window below it; a pixel range shares pooled rows with the next range): with
+// consecutive ranges on consecutive ids every shared row was fetched by two XCDs (PMC: 629 MB for the 503 MB forward input, 1041 MB for
+// the backward's 693, profiles/r05_final_pmc_summary_bf16.txt).  Logical id = XCD-major: consecutive ranges sit on ONE XCD.
+__device__ __forceinline__ unsigned xcd_major_block()
+{
+    const unsigned nwg = gridDim.x, b = blockIdx.x;
+    const unsigned xcd = b & 7u, q = nwg >> 3, rr = nwg & 7u;
+    return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+}
+
 template <typename T, typename IDX>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
 {
@@ -23,7 +34,12 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_fwd_k(PoolFwdArgs a)
     // IDX = unsigned when every index of the launch fits 32 bits (lbc_bn_relu_maxpool_fwd): four 64-bit divisions per element otherwise
     const IDX total = (IDX)((long long)a.N * OH * OW * cvn);
     const IDX stride = (IDX)gridDim.x * (IDX)blockDim.x;
-    for (IDX i = (IDX)blockIdx.x * (IDX)blockDim.x + (IDX)threadIdx.x; i < total; i += stride) {
+    // (each workgroup owns a contiguous span of ceil(total / grid) elements, spans in XCD-major order: vertical neighbours share an L2)
+    const IDX span = (total + (IDX)gridDim.x - 1) / (IDX)gridDim.x;
+    const IDX i0 = (IDX)xcd_major_block() * span;
+    const IDX i1 = i0 + span < total ? i0 + span : total;
+    (void)stride;
+    for (IDX i = i0 + (IDX)threadIdx.x; i < i1; i += (IDX)blockDim.x) {
         IDX t = i;
         const int cg = (int)(t % (IDX)cvn); t /= (IDX)cvn;
         const int ox = (int)(t % (IDX)OW); t /= (IDX)OW;
@@ -99,7 +115,7 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_reduce_k(PoolBwdArgs a)
         const vec sc = PV::ld(a.scale + c), sh = PV::ld(a.shift + c);
         const vec mean = PV::ld(a.mean + c), inv = PV::ld(a.invstd + c);
         const long long pixels = (long long)a.N * a.H * a.W;
-        const long long p0 = (long long)blockIdx.x * a.pix_per_block;
+        const long long p0 = (long long)xcd_major_block() * a.pix_per_block;
         long long p1 = p0 + a.pix_per_block;
         if (p1 > pixels) p1 = pixels;
         for (long long p = p0 + pl; p < p1; p += rl) {

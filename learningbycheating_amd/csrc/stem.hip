@@ -717,14 +717,26 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_rows_k(StemArgs a, int ntiles
     };
 
     float s1 = 0.f, s2 = 0.f;
-    int tile = blockIdx.x, it = 0;
-    if (tile < ntiles) band_load(tile);
+    // A workgroup walks a CONTIGUOUS range of tiles (along an output row, then down the rows of an image), and consecutive ranges sit on
+    // ONE XCD (workgroup ids go round-robin over the 8 XCDs, each with an L2 of its own): an input row serves 3.5 output rows, and with
+    // the grid-stride walk of rounds 2-4 those were tiles of 3-4 different workgroups on different XCDs -- PMC of round 5's evidence
+    // call: 387 MB fetched for the 99 MB RGB image, 685 MB for the 140 MB bird view (profiles/r05_final_pmc_summary_bf16.txt)
+    int tile, tend, it = 0;
+    {
+        const int nwg = gridDim.x, b = blockIdx.x;
+        const int xcd = b & 7, q = nwg >> 3, rr = nwg & 7;
+        const int logical = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (b >> 3);
+        const int per = (ntiles + nwg - 1) / nwg;
+        tile = logical * per;
+        tend = tile + per < ntiles ? tile + per : ntiles;
+    }
+    if (tile < tend) band_load(tile);
     __syncthreads();                                           // the zero fill above is complete
-    if (tile < ntiles) band_store(0);
+    if (tile < tend) band_store(0);
     __syncthreads();
-    for (; tile < ntiles; tile += gridDim.x, ++it) {
+    for (; tile < tend; ++tile, ++it) {
         const int buf = it & 1;
-        const int next = tile + gridDim.x;
+        const int next = tile + 1 < tend ? tile + 1 : ntiles;
         if (next < ntiles) band_load(next);
         const int xt = tile % tiles_x;
         const int t2 = tile / tiles_x;
