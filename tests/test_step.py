@@ -235,8 +235,9 @@ def test_native_trainer_k_steps_bf16_mode(env):
     """the same composition check on the shipped mixed-precision mode (BASELINE.json config 3): here a stage's weight gradients
     are deferred to one grouped launch at the stage's end and must have landed in the flat gradient buffer before Adam reads it.
     The float64 oracle rounds at the executor's rounding points; bf16 bounds (every stored tensor carries 2^-9 relative noise and
-    sums of ~1e6 such terms meet in a weight gradient): per-tensor gradients within 0.2 of the tensor's largest entry (measured:
-    see the k-step line in profiles/), while everything structural -- the Adam update of the executor's own gradient, counters,
+    sums of ~1e6 such terms meet in a weight gradient): per-tensor gradients within 0.1 of the tensor's largest entry (measured 3.5e-2
+    with the oracle's backward started from the executor's loss gradient -- round 5, see _k_steps; 0.2 and a measured 0.06-0.3 before,
+    the spread being the loss's 1 / y pole), while everything structural -- the Adam update of the executor's own gradient, counters,
     running statistics, conv.fc -- is held exactly as on the f32 path."""
     dev, _ = env
-    _k_steps(dev, 1, False, 3, 8, 0.2, 0.2, precision="bf16", fwd_tol=3e-2, stat_rtol=5e-3)
+    _k_steps(dev, 1, False, 3, 8, 0.1, 0.1, precision="bf16", fwd_tol=3e-2, stat_rtol=5e-3)
