@@ -160,17 +160,17 @@ int lbc_igemm_pick(long long M, int K);            // tile configuration 0..2 of
 int lbc_igemm_pick_for(const IgemmArgs& a, int mode);
 constexpr int kLbcCfgGlds = 3;
 constexpr int kLbcGldsCfgs = 7;
-constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip: {0: 256x256, 1: 256x128, 2: 128x256, 3: 256x64 persistent (C = K = 64)}
+constexpr int kLbcCfgHdma = kLbcCfgGlds + kLbcGldsCfgs;     // conv_hdma.hip (policy): {0: retired, 1: 256x128, 2: 128x256, 3: the 64-channel kernel conv_c64p.hip (C = K = 64)}
 constexpr int kLbcHdmaCfgs = 5;                             // ... 4: 128 x 64, four waves, two workgroups per CU (launches with few rows)
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode);
 int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s);     // conv_c64p.hip: cfg kLbcCfgHdma + 3 (C = K = 64)
 int lbc_conv_c64p_rows(const IgemmArgs& a);                                  // statistics rows it writes: one per persistent workgroup
-bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg);       // conv_hdmap.hip: persistent form of cfg 1 / 2
+bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg);       // conv_hdmap.hip: the persistent kernel takes cfg 1 / 2 / 4
 int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg);          // split-K ranges of that launch (1 = none)
-int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64} or -1
+int lbc_conv_glds_pick(const IgemmArgs& a, int mode);      // kLbcCfgGlds + {0: 256x256, 1: 256x128, 2: 128x256, 3: 512x128, 4: 512x64, 5: 256x64 and 6: 128x128 on four waves} or -1
 int lbc_conv_glds_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_glds_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 // 256 zero bytes in device memory (per device, allocated on first use): source of the zero padding of LDS-DMA staging
