@@ -41,6 +41,17 @@ constexpr long long kHdmaSmallMinTiles = 48;      // fill threshold of the four-
 int lbc_conv_hdma_pick(const IgemmArgs& a, int mode)
 {
     if (lbc_opt_on(kOptNoHdma) || lbc_opt_on(kOptNoGemm256)) return -1;
+    if (a.nphase == 4) {
+        // Stride-2 transposed launches (round 5): the four-wave persistent kernel with the 2 x 2-neighbourhood halo and one accumulator set
+        // per output-parity phase (conv_hdmap_k<.., MODE 2>), from the same fill threshold as its stride-1 use; a pinned shape of the
+        // per-tap kernel (LBC_GEMM256_CFG: its tests) keeps the launch there
+        if (!lbc_conv_hdmap_phased(a, mode) || lbc_opt(kOptGemm256Cfg) >= 0) return -1;
+        const long long forcedp = lbc_opt(kOptHdmaCfg);
+        if (forcedp >= 0 && forcedp != 4) return -1;
+        const long long tiles = (long long)lbc_cdiv(a.M, 128) * (a.K / 64);
+        const long long small_fill = lbc_opt(kOptGemm256MinTiles) > 0 ? lbc_opt(kOptGemm256MinTiles) : kHdmaSmallMinTiles;
+        return tiles >= small_fill ? kLbcCfgHdma + 4 : -1;
+    }
     if (!(a.w_bf16 && a.act_bf16) || a.ostep != 1 || a.nphase > 1 || a.oy0 || a.ox0) return -1;
     // BatchNorm-on-load: only the 64-channel layer's kernel has it (conv_c64p_k<0, 0, true>: an in-place transform of the landed halo,
     // once per tile).  Inside conv_hdmap_k it was built twice (round 2 non-persistent, round 4 persistent) and measured slower than the
@@ -103,7 +114,7 @@ int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
 {
     LBC_REQUIRE(cfg > kLbcCfgHdma && cfg < kLbcCfgHdma + kLbcHdmaCfgs, "conv_hdma: bad cfg %d", cfg);
     const HdmaCfg c = kHdmaCfg[cfg - kLbcCfgHdma];
-    LBC_REQUIRE(a.K % c.bn == 0 && a.C % 64 == 0 && c.bm + 2 * a.W + 2 < c.hrmax, "conv_hdma: shape not tileable");
+    LBC_REQUIRE(a.K % c.bn == 0 && a.C % 64 == 0 && c.bm + (a.nphase == 4 ? 1 : 2) * a.W + 2 < c.hrmax, "conv_hdma: shape not tileable");
     if (cfg == kLbcCfgHdma + 3) return lbc_conv_c64p_launch(a, mode, s);
     return lbc_conv_hdmap_launch(a, mode, cfg, s);
 }

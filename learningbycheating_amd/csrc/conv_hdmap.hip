@@ -102,7 +102,7 @@ __global__ __launch_bounds__(256) void conv_split_epilogue_k(IgemmArgs a, const 
 int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
 {
     (void)mode;
-    if (cfg != kLbcCfgHdma + 4 || !a.split_ws || a.pre_scale) return 1;
+    if (cfg != kLbcCfgHdma + 4 || !a.split_ws || a.pre_scale || a.nphase == 4) return 1;
     const long long opt = lbc_opt(kOptHdmapSplit);
     if (opt == 0) return 1;
     const int nslab = a.C / 64;
@@ -114,8 +114,19 @@ int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg)
 }
 
 // Which launches the persistent kernel takes (cfg 1: 256 x 128, 2: 128 x 256, 4: 128 x 64 on four waves)
+// the stride-2 transposed launches whose four output-parity phases conv_hdmap_k<.., MODE 2> computes in one tile (same predicate as
+// conv_glds.hip's phased form: input gradient of a stride-2 3x3 convolution, ConvTranspose2d forward; plain epilogue)
+bool lbc_conv_hdmap_phased(const IgemmArgs& a, int mode)
+{
+    return mode == 1 && a.nphase == 4 && a.S == 2 && a.ostep == 2 && a.KH == 3 && a.KW == 3 && a.P == 1 && a.H == a.LH && a.W == a.LW &&
+           a.OH == 2 * a.LH && a.OW == 2 * a.LW && a.M == a.N * a.LH * a.LW && !a.resid && !a.bnb_y && !a.pre_scale && a.w_bf16 && a.act_bf16 &&
+           a.C % 64 == 0 && a.K % 64 == 0 && 128 + a.W + 2 <= 192 - 8 && (long long)a.N * a.OH * a.OW * a.K < (1ll << 31) &&
+           (long long)a.N * a.H * a.W * a.C < (1ll << 31) && (long long)a.K * 9 * a.C < (1ll << 31) && !lbc_opt_on(kOptNoGldsPhased);
+}
+
 bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg)
 {
+    if (a.nphase == 4) return cfg == kLbcCfgHdma + 4 && lbc_conv_hdmap_phased(a, mode);
     if (mode != 0 && mode != 1) return false;
     if (a.pre_scale) return false;                       // no BatchNorm-on-load form (conv_hdma.hip)
     if (a.bnb_y && (mode != 1 || (a.resid != nullptr) != (a.bnb_mask != nullptr))) return false;      // (form 2: no residual; form 4: residual + mask tensor)
@@ -137,6 +148,10 @@ int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const int ntiles = lbc_cdiv(a.M, bm) * (a.K / bn);
     // one workgroup per CU (LDS; two for the four-wave shape); tiles per workgroup so that a grid of <= `cap` workgroups covers the launch
     const int cap = lbc_opt(kOptHdmaPersistWgs) > 0 ? (int)lbc_opt(kOptHdmaPersistWgs) : (cfg == kLbcCfgHdma + 4 ? 512 : 256);
+    if (a.nphase == 4) {       // phased transposed form (MODE 2): persistent, several tiles per workgroup, no K split
+        const int tpwp = lbc_cdiv(ntiles, cap);
+        return lbc_conv_hdmap_launch_128x64_192(a, 2, zero, ntiles, tpwp, (unsigned)lbc_cdiv(ntiles, tpwp), s, 1, 1);
+    }
     const int nsplit = lbc_conv_hdmap_nsplit(a, mode, cfg);
     if (nsplit > 1) {
         rc = lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, 1, (unsigned)(ntiles * nsplit), s, nsplit, 1);

@@ -43,6 +43,14 @@ __device__ __forceinline__ const char* uniform_ptr(const char* p)
 // the gradient wrt the previous block's output relu(bn2(y2) + identity); masking it with that output (IgemmArgs::bnb_mask > 0) and summing
 // (g, g * xhat(y2)) here removes the previous block's whole channel_reduce pass (three tensors read, one written).  The residual is added
 // to the f32 accumulator as in form 1 (same rounding as the unfused path), mask and sums happen in the chunk phase as in form 2.
+// MODE 2 (round 5; four-wave shape, plain epilogue): the stride-2 TRANSPOSED launches -- input gradient of the stride-2 3x3 convolutions
+// (resnet.py:132-138), ConvTranspose2d(.,.,3,2,1,1) forward (image.py:37-47) -- with all four output-parity phases of a lattice position
+// in ONE tile.  Output pixel (2 ly + oy0, 2 lx + ox0) gathers x at (ly + dy, lx + dx) through the taps (r, s) with dy = [r == 0],
+// dx = [s == 0] and oy0 = [r != 1], ox0 = [s != 1]: a 2 x 2 neighbourhood, nine taps, each feeding exactly one of four accumulator sets
+// (1 / 2 / 2 / 4 taps per phase).  So the halo is BM + W + 2 rows, staged once per 64-channel slab like the stride-1 forms, a tap is a
+// row offset in {0, 1, W, W + 1}, and the K loop is the stride-1 loop with the accumulator set chosen by the (compile-time) tap.  The
+// per-tap LDS-DMA kernel (conv_glds2_k<.., PH>) these launches used stages one shifted activation tile per (tap, slab) for K loops of
+// 2 - 8 K-tiles per (phase, tile) workgroup: 320 - 600 TF/s and 226 MB fetched for a 63 MB operand (profiles/r05_final_*).
 // KG = 2 (round 5; four-wave shape, launches of at most one tile per CU): an IN-WORKGROUP split of the channel contraction.  A launch with
 // <= 256 tiles of 128 x 64 puts one four-wave workgroup on a CU -- one wave per SIMD, nothing hides that wave's LDS / DMA-issue / barrier
 // latencies, and the serial K loop (36 - 72 K-tiles) IS the launch (layers 3 / 4 at 32 images per GPU: 15 / 22 us for 5.4 GFLOP).  With
@@ -61,6 +69,8 @@ template <int BM, int BN, int WM, int WN, int HRMAX, int SROWS, int MODE, int EP
 __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4) ? 1 : 2) void conv_hdmap_k(IgemmArgs a, const void* zero_page, const int ntiles, const int tpw, const int nsplit)
 {
     static_assert(KG == 1 || (KG == 2 && WM * WN == 4 && EPI != 3), "conv_hdmap: the in-workgroup K split doubles the four-wave shape");
+    static_assert(MODE != 2 || (WM * WN == 4 && EPI == 0 && KG == 1), "conv_hdmap: the phased transposed form is a plain-epilogue form of the four-wave shape");
+    constexpr int NPH = MODE == 2 ? 4 : 1;                      // accumulator sets (output-parity phases)
     constexpr int WTM = BM / WM, WTN = BN / WN;                 // per-wave output tile
     constexpr int MT = WTM / 32, NT = WTN / 32;
     constexpr int NW = WM * WN;                                 // waves per workgroup: 8 (256 x 128 / 128 x 256 tiles, one workgroup per CU) or
@@ -132,7 +142,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
     //      m0 - (W + 1) + hr.  Rows outside the tensor read a clamped pixel (they are only ever met by taps that the border select
     //      sends to the zero row); pieces that lie entirely past the halo (8 p >= BM + 2W + 2: the launcher guarantees that the
     //      last piece, which holds the ZERO ROW, is one of them) come from the zero page
-    const int HR = BM + 2 * W + 2;
+    const int HR = MODE == 2 ? BM + W + 2 : BM + 2 * W + 2;     // (MODE 2: halo row hr holds input pixel m0 + hr -- no taps above / left of the position)
+    const int hshift = MODE == 2 ? 0 : W + 1;
     const int arow0 = wave * HPW * 8 + prow;                                   // halo row of piece j: arow0 + 8 j
     const unsigned aswz[2] = {(unsigned)((pseg ^ ((arow0 >> 1) & 7)) * 16), (unsigned)((pseg ^ (((arow0 >> 1) + 4) & 7)) * 16)};   // j even / odd
     const unsigned zoff = (unsigned)((lane & 7) * 16);
@@ -140,7 +151,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
     const char* zbytes = static_cast<const char*>(zero_page);
     auto issue_a = [&](const int m0x, const int slab, const int buf, const int j) {
         const bool pad = (wave * HPW + j) * 8 >= HR;                           // wave-uniform
-        int q = m0x - (W + 1) + arow0 + 8 * j;
+        int q = m0x - hshift + arow0 + 8 * j;
         q = q < 0 ? 0 : (q >= a.M ? a.M - 1 : q);
         const unsigned off = (unsigned)q * (unsigned)(2 * C) + aswz[j & 1];
         const char* sbase = uniform_ptr(pad ? zbytes : xbytes + (size_t)(slab * 128));
@@ -167,7 +178,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
     const int baddr = (BRING + (wn * WTN + l31) * 128) | ((kh ^ ((l31 >> 1) & 7)) << 4);
     int rowc[MT];
 #pragma unroll
-    for (int i = 0; i < MT; ++i) rowc[i] = W + 1 + wm * WTM + i * 32 + l31;
+    for (int i = 0; i < MT; ++i) rowc[i] = hshift + wm * WTM + i * 32 + l31;
     auto tap_mask = [&](const int m0x, int (&mask)[MT]) {
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -179,8 +190,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
 #pragma unroll
                 for (int t = 0; t < 9; ++t) {
                     const int r = t / 3, s = t - 3 * r;
-                    const int dy = MODE == 0 ? r - 1 : 1 - r;
-                    const int dx = MODE == 0 ? s - 1 : 1 - s;
+                    const int dy = MODE == 0 ? r - 1 : (MODE == 2 ? (r == 0 ? 1 : 0) : 1 - r);
+                    const int dx = MODE == 0 ? s - 1 : (MODE == 2 ? (s == 0 ? 1 : 0) : 1 - s);
                     if ((unsigned)(y + dy) < (unsigned)H && (unsigned)(x + dx) < (unsigned)W) bits |= 1 << t;
                 }
             }
@@ -189,14 +200,16 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
     };
     int amask[MT], amaskn[MT];
 
-    f32x16 acc[MT][NT];
+    f32x16 acc[NPH][MT][NT];
     auto zero_acc = [&]() {
 #pragma unroll
-        for (int i = 0; i < MT; ++i)
+        for (int p = 0; p < NPH; ++p)
 #pragma unroll
-            for (int j = 0; j < NT; ++j)
+            for (int i = 0; i < MT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+                for (int j = 0; j < NT; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][i][j][r] = 0.f;
     };
     zero_acc();
 
@@ -204,7 +217,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
     int aaddr[MT];
     auto tap_addr = [&](const int tap, const int buf, const int (&mask)[MT]) {
         const int r = tap / 3, s = tap - 3 * r;
-        const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (1 - r) * W + (1 - s);
+        const int off = MODE == 0 ? (r - 1) * W + (s - 1) : (MODE == 2 ? (r == 0 ? W : 0) + (s == 0 ? 1 : 0) : (1 - r) * W + (1 - s));
         const int abuf = buf * ABYTES;
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
@@ -248,11 +261,12 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
         if constexpr (NT == 2) { LBC_RD1(fb[SET][0], baddr ^ (32 * (G)), (SLOT) * TILE_B); LBC_RD1(fb[SET][NT - 1], baddr ^ (32 * (G)), (SLOT) * TILE_B + 4096); } \
         else LBC_RD1(fb[SET][0], baddr ^ (32 * (G)), (SLOT) * TILE_B);                                                           \
     } while (0)
-#define LBC_MM(SET)                                                                                                              \
+    // (PHX: the accumulator set of the K-tile's tap -- a constant once the tap loop is unrolled; 0 outside MODE 2)
+#define LBC_MM(SET, PHX)                                                                                                         \
     do {                                                                                                                         \
         _Pragma("unroll") for (int i = 0; i < MT; ++i)                                                                           \
             _Pragma("unroll") for (int j = 0; j < NT; ++j)                                                                       \
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[i][j], 0, 0, 0);                 \
+                acc[PHX][i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[SET][i], fb[SET][j], acc[PHX][i][j], 0, 0, 0);       \
     } while (0)
 
     // s_waitcnt vmcnt(n) for the handful of counts the stream produces (the immediate must be a constant)
@@ -265,7 +279,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
             default: LBC_WAIT_VM(0); break;      // (0, and anything unforeseen: wait for everything)
         }
     };
-    static_assert(NBW + 2 * PPT + NST <= 24, "conv_hdmap: counted waits");
+    static_assert(NBW + 2 * PPT + NPH * NST <= 24, "conv_hdmap: counted waits");
 
     // ---- the tile stream
     int tile = first;
@@ -300,6 +314,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
 #pragma unroll
             for (int t = 0; t < 9; ++t) {
                 const int slot = t % 3, nslot = (t + 1) % 3, islot = (t + 2) % 3;
+                const int tph = MODE == 2 ? (t / 3 == 1 ? 0 : 2) + (t % 3 == 1 ? 0 : 1) : 0;      // phase 2 oy0 + ox0 this tap feeds
                 const bool has_next = t < 8 || follows;
                 const bool w2 = t + 2 < 9 || follows;                          // K-tile k + 2 exists
                 const int np_here = (t * PPT < HPW ? (HPW - t * PPT < PPT ? HPW - t * PPT : PPT) : 0);            // halo pieces of the next slab requested here
@@ -337,7 +352,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                     else issue_h();
                     LBC_WAIT_OLDER_READS();                              // set g & 1 is in (its reads were issued a full step ago)
                     LBC_USE(g & 1);
-                    LBC_MM(g & 1);
+                    LBC_MM(g & 1, tph);
                     // the step's fragment reads first: a full step of MFMAs (128 cycles of this wave's own, 256 with its SIMD
                     // partner) between a read and the wait that needs it -- a wave that runs alone no longer stalls on LDS latency
                     LBC_SG(0x100, MT + NT);
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                     int n = 0;
                     if (w2) {
                         n = NBW + (follows ? np_prev + np_here : 0);
-                        if (c == 0 && t == 0 && stores_pending) n += NST;
+                        if (c == 0 && t == 0 && stores_pending) n += NPH * NST;
                     }
                     wait_vm(n);
                 }
@@ -361,7 +376,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                 __builtin_amdgcn_sched_barrier(0);
                 if (has_next) LBC_RD(nslot, 0, 0);
                 LBC_USE((KS - 1) & 1);                                   // in since the lgkmcnt(0) in front of the barrier
-                LBC_MM((KS - 1) & 1);
+                LBC_MM((KS - 1) & 1, tph);
                 LBC_SG(0x100, MT + NT);
 #pragma unroll
                 for (int q = 0; q < MT * NT; ++q) { LBC_SG(0x008, 1); LBC_SG(0x036, 6); }
@@ -385,7 +400,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) xch[((i * NT + j) * 16 + r) * 64] = acc[i][j][r];
+                        for (int r = 0; r < 16; ++r) xch[((i * NT + j) * 16 + r) * 64] = acc[0][i][j][r];
             }
             LBC_WAIT_LGKM0();
             __builtin_amdgcn_s_barrier();
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
 #pragma unroll
                     for (int j = 0; j < NT; ++j)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[i][j][r] += xch[((i * NT + j) * 16 + r) * 64];
+                        for (int r = 0; r < 16; ++r) acc[0][i][j][r] += xch[((i * NT + j) * 16 + r) * 64];
             }
         }
         const bool epi_on = KG == 1 || grp == 0;   // (instance 1 only keeps the epilogue's workgroup barrier company)
@@ -412,7 +427,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                     const int m = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
                     if (m < a.M) {
 #pragma unroll
-                        for (int nj = 0; nj < NT; ++nj) part[(unsigned)m * (unsigned)a.K + (unsigned)(colw + nj * 32 + l31)] = acc[mi][nj][r];
+                        for (int nj = 0; nj < NT; ++nj) part[(unsigned)m * (unsigned)a.K + (unsigned)(colw + nj * 32 + l31)] = acc[0][mi][nj][r];
                     }
                 }
         } else {
@@ -433,6 +448,23 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                 psh[nj] = a.post_scale ? a.post_shift[col] : 0.f;
                 bia[nj] = a.bias ? a.bias[col] : 0.f;
             }
+            // MODE 2: lattice position m = (n, ly, lx) -> element index of output pixel (n, 2 ly, 2 lx) of its copy-out chunks; phase
+            // (oy0, ox0) adds oy0 * OW + ox0 pixels
+            unsigned obase[MODE == 2 ? NSTEP : 1][CPL];
+            if constexpr (MODE == 2) {
+#pragma unroll
+                for (int s = 0; s < NSTEP; ++s)
+#pragma unroll
+                    for (int q = 0; q < CPL; ++q) {
+                        const int m = m0 + wm * WTM + s * SROWS + crow + RPP * q;
+                        const int mm = m < a.M ? m : 0;
+                        const int x = mm % W, t = mm / W;
+                        const int y = t % H, n = t / H;
+                        obase[s][q] = (unsigned)((n * 2 * H + 2 * y) * (2 * W) + 2 * x);
+                    }
+            }
+#pragma unroll
+            for (int ph = 0; ph < NPH; ++ph) {
             f32x8 t1 = ParamVec<8>::splat(0.f), t2 = t1;
             float s1[NT], s2[NT];
 #pragma unroll
@@ -491,7 +523,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                     const bool live = m0 + wm * WTM + mi * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh < a.M;
 #pragma unroll
                     for (int nj = 0; nj < NT; ++nj) {
-                        float v = acc[mi][nj][r];
+                        float v = acc[ph][mi][nj][r];
                         if (a.post_scale) v = v * psc[nj] + psh[nj];
                         if (a.bias) v += bia[nj];
                         if constexpr (RES) v += rv[mi][r][nj];
@@ -522,7 +554,8 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                         ch = __builtin_convertvector(g, bf16x8);
                         if (m < a.M) { t1 += g; t2 += g * (yf - bmu) * biv; }
                     }
-                    if (m < a.M) *reinterpret_cast<bf16x8*>(yout + ((unsigned)m * (unsigned)a.K + (unsigned)(colw + cseg * 8))) = ch;
+                    const unsigned opix = MODE == 2 ? obase[MODE == 2 ? s : 0][q] + (unsigned)((ph >> 1) * 2 * W + (ph & 1)) : (unsigned)m;
+                    if (m < a.M) *reinterpret_cast<bf16x8*>(yout + (opix * (unsigned)a.K + (unsigned)(colw + cseg * 8))) = ch;
                 }
                 __builtin_amdgcn_wave_barrier();
             }
@@ -563,12 +596,16 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
                     float u1 = 0.f, u2 = 0.f;
 #pragma unroll
                     for (int w2 = 0; w2 < WM; ++w2) { u1 += red[(w2 * 2 + 0) * BN + tid]; u2 += red[(w2 * 2 + 1) * BN + tid]; }
-                    float* dst = a.stats + (size_t)(a.stat_row0 + mtile) * 2 * (size_t)a.K;
+                    // (MODE 2: statistics rows phase-major, as the per-tap kernel writes them: row ph * M-tiles + M-tile)
+                    float* dst = a.stats + (size_t)(a.stat_row0 + ph * (ntiles / ntn) + mtile) * 2 * (size_t)a.K;
                     dst[n0 + tid] = u1;
                     dst[a.K + n0 + tid] = u2;
                 }
-                // (the next write of `red` lies behind at least the nine K-tile barriers of the next tile)
+                // (the next write of `red` lies behind at least the nine K-tile barriers of the next tile -- or, between the phases of
+                //  a MODE 2 tile, behind this barrier)
+                if constexpr (NPH > 1) { LBC_WAIT_LGKM0(); __builtin_amdgcn_s_barrier(); }
             }
+            }       // ph
         }
         zero_acc();
         stores_pending = true;
@@ -601,6 +638,16 @@ int conv_hdmap_launch_shape(const IgemmArgs& a, int mode, const void* zero, int 
     }
     const int epi = a.bnb_y ? (a.bnb_mask ? 4 : 2) : (a.resid ? 1 : 0);
     LBC_REQUIRE(!a.pre_scale, "conv_hdmap: no BatchNorm-on-load form (measured slower on the MI355X, profiles/r05_call1_hdmap_pre_land_or_kill.txt)");
+    if (mode == 2) {
+        // the phased stride-2 transposed form: four-wave shape, plain epilogue
+        if constexpr (BM == 128 && BN == 64) {
+            LBC_REQUIRE(!a.resid && !a.bnb_y && a.nphase == 4 && kgroups == 1, "conv_hdmap: the phased transposed form has the plain epilogue only");
+            hipLaunchKernelGGL((conv_hdmap_k<BM, BN, WM, WN, HRMAX, SROWS, 2, 0>), grid, dim3(WM * WN * 64), 0, s, a, zero, ntiles, tpw, 1);
+            return lbc_check_launch("conv_hdmap(phased)");
+        } else {
+            LBC_REQUIRE(false, "conv_hdmap: the phased transposed form exists for the 128 x 64 shape only");
+        }
+    }
     if (kgroups == 2) {
         // in-workgroup K split (KG = 2): eight waves, one tile per workgroup
         if constexpr (BM == 128 && BN == 64) {

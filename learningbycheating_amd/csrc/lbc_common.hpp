@@ -167,6 +167,7 @@ int lbc_conv_hdma_rows(const IgemmArgs& a, int cfg);
 int lbc_conv_hdma_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_c64p_launch(const IgemmArgs& a, int mode, hipStream_t s);     // conv_c64p.hip: cfg kLbcCfgHdma + 3 (C = K = 64)
 int lbc_conv_c64p_rows(const IgemmArgs& a);                                  // statistics rows it writes: one per persistent workgroup
+bool lbc_conv_hdmap_phased(const IgemmArgs& a, int mode);                  // conv_hdmap.hip: a stride-2 transposed launch the persistent kernel's MODE 2 takes (all four parity phases per tile)
 bool lbc_conv_hdmap_eligible(const IgemmArgs& a, int mode, int cfg);       // conv_hdmap.hip: the persistent kernel takes cfg 1 / 2 / 4
 int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s);
 int lbc_conv_hdmap_nsplit(const IgemmArgs& a, int mode, int cfg);          // split-K ranges of that launch (1 = none)

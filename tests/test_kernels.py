@@ -477,6 +477,67 @@ def test_conv_glds_stride2_transposed_phases(env, case, lbc_config):
     assert relerr(dx, dx2) < 2.0 ** -7
 
 
+PHASED_SMALL = [(2, 10, 18, 64, 128), (1, 12, 14, 128, 256), (3, 8, 10, 64, 256), (2, 6, 34, 128, 128), (1, 4, 6, 192, 128), (2, 8, 104, 64, 64), (5, 14, 22, 64, 64)]
+PHASED_REAL = [pytest.param(c, marks=gpu) for c in [(32, 40, 96, 64, 128), (64, 20, 48, 128, 256), (256, 10, 24, 256, 512), (256, 40, 96, 64, 128), (32, 20, 48, 128, 256)]]
+
+
+@pytest.mark.parametrize("case", PHASED_SMALL + PHASED_REAL)
+def test_conv_hdmap_phased_transposed(env, case, lbc_config):
+    """Round 5: the stride-2 transposed launches on the persistent halo-staged kernel (conv_hdmap_k<.., MODE 2>): a 2 x 2-neighbourhood halo
+    per 64-channel slab, nine taps feeding four accumulator sets (one per output-parity phase), all four phases of a lattice position
+    written by one tile.  (a) input gradient of a stride-2 3x3 convolution against autograd on the bf16-rounded operands and against the
+    generic kernel; one / two workgroups for the whole launch (several tiles per workgroup) bit-identical; (b) ConvTranspose2d forward
+    with bias + ReLU + statistics (the decoder's form after its bn_apply pass) against torch."""
+    dev, _ = env
+    from learningbycheating_amd import _lib
+    N, H, W, C, K = case            # conv C -> K over H x W (even), stride 2: dy is [N, K, H/2, W/2], dx has C channels
+    lib = _lib.get()
+    small = N * H * W < 100000
+    if small:
+        lbc_config("LBC_GEMM256_MIN_TILES", 1)
+        lbc_config("LBC_HDMA_CFG", 4)
+    x, w = make((N, H, W, C, K, 3, 2, 1), 590 + C + K)
+    xg = rbf(x).requires_grad_(True)
+    yy = F.conv2d(xg, rbf(w), None, 2, 1)
+    g = torch.Generator().manual_seed(591)
+    dy = rbf(torch.randn(yy.shape, generator=g))
+    yy.backward(dy)
+    rows = ctypes.c_int(0)
+    dx = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
+    assert relerr(dx, xg.grad) < 1e-4 + OUT_TOL[2]
+    for wgs in (1, 2):
+        lbc_config("LBC_HDMA_PERSIST_WGS", wgs)
+        assert torch.equal(Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True), dx), wgs
+    lbc_config("LBC_HDMA_PERSIST_WGS", -1)
+    lbc_config("LBC_NO_GLDS_PHASED", 1)
+    dx2 = Conv(dev).dgrad(dy, w, H, W, 2, 1, bf16=3, transposed=True)
+    assert relerr(dx, dx2) < 2.0 ** -7
+    lbc_config("LBC_NO_GLDS_PHASED", -1)
+    # (b) ConvTranspose2d(K -> C) forward over the low-resolution map [N, K, H/2, W/2] -> [N, C, H, W]: bias + ReLU + statistics
+    LH, LW = H // 2, W // 2
+    xt = rbf(torch.randn((N, K, LH, LW), generator=g))
+    wt = torch.randn((K, C, 3, 3), generator=g) * (2.0 / (K * 2.25)) ** 0.5
+    b = torch.randn(C, generator=g)
+    ref = F.relu(F.conv_transpose2d(xt, rbf(wt), b, 2, 1, 1))
+    dd = _lib.ConvDesc(N, LH, LW, K, C, 3, 3, 2, 1, 1, 3, 1)
+    xh = xt.permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+    wh = wt.permute(0, 2, 3, 1).contiguous().to(dev)                       # [K][kh][kw][C] = [Cin_T][T][Cout_T]
+    wfwd = Conv(dev).transpose(wh.view(K, 9, C), K, 9, C).to(torch.bfloat16)
+    bd = b.to(dev)
+    _lib.check(lib.lbc_deconv3x3s2_fwd(ctypes.byref(dd), None, None, None, None, None, 0, None, None, ctypes.byref(rows), None))
+    assert rows.value == 4 * -(-(N * LH * LW) // 128), (rows.value, N * LH * LW)       # (the four-wave persistent shape: 128 lattice rows per tile, four phases)
+    st = torch.zeros((rows.value, 2, C), device=dev)
+    from tests.helpers import guarded, check_guard
+    buf, y = guarded((N, H, W, C), dev, dtype=torch.bfloat16)
+    _lib.check(lib.lbc_deconv3x3s2_fwd(ctypes.byref(dd), _lib.ptr(xh), _lib.ptr(wfwd), _lib.ptr(bd), None, None, 0, _lib.ptr(y), _lib.ptr(st),
+                                       ctypes.byref(rows), _lib.stream_for(xh)))
+    check_guard(buf, y.numel())
+    got = y.permute(0, 3, 1, 2).float().cpu()
+    assert relerr(got, ref) < 1e-4 + OUT_TOL[2]
+    assert torch.allclose(st.cpu()[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=2e-2)
+    assert torch.allclose(st.cpu()[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), rtol=1e-3, atol=2e-2)
+
+
 def test_conv_launch_policy_at_the_per_gpu_batches(env, lbc_config):
     """which tile shape a 3x3 / stride-1 launch of the ResNet-34 layers (resnet.py:164) gets at the per-GPU batches of the 1 / 2 / 4 / 8
     GPU runs -- host logic only, read off the statistics-row count of a query call (rows = M / tile rows).  Eight-wave 256 x 128 tiles
