@@ -89,7 +89,7 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
     constexpr int RED = STG + NW * SROWS * SROW_B;              // [WM][2][BN] floats
     constexpr int SMEM = RED + WM * 2 * BN * 4;
     static_assert(SMEM == hdmap_lds_bytes<BM, BN, WM, WN, HRMAX, SROWS>(), "conv_hdmap: LDS layout");
-    constexpr int ZROW = (HRMAX - 1) * 128;                     // last row of either halo buffer: beyond the halo, filled from the zero page
+    constexpr int ZROW2 = (HRMAX - 2) * 128;                    // last two rows of either halo buffer: beyond the halo, filled from the zero page
     static_assert(SMEM * KG <= 160 * 1024, "conv_hdmap: LDS");
     __shared__ __attribute__((aligned(16))) char smem_all[SMEM * KG];    // the ONLY LDS object (KG = 2: one SMEM-sized region per instance)
     constexpr int HPW = HRMAX / (8 * NW);                       // 1-KiB halo pieces (8 rows) per wave per slab
@@ -222,7 +222,11 @@ __global__ __launch_bounds__(WM * WN * 64 * KG, (BM / WM == 128 && WM * WN == 4)
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int hr = rowc[i] + off;
-            const int val = (hr << 7) | ((kh ^ ((hr >> 1) & 7)) << 4), zval = ZROW | (kh << 4);
+            // (the zero address keeps the lane's position inside the 256-byte bank period -- rows HRMAX - 2 / HRMAX - 1, both from the zero
+            //  page: a border lane then sits on the banks its own row would have used and the read stays conflict-free.  One shared zero
+            //  slot put every border lane on 4 banks that one of the 15 other lanes of its ds_read_b128 group also needs: +25 % LDS cycles on
+            //  the A reads at W = 24, +44 % at W = 12 -- scripts/probe/lds_conflict_model.py, profiles/r05_final_pmc_lds_conflicts.txt)
+            const int val = (hr << 7) | ((kh ^ ((hr >> 1) & 7)) << 4), zval = ZROW2 | (val & 255);
             const int m = -((mask[i] >> tap) & 1);               // all ones when the tap is inside the image (written as a bit
             aaddr[i] = abuf + (((val ^ zval) & m) ^ zval);       // select: as `ok ? val : zval` the compiler branches over exec)
         }
