@@ -7,9 +7,6 @@
 int lbc_conv_hdmap_launch_256x128_320(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_256x128_384(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_128x256_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
-// the wave-specialised form of the 256 x 128 shape (conv_hdmaw.hpp: four multiplying + four loading waves)
-int lbc_conv_hdmaw_launch_256x128_320(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
-int lbc_conv_hdmaw_launch_256x128_384(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s);
 int lbc_conv_hdmap_launch_128x64_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s, int nsplit, int kgroups);
 
 namespace {
@@ -172,11 +169,8 @@ int lbc_conv_hdmap_launch(const IgemmArgs& a, int mode, int cfg, hipStream_t s)
     const int tpw = lbc_cdiv(ntiles, cap);
     const unsigned grid = (unsigned)lbc_cdiv(ntiles, tpw);
     if (cfg == kLbcCfgHdma + 1) {
-        // the wave-specialised kernel (round 6) unless LBC_HDMAW=0 (A/B, tests: the eight-wave all-purpose kernel)
-        const bool ws = lbc_opt(kOptHdmaw) != 0;
-        if (256 + 2 * a.W + 2 <= 320 - 8)       // W <= 27: layers 3 / 4
-            return ws ? lbc_conv_hdmaw_launch_256x128_320(a, mode, zero, ntiles, tpw, grid, s) : lbc_conv_hdmap_launch_256x128_320(a, mode, zero, ntiles, tpw, grid, s);
-        return ws ? lbc_conv_hdmaw_launch_256x128_384(a, mode, zero, ntiles, tpw, grid, s) : lbc_conv_hdmap_launch_256x128_384(a, mode, zero, ntiles, tpw, grid, s);
+        if (256 + 2 * a.W + 2 <= 320 - 8) return lbc_conv_hdmap_launch_256x128_320(a, mode, zero, ntiles, tpw, grid, s);   // W <= 27: layers 3 / 4
+        return lbc_conv_hdmap_launch_256x128_384(a, mode, zero, ntiles, tpw, grid, s);
     }
     if (cfg == kLbcCfgHdma + 4) return lbc_conv_hdmap_launch_128x64_192(a, mode, zero, ntiles, tpw, grid, s, 1, 1);
     return lbc_conv_hdmap_launch_128x256_192(a, mode, zero, ntiles, tpw, grid, s);

@@ -1,5 +1,4 @@
-// Wave-private epilogue of the persistent halo-staged convolutions (conv_hdmap.hpp: every wave multiplies and stores; conv_hdmaw.hpp: four
-// multiplying waves next to four DMA waves).  Reference arithmetic: what follows a BasicBlock convolution -- folded BatchNorm affine /
+// Wave-private epilogue of the persistent halo-staged convolution (conv_hdmap.hpp).  Reference arithmetic: what follows a BasicBlock convolution -- folded BatchNorm affine /
 // bias / residual / ReLU (bird_view/models/resnet.py:38-54) and, for input-gradient launches, the BatchNorm-backward sums of autograd.
 //   affine / bias / residual / ReLU on the accumulators, SROWS rows at a time through this wave's own staging rows (SROWS x (WTN bf16 +
 //   16 bytes) of LDS that belong to nothing else), read back as 16-byte chunks, stored -- no workgroup barrier; statistics rows (or the
@@ -14,9 +13,7 @@
 
 namespace {
 
-// RVA: the residual one copy-out step ahead (two register sets of SROWS / 2 x NT values) instead of the whole wave tile up front
-// (16 MT NT registers: 128 for a 128 x 64 wave tile, next to its 128 accumulators)
-template <int BN, int WM, int WTM, int WTN, int SROWS, int MODE, int EPI, int NPH, int MT, int NT, bool RVA = false>
+template <int BN, int WM, int WTM, int WTN, int SROWS, int MODE, int EPI, int NPH, int MT, int NT>
 __device__ __forceinline__ void hdmap_tile_epilogue(const IgemmArgs& a, f32x16 (&acc)[NPH][MT][NT], char* const stg, float* const red, const int wm, const int wn,
                                                     const int lane, const int tid, const bool epi_on, const int m0, const int n0, const int mtile, const int mtiles,
                                                     const int W, const int H)
@@ -64,23 +61,10 @@ __device__ __forceinline__ void hdmap_tile_epilogue(const IgemmArgs& a, f32x16 (
 #pragma unroll
     for (int nj = 0; nj < NT; ++nj) { s1[nj] = 0.f; s2[nj] = 0.f; }
     if (epi_on) {
-    // every load of the epilogue is requested before its first store (a load behind a store would wait for the store) -- or, RVA and form 4,
-    // one copy-out step ahead: the loads of step s + 1 are requested before the stores of step s, so the wait for them covers stores
-    // that are two steps old
+    // every load of the epilogue is requested before its first store (a load behind a store would wait for the store)
     constexpr int SPB = 32 / SROWS, RPS = SROWS / 2;                          // steps per 32-row block, accumulator registers per step
-    float rv[RES ? (RVA ? 2 : MT) : 1][RVA ? RPS : 16][NT];
-    auto resid_step = [&](const int s, const int set) {
-#pragma unroll
-        for (int r8 = 0; r8 < RPS; ++r8) {
-            const int r = (s % SPB) * RPS + r8;
-            const int m = m0 + wm * WTM + (s / SPB) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const unsigned ob = (unsigned)(m < a.M ? m : 0) * (unsigned)a.K + (unsigned)(colw + l31);
-#pragma unroll
-            for (int nj = 0; nj < NT; ++nj) rv[set][r8][nj] = (float)resid[ob + (unsigned)(nj * 32)];
-        }
-    };
-    if constexpr (RES && RVA) resid_step(0, 0);
-    if constexpr (RES && !RVA) {
+    float rv[RES ? MT : 1][16][NT];
+    if constexpr (RES) {
 #pragma unroll
         for (int mi = 0; mi < MT; ++mi)
 #pragma unroll
@@ -96,7 +80,7 @@ __device__ __forceinline__ void hdmap_tile_epilogue(const IgemmArgs& a, f32x16 (
     // Form 2 requests all of its side chunks up front (64 / 128 bytes per lane).  Form 4 has the residual's 64 registers as well: its two
     // side tensors come one copy-out step ahead instead (two register sets; the loads of step s + 1 are requested before the stores
     // of step s, so the wait for them covers stores that are two steps old) -- all up front the eight-wave shapes spilled 26-38 registers
-    constexpr bool AHEAD = EPI == 4 || RVA;
+    constexpr bool AHEAD = EPI == 4;
     constexpr int YSETS = AHEAD ? 2 : (BNB ? NSTEP : 1);
     bf16x8 yv[YSETS][CPL], mv[EPI == 4 ? 2 : 1][CPL];
     f32x8 bsc, bsh, bmu, biv;
@@ -124,7 +108,6 @@ __device__ __forceinline__ void hdmap_tile_epilogue(const IgemmArgs& a, f32x16 (
         const int mi = s / SPB;
         const int yset = AHEAD ? (s & 1) : s;
         if constexpr (BNB && AHEAD) { if (s + 1 < NSTEP) side_chunks(s + 1, (s + 1) & 1); }
-        if constexpr (RES && RVA) { if (s + 1 < NSTEP) resid_step(s + 1, (s + 1) & 1); }
 #pragma unroll
         for (int r8 = 0; r8 < RPS; ++r8) {
             const int r = (s % SPB) * RPS + r8;
@@ -135,7 +118,7 @@ __device__ __forceinline__ void hdmap_tile_epilogue(const IgemmArgs& a, f32x16 (
                 float v = acc[ph][mi][nj][r];
                 if (a.post_scale) v = v * psc[nj] + psh[nj];
                 if (a.bias) v += bia[nj];
-                if constexpr (RES) v += RVA ? rv[s & 1][r8][nj] : rv[mi][r][nj];
+                if constexpr (RES) v += rv[mi][r][nj];
                 if (a.relu) v = fmaxf(v, 0.f);
                 *reinterpret_cast<__bf16*>(stg + lr * SROW_B + (nj * 32 + l31) * 2) = (__bf16)v;
                 if (!BNB && live) { s1[nj] += v; s2[nj] += v * v; }

@@ -54,7 +54,6 @@ enum LbcOpt {
     kOptC64pBm,            // LBC_C64P_BM: tile rows of conv_c64p_k: 256 = eight waves, double-buffered halo, one workgroup per CU; 128 = four waves, ring halo, two per CU; unset = policy
     kOptHdmapSplit,        // LBC_HDMAP_SPLIT: split-K of the four-wave persistent convolution for launches with few tiles (IgemmArgs::split_ws): 0 = never, n > 1 = n ranges wherever they divide the slabs (tests, A/B), unset / 1 = policy (lbc_conv_hdmap_nsplit)
     kOptHdmaSmallBelow,    // LBC_HDMA_SMALL_BELOW: launches whose best eight-wave shape has fewer tiles than this take the four-wave 128 x 64 shape instead where it fits (default 160; 0 = never)
-    kOptHdmaw,             // LBC_HDMAW: 0 = the 256 x 128 halo-staged launches on the eight-wave all-purpose kernel (conv_hdmap_k) instead of the wave-specialised one (conv_hdmaw_k: A/B, tests)
     kOptCount
 };
 long long lbc_opt(LbcOpt o);

@@ -34,7 +34,7 @@ namespace {
 const char* const kOptNames[kOptCount] = {
     "LBC_FORCE_CFG", "LBC_HALO_BLOCKS", "LBC_HEAD_NO_MFMA", "LBC_NO_SIDE_STREAM", "LBC_NO_GEMM256", "LBC_GEMM256_MIN_TILES", "LBC_GEMM256_CFG",
     "LBC_NO_BN_BWD_FUSE", "LBC_NO_HDMA", "LBC_HDMA_CFG", "LBC_NO_GLDS_PHASED", "LBC_HDMA_PERSIST_WGS", "LBC_WGRAD_TR2_MIN_WGS", "LBC_NO_C64P_PRE",
-    "LBC_NO_BN_FOLD", "LBC_C64P_BM", "LBC_HDMAP_SPLIT", "LBC_HDMA_SMALL_BELOW", "LBC_HDMAW"};
+    "LBC_NO_BN_FOLD", "LBC_C64P_BM", "LBC_HDMAP_SPLIT", "LBC_HDMA_SMALL_BELOW"};
 struct OptTable {
     long long v[kOptCount];
     OptTable()

@@ -57,6 +57,13 @@ def main():
             x = torch.randn((N, H, W, C), device=dev).to(at)
             dy = torch.randn((N, OH, OW, K), device=dev).to(at)
             w = torch.randn((K, k, k, C), device=dev) * 0.05
+            # BENCH_OPS_FILL: zero = all-zero operands, relu = activations post-ReLU (half zeros): the chip clocks to its power budget,
+            # so operand values move the launch time (MI355X_MICROARCH.md "DVFS give-back")
+            fill = os.environ.get("BENCH_OPS_FILL", "")
+            if fill == "zero":
+                x, dy, w = x * 0, dy * 0, w * 0
+            elif fill == "relu":
+                x = torch.relu(x)
             wt = torch.empty((C, k * k, K), device=dev)
             y = torch.empty((N, OH, OW, K), device=dev, dtype=at)
             dx = torch.empty((N, H, W, C), device=dev, dtype=at)

@@ -1,11 +1,11 @@
 // In-kernel cycle budget of the wave-specialised persistent halo-staged convolution (conv_hdmaw.hpp) on one ResNet-34 shape, no Python:
 // builds the kernel with LBC_HDMAW_PROF (per-wave s_memtime sums) and, optionally, one of the timing-experiment switches
-//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ilearningbycheating_amd/csrc [-DLBC_HDMAW_ABL_NOMFMA ...] scripts/probe/hdmaw_prof.hip
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -Iinclude -Ilearningbycheating_amd/csrc -Iscripts/probe [-DLBC_HDMAW_ABL_NOMFMA ...] scripts/probe/hdmaw_prof.hip
 //         learningbycheating_amd/csrc/lbc_util.cpp -o scripts/probe/hdmaw_prof[_variant]
-//   scripts/probe/hdmaw_prof [H W C K N]          (default 10 24 256 256 256: layer 3 at batch 256)
+//   scripts/probe/hdmaw_prof [H W C K N fill]     (default 10 24 256 256 256 1: layer 3 at batch 256, random operands; fill 0 = zeros, 2 = half zeros)
 // Prints the launch time (HIP events, 20 launches) and the stamp sums averaged over workgroups, per K-tile.
 #define LBC_HDMAW_PROF 1
-#include "conv_hdmaw.hpp"
+#include "conv_hdmaw.hpp"       // (this directory: the experiment is not part of the library)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -17,12 +17,13 @@ int main(int argc, char** argv)
 {
     const int H = argc > 1 ? atoi(argv[1]) : 10, W = argc > 2 ? atoi(argv[2]) : 24, C = argc > 3 ? atoi(argv[3]) : 256, K = argc > 4 ? atoi(argv[4]) : 256;
     const int N = argc > 5 ? atoi(argv[5]) : 256;
+    const int fill = argc > 6 ? atoi(argv[6]) : 1;       // operands: 0 zeros, 1 uniform (-0.5, 0.5), 2 the activations half zeros (post-ReLU-like)
     const int M = N * H * W;
     std::vector<unsigned short> hx((size_t)M * C), hw((size_t)K * 9 * C);
     unsigned s = 12345u;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; const float f = ((s >> 8) & 0xffff) / 65536.f - 0.5f; return (unsigned short)(__builtin_bit_cast(unsigned, f) >> 16); };
-    for (auto& v : hx) v = rnd();
-    for (auto& v : hw) v = rnd();
+    for (auto& v : hx) { v = rnd(); if (fill == 0 || (fill == 2 && (v & 0x8000))) v = 0; }
+    for (auto& v : hw) { v = rnd(); if (fill == 0) v = 0; }
     void *x, *w, *y, *zero;
     CK(hipMalloc(&x, hx.size() * 2)); CK(hipMalloc(&w, hw.size() * 2)); CK(hipMalloc(&y, (size_t)M * K * 2)); CK(hipMalloc(&zero, 256));
     CK(hipMemcpy(x, hx.data(), hx.size() * 2, hipMemcpyHostToDevice)); CK(hipMemcpy(w, hw.data(), hw.size() * 2, hipMemcpyHostToDevice));
@@ -36,8 +37,8 @@ int main(int argc, char** argv)
     const unsigned grid = (unsigned)lbc_cdiv(ntiles, tpw);
     const bool big = 256 + 2 * W + 2 > 320 - 8;
     auto launch = [&]() {
-        return big ? conv_hdmaw_launch_shape<256, 128, 384, 16>(a, 0, zero, ntiles, tpw, dim3(grid), nullptr)
-                   : conv_hdmaw_launch_shape<256, 128, 320, 32>(a, 0, zero, ntiles, tpw, dim3(grid), nullptr);
+        return big ? conv_hdmaw_launch_shape<256, 128, 368>(a, 0, zero, ntiles, tpw, dim3(grid), nullptr)
+                   : conv_hdmaw_launch_shape<256, 128, 320>(a, 0, zero, ntiles, tpw, dim3(grid), nullptr);
     };
     for (int i = 0; i < 3; ++i) if (launch()) { fprintf(stderr, "launch failed\n"); return 1; }
     CK(hipDeviceSynchronize());
@@ -54,7 +55,7 @@ int main(int argc, char** argv)
     std::vector<unsigned long long> p(256 * 8 * 4);
     CK(hipMemcpyFromSymbol(p.data(), HIP_SYMBOL(g_hdmaw_prof), p.size() * 8));
     const int ktiles = tpw * 9 * (C / 64);
-    printf("H %d W %d C %d K %d N %d: %d tiles, %d per workgroup, %u workgroups, %d K-tiles per workgroup\n", H, W, C, K, N, ntiles, tpw, grid, ktiles);
+    printf("fill %d; H %d W %d C %d K %d N %d: %d tiles, %d per workgroup, %u workgroups, %d K-tiles per workgroup\n", fill, H, W, C, K, N, ntiles, tpw, grid, ktiles);
     printf("launch %.1f us = %.0f TF/s\n", us, flop / us * 1e-6);
     double c[4] = {0, 0, 0, 0}, l[4] = {0, 0, 0, 0}, cmax = 0;
     const unsigned full = (unsigned)(ntiles / tpw);      // workgroups with a full tile count

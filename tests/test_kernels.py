@@ -608,17 +608,8 @@ def test_conv_hdma_fwd_dgrad(env, case, lbc_config):
         assert rows.value in ([-(-M // HDMA_BM[cfgid])] if cfgid >= 0 else [-(-M // b) for b in (128, 256)]), (rows.value, M)
     y, st = Conv(dev).fwd(x, w, 1, 1, stats=True, bf16=3)
     assert relerr(y, ref) < 1e-4 + OUT_TOL[2]
-    # Statistics rows: the all-purpose kernels sum the f32 accumulator; the wave-specialised 256 x 128 kernel (conv_hdmaw_k, round 6) sums the
-    # STORED, bf16-rounded value in its chunk phase -- exactly the tensor the following BatchNorm pass normalises.  So either the sums match
-    # the f32 convolution tightly, or they match the sums of the returned tensor even more tightly AND the f32 convolution within the
-    # accumulated rounding noise of the tensor (each element off by at most 2^-9 of its magnitude)
-    s1, s2 = st[:, 0].sum(0), st[:, 1].sum(0)
-    yf = y.float()
-    of_accumulator = torch.allclose(s1, ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2) and torch.allclose(s2, (ref * ref).sum((0, 2, 3)), rtol=1e-3)
-    noise = 2.0 ** -9 * ref.abs().sum((0, 2, 3))
-    of_stored = (torch.allclose(s1, yf.sum((0, 2, 3)), rtol=1e-5, atol=1e-3) and torch.allclose(s2, (yf * yf).sum((0, 2, 3)), rtol=1e-5) and
-                 bool(((s1 - ref.sum((0, 2, 3))).abs() <= noise + 1e-2).all()) and torch.allclose(s2, (ref * ref).sum((0, 2, 3)), rtol=4e-3))
-    assert of_accumulator or of_stored, (s1 - ref.sum((0, 2, 3))).abs().max()
+    assert torch.allclose(st[:, 0].sum(0), ref.sum((0, 2, 3)), rtol=1e-3, atol=1e-2)
+    assert torch.allclose(st[:, 1].sum(0), (ref * ref).sum((0, 2, 3)), rtol=1e-3)
     g = torch.Generator().manual_seed(291)
     r = rbf(torch.randn(ref.shape, generator=g))
     y2, _ = Conv(dev).fwd(x, w, 1, 1, resid=r, relu=1, bf16=3)
