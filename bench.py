@@ -238,10 +238,10 @@ def self_spawn(args):
 
 
 def read_traffic():
-    """HBM bytes per launch of the convolution family from the committed PMC passes of THIS round's code: profiles/r05_pmc_traffic.json,
+    """HBM bytes per launch of the convolution family from the committed PMC passes of THIS round's code: profiles/r06_pmc_traffic.json,
     written by scripts/pmc_traffic.py from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of scripts/gpu_evidence.sh (counters need
     their own runs: they cannot be collected inside this process); an older round's file is a fallback and says so in its `source`"""
-    for name in ("r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
+    for name in ("r06_pmc_traffic.json", "r05_pmc_traffic.json", "r04_pmc_traffic.json", "r03_pmc_traffic.json", "r02_pmc_traffic.json"):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             try:
@@ -438,6 +438,11 @@ def main():
             gb = sum(v["gbyte"] for v in conv.values())
             roof["algorithmic_bytes_per_launch"] = round(gb * 1e9 / max(n, 1))
             roof["traffic_over_algorithmic"] = round(roof["traffic"] * max(n, 1) / (gb * 1e9), 3) if gb and roof["traffic"] else None
+            # round 4's definition of the algorithmic bytes (the side tensors of the fused BatchNorm-backward launches not counted): kept next to
+            # the current one so that the ratio stays comparable across rounds
+            side = br.get("side_tensors_of_fused_reduce", {}).get("gbyte", 0.0)
+            roof["algorithmic_bytes_per_launch_without_fused_side_tensors"] = round((gb - side) * 1e9 / max(n, 1))
+            roof["traffic_over_algorithmic_without_fused_side_tensors"] = round(roof["traffic"] * max(n, 1) / ((gb - side) * 1e9), 3) if gb - side > 0 and roof["traffic"] else None
             roof["traffic_kernel"] = t.get("kernel")
             roof["traffic_source"] = t.get("source")
         bn = {k: v for k, v in br.items() if k in ("bn_apply", "bn_bwd_reduce", "bn_bwd_apply", "channel_stats")}
@@ -450,7 +455,7 @@ def main():
 
     tr, dt, loss_mean = timed_run(dtype, args.steps, args.warmup)
     # the ranks the gradient buckets really travel between: a one from every rank summed on the buckets' own communicator and stream
-    rccl_ranks = tr.reducer.participants() if world > 1 else None
+    comm_ranks = tr.reducer.participants() if world > 1 else None        # read back from the buckets' communicator, whatever its backend
     roof, hbm, breakdown = instrumented_step(tr, dtype)
     if rank == 0 and args.breakdown:
         os.makedirs(os.path.dirname(os.path.abspath(args.breakdown)), exist_ok=True)
@@ -467,7 +472,7 @@ def main():
                "n_gpus": world, "world_size": dist.get_world_size() if world > 1 else 1,
                # ranks of the communicator the gradient buckets actually travelled on, read back from it (StageAllReducer.participants;
                # None: one process, nothing travels); `comm_backend` says whether that communicator is RCCL
-               "rccl_ranks": rccl_ranks, "comm_backend": (("rccl" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None),
+               "comm_ranks": comm_ranks, "comm_backend": (("rccl" if args.dist_backend == "nccl" else args.dist_backend) if world > 1 else None),
                "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": round(1e3 * dt / args.steps, 3),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": dtype, "data": "synthetic",

@@ -28,7 +28,10 @@ const char* lbc_backend(void);   /* "hip-gfx950" for the product library */
 /* ABI version of THIS header; lbc_version() returns the one the library was built with -- a host compares the two at load time.
  * 100: rounds 1-3.  101: lbc_conv_desc grew split_workspace / split_workspace_bytes (round 4; the library still answered 100).
  * 200: lbc_conv_desc starts with struct_size, which every entry point checks (a descriptor from an older header, or one that was not
- *      initialised, is refused with LBC_EINVAL instead of being read past); lbc_adam_profile_elems. */
+ *      initialised, is refused with LBC_EINVAL instead of being read past); lbc_adam_profile_elems.  Accepted: every struct_size from the
+ *      ABI-200 layout (through split_workspace_bytes) up to the library's own sizeof -- fields appended later are optional for older hosts.
+ * The size_t-returning *_workspace() queries and the int-returning *_supported() queries answer 0 for "none / no" AND for a refused
+ * descriptor: a host that gets 0 checks lbc_last_error() (empty = a genuine 0), as tests/c_host/host.c does. */
 #define LBC_HIP_ABI_VERSION 200
 int lbc_version(void);
 
@@ -319,8 +322,9 @@ int lbc_augment_rgb_u8(unsigned char* images, const lbc_aug_params* params_dev, 
                        lbc_stream_t stream);
 
 /* Runtime options (A/B switches, tuning knobs, test hooks): names are the LBC_* environment variables that initialise the
- * table at load time; -1 = unset.  Options read when a network is created (LBC_NO_FUSE_Z1,
- * LBC_DGRAD_WT, LBC_NO_SIDE_STREAM) apply to networks created afterwards. */
+ * table at load time; -1 = unset.  The one option read when a network is created (LBC_NO_SIDE_STREAM) applies to
+ * networks created afterwards.  An LBC_* environment variable that is not in the table (a switch of an earlier round, a typo) is reported
+ * on stderr when the library loads -- it would otherwise be ignored silently and an A/B script would measure nothing. */
 int lbc_config_set(const char* name, long long value);
 long long lbc_config_get(const char* name);
 

@@ -1,6 +1,7 @@
 // C-ABI entry points (include/lbc_hip.h) over the internal launchers.
 #include "lbc_common.hpp"
 #include "lbc_hip.h"
+#include <stddef.h>
 #include <string.h>
 
 extern "C" {
@@ -15,14 +16,17 @@ const char* lbc_backend(void)
 }
 int lbc_version(void) { return LBC_HIP_ABI_VERSION; }
 
-// Every entry point that takes a descriptor checks it came from THIS header: a host built against an older lbc_hip.h (the struct grew
-// in ABI 101: split_workspace) or one that forgot LBC_CONV_DESC_INIT passes a struct the library would read past / read garbage from
+// Every entry point that takes a descriptor checks it: struct_size must cover the fields of the first checked layout (ABI 200: everything up to
+// and including split_workspace_bytes) and must not exceed this library's struct.  A host built against an OLDER header of the same major
+// ABI (fewer trailing fields) stays valid: whoever appends a field must read it only where struct_size covers it (today the checked
+// layout IS the struct: the two bounds coincide).  A host that forgot LBC_CONV_DESC_INIT (struct_size 0 / garbage) is refused.
+static const unsigned kDescMinSize = (unsigned)(offsetof(lbc_conv_desc, split_workspace_bytes) + sizeof(((lbc_conv_desc*)0)->split_workspace_bytes));
 static bool desc_ok(const lbc_conv_desc* d, const char* who)
 {
     if (!d) { lbc_set_error("%s: null descriptor", who); return false; }
-    if (d->struct_size != sizeof(lbc_conv_desc)) {
-        lbc_set_error("%s: lbc_conv_desc.struct_size is %u, this library (ABI %d) expects %zu -- initialise the descriptor with LBC_CONV_DESC_INIT "
-                      "and rebuild the host against this library's lbc_hip.h", who, d->struct_size, LBC_HIP_ABI_VERSION, sizeof(lbc_conv_desc));
+    if (d->struct_size < kDescMinSize || d->struct_size > sizeof(lbc_conv_desc)) {
+        lbc_set_error("%s: lbc_conv_desc.struct_size is %u, this library (ABI %d) accepts %u .. %zu -- initialise the descriptor with LBC_CONV_DESC_INIT "
+                      "and build the host against a lbc_hip.h of this ABI", who, d->struct_size, LBC_HIP_ABI_VERSION, kDescMinSize, sizeof(lbc_conv_desc));
         return false;
     }
     return true;

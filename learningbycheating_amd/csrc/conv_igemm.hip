@@ -583,6 +583,9 @@ int lbc_igemm_launch(const IgemmArgs& a, int wmajor, int mode, int cfg, hipStrea
                       // (+ the side tensors of the fused BatchNorm-backward reduce: the pre-BatchNorm activation, and in the tensor-masked form the ReLU output)
                       (a.act_bf16 ? 2.0 : 4.0) * (in_elems + nph * (double)a.M * a.K * (1 + (a.resid ? 1 : 0) + (a.bnb_y ? 1 : 0) + (a.bnb_mask ? 1 : 0))) +
                           (a.w_bf16 ? 2.0 : 4.0) * taps * nph * a.C * a.K, s);
+    // (round 4's definition of a launch's algorithmic bytes did not count those side tensors: booked separately so that bench.py reports both ratios)
+    if (lbc_prof_on() && (a.bnb_y || a.bnb_mask))
+        lbc_prof_note("side_tensors_of_fused_reduce", (a.act_bf16 ? 2.0 : 4.0) * nph * (double)a.M * a.K * ((a.bnb_y ? 1 : 0) + (a.bnb_mask ? 1 : 0)));
     if (cfg >= kLbcCfgHdma) {
         LBC_REQUIRE(wmajor && lbc_conv_hdma_pick(a, mode) >= 0, "igemm: launch not eligible for the halo-staged LDS-DMA kernel");
         return lbc_conv_hdma_launch(a, mode, cfg, s);

@@ -115,7 +115,6 @@ Net::Net(const lbc_net_desc& d) : d_(d)
             // z1 = relu(bn1(y1)): applied on load by its three consumers (never written), unless conv2 would then lose the LDS-DMA
             // kernel (conv_glds.hip cannot transform what it stages): there one bn_apply pass (read + write 2 bytes per element)
             // costs less than the register-staged convolution does (batch 256: layer 2 144 -> 95 + 29 us, layer 3 120 -> 72 + 14 us)
-            // (with LBC_HDMA_PROLOGUE=1 the halo-staged kernel applies bn1 itself: fused again)
             // (the 64-channel layer keeps bn1 on load: conv_halo.hip transforms its register-staged halo for free, while the LDS-DMA kernel
             //  for that layer -- conv_c64p.hip -- would need the extra pass; its other launches take that kernel)
             b.fuse_z1 = planes == 64 || !conv_takes_glds(b.c2, (int)NB) || conv_takes_glds(b.c2, (int)NB, true);
@@ -848,6 +847,10 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
         //  pass in its epilogue, bwd_pre_rows_ rows of sums in partial_)
         const int pre_rows = bwd_pre_rows_;
         bwd_pre_rows_ = 0;
+        // (partial_ is LIVE across the block boundary then: nothing may write it between the producing conv_dgrad of the block behind this
+        //  one and the bn_backward below, and the sums were taken over THIS block's bn2 extent -- checked, not assumed)
+        LBC_REQUIRE(pre_rows == 0 || (bwd_pre_pix_ == pix && bwd_pre_C_ == b.b2.C), "net.backward: pre-reduced rows of %lld x %d do not match this block's bn2 (%lld x %d)",
+                    bwd_pre_pix_, bwd_pre_C_, pix, b.b2.C);
         LBC_TRY(bn_backward(b.b2, D, W(b.out), D, W(b.c2.y), pix, E2, b.b2.C, s, nullptr, false, pre_rows));   // E2 = dY2
         int fr = 0;
         LBC_TRY(conv_dgrad(b.c2, E2, nullptr, F, N, s, &b.b1, W(b.c1.y), &fr));                       // F = dZ1 (masked when fr > 0)
@@ -868,6 +871,7 @@ int Net::block_backward(Block& b, float*& D, float*& Gbuf, float* E, float* F, h
             if (pb) LBC_TRY(conv_dgrad(b.c1, E1, D, Gbuf, N, s, &pb->b2, W(pb->c2.y), &pr, W(pb->out)));
             else    LBC_TRY(conv_dgrad(b.c1, E1, D, Gbuf, N, s));
             bwd_pre_rows_ = pr;
+            if (pr > 0) { bwd_pre_pix_ = (long long)N * pb->c2.OH * pb->c2.OW; bwd_pre_C_ = pb->b2.C; }
         } else {
             float* Fd = dy_slot(pix * b.bd.C);
             LBC_REQUIRE(Fd, "net.backward: dY arena exhausted");

@@ -201,6 +201,7 @@ private:
     int lastN_ = 0;
     int last_train_ = 0;
     float* bwd_D_ = nullptr;   // running "gradient wrt block output" buffer between stages
+    long long bwd_pre_pix_ = 0; int bwd_pre_C_ = 0;   // ... what those rows were summed over (pixels, channels of the consuming block's bn2): checked by the consumer
     int bwd_pre_rows_ = 0;     // > 0: the gradient in bwd_D_ is already masked with its block's ReLU output and partial_ holds that many rows of bn2's backward sums (the producing input gradient did both: IgemmArgs::bnb_mask)
     float* bwd_G_ = nullptr;
 };

@@ -65,6 +65,7 @@ static inline bool lbc_opt_on(LbcOpt o) { return lbc_opt(o) == 1; }
 bool lbc_prof_on();
 void lbc_prof_begin(const char* name, double flops, double bytes, hipStream_t s);
 void lbc_prof_end(hipStream_t s);
+void lbc_prof_note(const char* name, double bytes);
 struct LbcProfScope {
     hipStream_t s; bool on;
     LbcProfScope(const char* name, double flops, double bytes, hipStream_t st) : s(st), on(lbc_prof_on()) {
@@ -218,7 +219,7 @@ int lbc_wgrad_tr_launch(const WgradArgs& a, hipStream_t s);
 constexpr int kLbcWgradGroupMax = 12;
 struct WgradGroup {
     int n;
-    int linear_order;       // 1: workgroup id = logical id (A/B: LBC_WGRAD_TR_LINEAR); 0: XCD-major logical order
+    int linear_order;       // 1: workgroup id = logical id (tests / A/B scripts set it through the C ABI); 0: XCD-major logical order
     const void* p[kLbcWgradGroupMax];
     const void* q[kLbcWgradGroupMax];
     const float* q_scale[kLbcWgradGroupMax];

@@ -29,6 +29,7 @@ extern "C" const char* lbc_last_error(void) { return g_err; }
 // ---- runtime options -----------------------------------------------------------------
 #include <stdlib.h>
 #include <mutex>
+extern "C" char** environ;      // (POSIX; <unistd.h> declares it only under _GNU_SOURCE)
 #include <string.h>
 namespace {
 const char* const kOptNames[kOptCount] = {
@@ -42,6 +43,16 @@ struct OptTable {
         for (int i = 0; i < kOptCount; ++i) {
             const char* e = getenv(kOptNames[i]);
             v[i] = (e && *e) ? atoll(e) : -1;
+        }
+        // an LBC_* variable that is no option (a switch removed in an earlier round, a typo) would be ignored silently: say so once.
+        // (LBC_PROF_LAUNCHES is the launch profiler's, read where it reports; LBC_PIN_STAGING the Python loader's; LBC_ARCH / LBC_BUILD_* the build scripts', LBC_TEST_* / LBC_EMU_* the test suite's and the CPU emulator's.)
+        for (char** ep = environ; ep && *ep; ++ep) {
+            if (strncmp(*ep, "LBC_", 4)) continue;
+            const char* eq = strchr(*ep, '=');
+            const size_t n = eq ? (size_t)(eq - *ep) : strlen(*ep);
+            bool known = (n == 17 && !strncmp(*ep, "LBC_PROF_LAUNCHES", n)) || (n == 15 && !strncmp(*ep, "LBC_PIN_STAGING", n)) || !strncmp(*ep, "LBC_ARCH", 8) || !strncmp(*ep, "LBC_BUILD_", 10) || !strncmp(*ep, "LBC_TEST_", 9) || !strncmp(*ep, "LBC_EMU_", 8);
+            for (int i = 0; i < kOptCount && !known; ++i) known = strlen(kOptNames[i]) == n && !strncmp(*ep, kOptNames[i], n);
+            if (!known) fprintf(stderr, "liblbc_hip: environment variable %.*s is not an option of this library (ignored); see include/lbc_hip.h, lbc_config_set\n", (int)n, *ep);
         }
     }
 };
@@ -104,6 +115,15 @@ void lbc_prof_begin(const char* name, double flops, double bytes, hipStream_t s)
     g_recs.push_back(r);
 }
 void lbc_prof_end(hipStream_t s) { if (!g_recs.empty()) (void)hipEventRecord(g_recs.back().e1, s); }
+// a byte count booked under a class of its own, no events (reported with 0 launches' worth of time): what part of a launch's algorithmic bytes
+// an older definition did not count (bench.py keeps both traffic ratios on its line so that rounds stay comparable)
+void lbc_prof_note(const char* name, double bytes)
+{
+    ProfRec r;
+    r.name = name; r.flops = 0.0; r.bytes = bytes; r.e0 = nullptr; r.e1 = nullptr;
+    // (in FRONT of the record of the launch scope that is open around the caller: lbc_prof_end closes g_recs.back())
+    if (g_recs.empty()) g_recs.push_back(r); else g_recs.insert(g_recs.end() - 1, r);
+}
 
 extern "C" int lbc_profile_enable(int on)
 {
@@ -120,14 +140,16 @@ extern "C" int lbc_profile_report(char* buf, int cap)
     const char* per_launch = getenv("LBC_PROF_LAUNCHES");
     FILE* pl = (per_launch && *per_launch) ? fopen(per_launch, "a") : nullptr;
     for (ProfRec& r : g_recs) {
-        (void)hipEventSynchronize(r.e1);
         float ms = 0.f;
-        (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        if (r.e0) {
+            (void)hipEventSynchronize(r.e1);
+            (void)hipEventElapsedTime(&ms, r.e0, r.e1);
+        }
         if (!agg.count(r.name)) order.push_back(r.name);
         Agg& a = agg[r.name];
         a.n++; a.ms += ms; a.flops += r.flops; a.bytes += r.bytes;
         if (pl) fprintf(pl, "%s %.6f %.6e %.6e\n", r.name, ms, r.flops, r.bytes);
-        (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1);
+        if (r.e0) { (void)hipEventDestroy(r.e0); (void)hipEventDestroy(r.e1); }
     }
     if (pl) fclose(pl);
     g_recs.clear();

@@ -72,7 +72,7 @@ class StageAllReducer:
 
     def participants(self):
         """how many ranks the buckets' communicator really joins: a one from every rank, summed on the path the buckets take (same
-        group, same stream, the staging dtype if there is one).  bench.py reports it as `rccl_ranks` -- read back from the communicator,
+        group, same stream, the staging dtype if there is one).  bench.py reports it as `comm_ranks` -- read back from the communicator,
         not from the launcher's environment"""
         if not self.active:
             return 1

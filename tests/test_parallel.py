@@ -90,7 +90,7 @@ def _reduce_worker(rank, world, port, q, grad_dtype=None):
     for st in range(6):
         red.launch(st)
     red.wait()
-    ranks_seen = red.participants()       # read back from the buckets' communicator (bench.py's `rccl_ranks`)
+    ranks_seen = red.participants()       # read back from the buckets' communicator (bench.py's `comm_ranks`)
     # initial weights: rank 0's values everywhere, including the channels_last 4-D tensors
     from learningbycheating_amd.parallel import broadcast_module
     from learningbycheating_amd.bird_view.models import BirdViewPolicyModelSS
