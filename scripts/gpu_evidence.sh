@@ -1,10 +1,10 @@
 #!/bin/bash
-# Evidence of the shipped code, ONE gpurun call (ROUND=r05 by default; the results are copied to profiles/${ROUND}_final_* afterwards):
+# Evidence of the shipped code, ONE gpurun call (ROUND=r06 by default; the results are copied to profiles/${ROUND}_final_* afterwards):
 # driver-default bench + breakdown, the per-GPU loads of 2 / 4 / 8 GPUs, BASELINE configs 2 / 4 / 5, the kernel-only (device-resident batch) rate,
 # SERIALIZED rocprofv3 kernel stats (no side streams: per-kernel durations are those of kernels running alone), three PMC passes (MFMA busy,
 # FETCH_SIZE, WRITE_SIZE) -> ${ROUND}_pmc_traffic.json, LDS bank-conflict pass, per-launch tables, kernel-trace gap analysis.
 # PHASES (default "bench prof pmc tables"): add "tests" for the full GPU test suite + smoke in the same call.
-cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out; R=gpurun_out; ROUND=${ROUND:-r05}
+cd "${GRAFT_REPO_ROOT:-/root/repo}"; export TMPDIR=/tmp; mkdir -p gpurun_out; R=gpurun_out; ROUND=${ROUND:-r06}
 PHASES="${PHASES:-bench prof pmc tables}"
 S=$R/summary.txt; echo "== $(date) phases: $PHASES" > $S
 if [[ "$PHASES" == *bench* ]]; then
@@ -19,17 +19,19 @@ if [[ "$PHASES" == *bench* ]]; then
     echo "$WLD: $(tail -1 $R/bench_$WLD.log | cut -c1-220)" >> $S
   done
 fi
-if [[ "$PHASES" == *bench* && -d scratch_r04 ]]; then
-  # boxes of the pool differ by up to 10 %: the previous round's tree (git archive of its last commit, built in scratch_r04/, not tracked)
+if [[ "$PHASES" == *bench* && -d scratch_prev ]]; then
+  # boxes of the pool differ by up to 10 %: the previous round's tree (git archive of its last commit, built in scratch_prev/, not tracked)
   # on THIS box next to the shipped code, one device-resident batch re-fed every step (the one input mode both trees have)
   pj() { python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['ms_per_step'], 'ms', d['value'], 'img/s')" 2>&1 | tail -1; }
   for B in 256 32; do
     for rep in 1 2; do
-      (cd scratch_r04 && timeout 300 python bench.py --resident --global-batch $B --steps 40 --warmup 10 --no-cpu-baseline --no-alt 2>/dev/null | tail -1 | pj) > $R/ab_prev_b${B}_$rep.txt 2>&1
+      (cd scratch_prev && timeout 300 python bench.py --resident --global-batch $B --steps 40 --warmup 10 --no-cpu-baseline --no-alt 2>/dev/null | tail -1 | pj) > $R/ab_prev_b${B}_$rep.txt 2>&1
       (timeout 300 python bench.py --resident --global-batch $B --steps 40 --warmup 10 --no-cpu-baseline --no-alt 2>/dev/null | tail -1 | pj) > $R/ab_head_b${B}_$rep.txt 2>&1
       echo "same box, $B images, run $rep: previous round's tree $(cat $R/ab_prev_b${B}_$rep.txt) | shipped code $(cat $R/ab_head_b${B}_$rep.txt)" >> $S
     done
   done
+  # ... and the exact-f32 path (the one held to the 1e-3 waypoint bar), both trees, one run each
+  echo "same box, 256 images, exact f32: previous round's tree $(cd scratch_prev && timeout 400 python bench.py --resident --dtype f32 --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>/dev/null | tail -1 | pj) | shipped code $(timeout 400 python bench.py --resident --dtype f32 --steps 10 --warmup 3 --no-cpu-baseline --no-alt 2>/dev/null | tail -1 | pj)" >> $S
 fi
 if [[ "$PHASES" == *prof* ]]; then
   rm -rf $R/prof
