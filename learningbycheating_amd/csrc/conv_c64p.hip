@@ -48,15 +48,12 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
     constexpr bool RING = BMv == 128;
     constexpr int NWAVES = WM * WN, NBUF = RING ? 1 : 2;
     constexpr int R = 456;                                      // ring rows (RING): >= BM + halo rows = 128 + 322, a multiple of 8
-    constexpr int HRMAX = RING ? R + 2 : 456;                   // rows per buffer; RING: the ring + the two zero rows.  BM + 2 W + 2 < 456 - 128 resp. 456 <=> W <= 98
+    constexpr int HRMAX = RING ? R + 1 : 456;                   // rows per buffer; RING: the ring + the zero row.  BM + 2 W + 2 < 456 - 128 resp. 456 <=> W <= 98
     constexpr int NP = (RING ? 328 : HRMAX) / 8;                // 1-KiB halo pieces of a WHOLE halo (57 / 41: RING requests them for its first tile only)
     constexpr int PPW = (NP + NWAVES - 1) / NWAVES;             // ... per wave (8 / 11; the last wave has fewer)
     constexpr int NPN = BM / 8 + 1, PPN = (NPN + NWAVES - 1) / NWAVES;   // RING: pieces that hold a tile's BM new rows (17: the range is not piece-aligned), per wave (5)
     constexpr int ABYTES = HRMAX * 128;
-    // the ZERO ROWS of the border select: two rows = one 256-byte bank period (a border lane reads the zero at its own row's position inside
-    // the period and stays on the banks its own row would have used: conflict-free like the unmasked read -- conv_hdmap.hpp, tap_addr)
-    constexpr int ZROW2 = RING ? R * 128 : (HRMAX - 2) * 128;
-    static_assert(ZROW2 % 256 == 0 && ABYTES % 256 == 0, "conv_c64p: zero rows on a bank period");
+    constexpr int ZROW = RING ? R * 128 : (HRMAX - 1) * 128;
     constexpr int SROWS = (RING && EPI != 0) ? 8 : 16, SROW_B = 32 * 2 + 16;   // staged rows per copy-out step (8 where the side tile leaves no room for 16), their LDS pitch (32 bf16 + 16 bytes)
     constexpr int STG = NBUF * ABYTES;                          // wave-private staging: NWAVES x SROWS x SROW_B
     constexpr int RED = STG + NWAVES * SROWS * SROW_B;          // [2][WM][2][BN] floats
@@ -142,7 +139,7 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
 
     // the first tile's halo
     if constexpr (RING) {
-        if (tid < 16) *reinterpret_cast<f32x4*>(smem + ZROW2 + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};    // the zero rows of the border select (visible behind the first barrier)
+        if (tid < 8) *reinterpret_cast<f32x4*>(smem + ZROW + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};     // the zero row of the border select (visible behind the first barrier)
 #pragma unroll
         for (int j = 0; j < PPW; ++j)
             if (wave * PPW + j < NP) issue_ring(wave * PPW + j, 0, BM + 2 * W + 2);
@@ -235,7 +232,7 @@ __global__ __launch_bounds__(BMv * 2, 2) void conv_c64p_k(IgemmArgs a, const voi
             for (int i = 0; i < MT; ++i) {
                 int hr = rowc[i] + off;
                 if constexpr (RING) { hr += rbase; hr = hr >= R ? hr - R : hr; }
-                const int val = (hr << 7) | ((kh ^ ((hr >> 1) & 7)) << 4), zval = ZROW2 | (val & 255);
+                const int val = (hr << 7) | ((kh ^ ((hr >> 1) & 7)) << 4), zval = ZROW | (kh << 4);
                 const int m = -((amask[i] >> tap) & 1);
                 aaddr[i] = abuf + (((val ^ zval) & m) ^ zval);
             }

@@ -697,10 +697,8 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_rows_k(StemArgs a, int ntiles
         br[q] = idx / BD;
         bj[q] = idx - br[q] * BD;
     }
-    // (round 6) the bands of the NEXT TWO tiles are in flight while one is multiplied: a tile is 14 / 28 MFMAs per wave (~0.3 - 0.5 us), one band
-    // ahead left every workgroup waiting a full HBM latency per tile (2.8 / 3.8 us per tile, 3.0 TB/s, profiles/r05_final_*)
-    unsigned regs[NLD], regs2[NLD];
-    auto band_load = [&](int tile, unsigned (&dst)[NLD]) {
+    unsigned regs[NLD];
+    auto band_load = [&](int tile) {
         const int xt = tile % tiles_x;
         const int t2 = tile / tiles_x;
         const int oy = t2 % OH, n = t2 / OH;
@@ -709,7 +707,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_rows_k(StemArgs a, int ntiles
         for (int q = 0; q < NLD; ++q) {
             const long long e = e0 + (long long)br[q] * Wp * CIN + 2 * bj[q];
             const bool ok = br[q] < 7 && e + 1 < total_elems;      // past the tensor only behind the last tile's last pixels
-            dst[q] = ok ? *reinterpret_cast<const unsigned*>(xpad + e) : 0u;
+            regs[q] = ok ? *reinterpret_cast<const unsigned*>(xpad + e) : 0u;
         }
     };
     auto band_store = [&](int buf) {
@@ -732,15 +730,14 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_rows_k(StemArgs a, int ntiles
         tile = logical * per;
         tend = tile + per < ntiles ? tile + per : ntiles;
     }
-    if (tile < tend) band_load(tile, regs);
+    if (tile < tend) band_load(tile);
     __syncthreads();                                           // the zero fill above is complete
     if (tile < tend) band_store(0);
-    if (tile + 1 < tend) band_load(tile + 1, regs);
     __syncthreads();
     for (; tile < tend; ++tile, ++it) {
         const int buf = it & 1;
         const int next = tile + 1 < tend ? tile + 1 : ntiles;
-        if (tile + 2 < tend) band_load(tile + 2, regs2);
+        if (next < ntiles) band_load(next);
         const int xt = tile % tiles_x;
         const int t2 = tile / tiles_x;
         const int oy = t2 % OH, n = t2 / OH;
@@ -767,9 +764,7 @@ __global__ __launch_bounds__(256, 2) void stem_fwd_rows_k(StemArgs a, int ntiles
             Act<T>::st1(&sOut[prow * OLD + col], v);
             if (ox0 + prow < OW) { s1 += v; s2 += v * v; }
         }
-        if (next < ntiles) band_store(buf ^ 1);                // (the band of tile + 1: requested a whole tile ago; tile + 2's stays in flight)
-#pragma unroll
-        for (int q = 0; q < NLD; ++q) regs[q] = regs2[q];
+        if (next < ntiles) band_store(buf ^ 1);
         __syncthreads();
         {
             constexpr int EPT = 16;                            // elements per thread: 64 x 64 / 256

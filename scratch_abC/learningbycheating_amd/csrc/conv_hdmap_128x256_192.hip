@@ -1,0 +1,7 @@
+// conv_hdmap.hpp instantiated for one tile shape (see conv_hdmap.hip)
+#include "conv_hdmap.hpp"
+
+int lbc_conv_hdmap_launch_128x256_192(const IgemmArgs& a, int mode, const void* zero, int ntiles, int tpw, unsigned grid, hipStream_t s)
+{
+    return conv_hdmap_launch_shape<128, 256, 2, 4, 192, 8>(a, mode, zero, ntiles, tpw, dim3(grid), s);
+}
