@@ -1,5 +1,5 @@
 """Registers / spills / scratch / LDS per kernel of one HIP translation unit (hipcc -Rpass-analysis=kernel-resource-usage).
-usage: python scripts/kernel_resources.py learningbycheating_amd/csrc/conv_hdmaw_256x128_320.hip [name filter]"""
+usage: python scripts/kernel_resources.py learningbycheating_amd/csrc/conv_hdmap_256x128_320.hip [name filter]"""
 import re, subprocess, sys, os
 
 def main():
